@@ -1,0 +1,125 @@
+"""Pins the CPU oracle against golden vectors produced by the reference itself
+(tests/golden/make_golden.py).  CPU only.  Tolerance: 1e-6 abs (the vectors were
+bit-identical when generated; the slack covers a different BLAS thread count)."""
+import torch
+
+from oracle import tacotron_oracle as O
+
+TOL = 1e-6
+
+
+def _dims(g):
+    d = g["meta"]["small_dims"]
+    return O.DecoderDims(d_mel=d["d_mel"], r=d["r"], d_pre=d["d_pre"], d_ctx=d["d_ctx"], h_att=d["h_att"], h_dec=d["h_dec"])
+
+
+def _close(a, b, tol=TOL):
+    assert a.shape == b.shape, (a.shape, b.shape)
+    err = float((a - b).abs().max())
+    assert err <= tol, err
+
+
+def test_memory_padding_rows_are_zero(golden):
+    mem, lens = golden["memory"], golden["lengths"]
+    for b, n in enumerate(lens.tolist()):
+        assert float(mem[b, n:].abs().max()) == 0.0 if n < mem.shape[1] else True
+
+
+def test_decode_inference(golden):
+    c, m = golden["cases"], golden["meta"]["infer"]
+    y, s, w = O.decode(golden["dec"], _dims(golden), golden["memory"], max_steps=m["max_steps"], masks=c["infer/masks"])
+    assert y.shape[1] == m["T"] == m["max_steps"] + 1
+    _close(y, c["infer/y"])
+    _close(s, c["infer/s"])
+    _close(w, c["infer/w"])
+    assert torch.equal(w.argmax(-1), c["infer/w"].argmax(-1))
+    yp = O.mel_postnet(y, golden["post"], golden["meta"]["small_dims"]["postnet_layers"])
+    _close(yp, c["infer/y_post"], 2e-6)
+
+
+def test_decode_stop_rule_is_batch_global_and_inclusive(golden):
+    c, m = golden["cases"], golden["meta"]["stop"]
+    y, s, w = O.decode(
+        golden["dec"], _dims(golden), golden["memory"], max_steps=m["max_steps"], stop_threshold=m["threshold"], masks=c["infer/masks"]
+    )
+    assert y.shape[1] == m["T"]
+    _close(y, c["stop/y"])
+    _close(s, c["stop/s"])
+    _close(w, c["stop/w"])
+    # the frame that fired the rule is kept; no earlier frame fired it
+    assert bool((s[:, -1] < m["threshold"]).any())
+    assert not bool((s[:, :-1] < m["threshold"]).any())
+
+
+def test_decode_max_steps_one(golden):
+    c = golden["cases"]
+    y, s, w = O.decode(golden["dec"], _dims(golden), golden["memory"], max_steps=1, masks=c["infer/masks"])
+    _close(y, c["t2/y"])
+    _close(w, c["t2/w"])
+
+
+def test_decode_teacher_forced(golden):
+    c = golden["cases"]
+    y, s, w = O.decode(golden["dec"], _dims(golden), golden["memory"], masks=c["teacher/masks"], x=c["teacher/x"], p_no_forcing=None)
+    _close(y, c["teacher/y"])
+    _close(s, c["teacher/s"])
+    _close(w, c["teacher/w"])
+
+
+def test_decode_teacher_partial_forcing_flags_and_rng_replay(golden):
+    c, m = golden["cases"], golden["meta"]["teacher_p"]
+    flags = c["teacher_p/flags"].bool().tolist()
+    y, s, w = O.decode(golden["dec"], _dims(golden), golden["memory"], masks=c["teacher_p/masks"], x=c["teacher/x"], teacher_flags=flags)
+    _close(y, c["teacher_p/y"])
+    _close(w, c["teacher_p/w"])
+    # same thing drawing from the default generator in the reference's order
+    torch.manual_seed(m["seed"])
+    y2, _, _ = O.decode(golden["dec"], _dims(golden), golden["memory"], dropout="rng", x=c["teacher/x"], p_no_forcing=m["p_no_forcing"])
+    _close(y2, c["teacher_p/y"])
+
+
+def test_unit_prenet(golden):
+    c = golden["cases"]
+    _close(O.prenet(c["unit/prenet_x"], golden["dec"], c["unit/prenet_masks"]), c["unit/prenet_out"])
+
+
+def test_unit_lstm_cells(golden):
+    c = golden["cases"]
+    for name, pref in (("lstm1", "decoder_cell.attention_rnn"), ("lstm2", "decoder_cell.decoder_rnn")):
+        h, cc = O.lstm_zoneout_cell(c[f"unit/{name}_x"], c[f"unit/{name}_h"], c[f"unit/{name}_c"], golden["dec"], pref, 0.1)
+        _close(h, c[f"unit/{name}_ho"])
+        _close(cc, c[f"unit/{name}_co"])
+
+
+def test_unit_attention(golden):
+    c = golden["cases"]
+    w = O.stepwise_monotonic_attention(c["unit/att_h"], c["unit/att_w"], golden["memory"], golden["dec"])
+    _close(w, c["unit/att_wo"])
+    # mass conservation: column L-1 absorbs (p0(1e4) == 1.0 exactly in fp32)
+    _close(w.sum(1), c["unit/att_w"].sum(1), 1e-6)
+
+
+def test_unit_postnet(golden):
+    c = golden["cases"]
+    _close(O.mel_postnet(c["unit/post_y"], golden["post"], 3), c["unit/post_out"], 2e-6)
+
+
+def test_isru_sigmoid_saturates_exactly():
+    assert float(O.isru_sigmoid(torch.tensor([1e4]))) == 1.0
+    assert float(O.isru_sigmoid(torch.tensor([0.0]))) == 0.5
+
+
+def test_attention_properties_long_run():
+    """Properties from attention.py:117-123: rows sum to 1, support after k
+    steps within [0, k], expected position non-decreasing."""
+    dims = O.DecoderDims(d_mel=8, d_pre=16, d_ctx=32, h_att=32, h_dec=32)
+    wts = O.random_decoder_weights(dims, seed=3)
+    mem = O.synthetic_memory(2, 12, 32, lengths=[12, 7])
+    T = 40
+    y, s, w = O.decode(wts, dims, mem, max_steps=T - 1, masks=O.synthetic_masks(T, 2, 16))
+    assert w.shape == (2, T, 12)
+    assert float((w.sum(-1) - 1).abs().max()) < 1e-5
+    pos = (w * torch.arange(12.0)).sum(-1)
+    assert bool((pos[:, 1:] >= pos[:, :-1] - 1e-6).all())
+    for k in range(5):
+        assert float(w[:, k, k + 2 :].abs().max()) == 0.0
