@@ -1,0 +1,257 @@
+#!/usr/bin/env python3
+"""Benchmark of the Tacotron decoder hot path on MI355X.
+
+    python bench.py --gpus N --steps K --warmup W        (N > 1: launched by torch.distributed.run)
+
+One "step" = one pass of the hot path over one batch of synthetic LJSpeech-shaped input:
+600 autoregressive decode frames (max_steps=599; random-init stop logits never cross -2.0)
+for B utterances per GPU with memory length L=120, followed by the Postnet over the
+[B, 600, 80] mel.  Metric: mel-frames/s over the whole job (all ranks), inputs resident
+in HBM.  Weak scaling: per-GPU batch fixed at 256 (BASELINE.json configs[2]/[3]:
+2048 = 8 x 256).  Rank 0 prints ONE JSON line.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+# configs/config-ljspeech.yaml:47-69 of the reference (the file itself does not travel)
+LJSPEECH = {
+    "text": {"alphabet": "x" * 39},  # alphabet_size = 1 + 39 = 40 (tacotron.py:189)
+    "audio": {"num_mels": 80, "sample_rate": 22050, "hop_length": 256},
+    "model": {
+        "encoder": {"type": "tacotron2", "dim_emb": 512, "dim_out": 512},
+        "decoder": {"type": "tacotron2prod", "r": 1, "dim_pre": 256, "dim_att": 1024, "dim_rnn": [1024, 1024]},
+        "postnet": {"type": "tacotron2", "dim_hidden": 512, "num_layers": 3},
+    },
+}
+FRAME_SEC = 256.0 / 22050.0
+HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
+
+# Algorithmic bytes per decode step (SURVEY.md 8d / BASELINE.md 4), split by kernel.
+# weights (fp32 params incl. biases) + per-utterance reads/writes, L = memory length.
+def step_bytes(B, L, d):
+    P, D, Ha, Hd, M = d["dim_pre"], 512, d["dim_rnn"][0], d["dim_rnn"][1], 80
+    w = {
+        "prenet": (P * M + P + P * P + P) * 4,
+        "lstm_att": (4 * Ha * (P + D + Ha) + 8 * Ha) * 4,
+        "query": D * Ha * 4,
+        "lstm_dec": (4 * Hd * (Ha + D + Hd) + 8 * Hd) * 4,
+        "proj": ((M + 1) * (Hd + D) + M + 1) * 4,
+    }
+    per_utt = {
+        "prenet": M * 4 + 2 * P,                       # y_prev + 2 uint8 masks
+        "lstm_att": 4 * Ha * 4 + D * 4,                # h,c read+write + ctx read
+        "query": 0,
+        "attention": L * D * 4 + 2 * L * 4 + L * 4 + D * 4,  # memory pass + w r/w + w_out + ctx write
+        "lstm_dec": 4 * Hd * 4,
+        "proj": M * 4 + 4,                             # y + s out
+    }
+    out = {k: w.get(k, 0) + B * per_utt.get(k, 0) for k in set(w) | set(per_utt)}
+    out["step"] = sum(out.values())
+    return out
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--batch", type=int, default=256, help="utterances per GPU")
+    ap.add_argument("--mem-len", type=int, default=120)
+    ap.add_argument("--frames", type=int, default=600)
+    ap.add_argument("--postnet", choices=["f32", "bf16"], default="f32")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-frames", type=int, default=0, help="decode frames for the CPU baseline sample (0 = auto)")
+    args = ap.parse_args()
+
+    import torch.distributed as dist
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus > 1 and world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} needs torch.distributed.run with {args.gpus} ranks (WORLD_SIZE={world})")
+    dev = torch.device("cuda", local_rank)
+    torch.cuda.set_device(dev)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+
+    import torch_tts_amd as T
+    from torch_tts_amd import _lib
+    from torch_tts_amd import distributed as D
+
+    B, L, NF = args.batch, args.mem_len, args.frames
+    Bg = B * world  # global batch
+
+    # ---- model: LJSpeech dims, random init seed 42 (xavier_normal gain 1.5, default LSTMCell init) ----
+    torch.manual_seed(42)
+    model = T.build_tacotron(LJSPEECH).eval()
+    model.to(dev)
+    dec, post = model.decoder, model.postnet
+    dec.dropout_source, dec.dropout_seed = "philox", 123
+    post.precision = args.postnet
+
+    # ---- weights: rank 0 packs, one RCCL broadcast of the blob, other ranks bind ----
+    eng = dec._engines.get(dec.decoder_cell.engine_dims(), dev)
+    peng = post._engines.get(post.engine_dims(), dev)
+    if world > 1:
+        D.broadcast_engine_weights(eng, dec.weight_tensors(), src=0)
+        D.broadcast_engine_weights(peng, post.weight_tensors(), src=0)
+        eng._fingerprint = None
+    else:
+        eng.ensure_packed(dec.weight_tensors())
+        peng.ensure_packed(post.weight_tensors())
+
+    # ---- synthetic input: ids -> stock encoder -> memory, this rank's shard of the global batch ----
+    g = torch.Generator().manual_seed(1234)
+    ids_all = torch.randint(1, 40, (Bg, L), generator=g)
+    lo, hi = D.shard_bounds(Bg, world, rank)
+    ids = ids_all[lo:hi].to(dev)
+    lens = torch.full((hi - lo,), L, dtype=torch.long, device=dev)
+    with torch.no_grad():
+        mem = torch.cat([model.encoder(ids[i : i + 64], lens[i : i + 64]) for i in range(0, hi - lo, 64)]).contiguous()
+    assert mem.shape == (B, L, 512)
+
+    y = torch.empty(B, NF, 80, device=dev)
+    s = torch.empty(B, NF, device=dev)
+    w = torch.empty(B, NF, L, device=dev)
+    t_out = torch.zeros(2, dtype=torch.int32, device=dev)
+    prec = {"f32": _lib.POSTNET_F32, "bf16": _lib.POSTNET_BF16}[args.postnet]
+
+    def one_step():
+        eng.decode(mem, t_begin=0, n_steps=NF, stop_threshold=-2.0, check_stop=True, dropout_mode=_lib.DROPOUT_PHILOX,
+                   masks=None, seed=123, teacher=None, teacher_flags=None, y=y, s=s, w=w, t_out=t_out)
+        return peng.postnet(y, prec)
+
+    def fence():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        one_step()
+    fence()
+    ev0, ev1, ev2 = (torch.cuda.Event(enable_timing=True) for _ in range(3))
+    t0 = time.perf_counter()
+    dec_ms = 0.0
+    for _ in range(args.steps):
+        ev0.record()
+        eng.decode(mem, t_begin=0, n_steps=NF, stop_threshold=-2.0, check_stop=True, dropout_mode=_lib.DROPOUT_PHILOX,
+                   masks=None, seed=123, teacher=None, teacher_flags=None, y=y, s=s, w=w, t_out=t_out)
+        ev1.record()
+        y_post = peng.postnet(y, prec)
+        ev2.record()
+        ev2.synchronize()
+        dec_ms += ev0.elapsed_time(ev1)
+    fence()
+    elapsed = time.perf_counter() - t0
+    assert t_out.tolist() == [NF, 0], f"decode ended early: {t_out.tolist()}"
+    assert bool(torch.isfinite(y_post).all())
+    if world > 1:
+        tt = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        elapsed = float(tt.item())
+
+    frames_total = Bg * NF * args.steps
+    value = frames_total / elapsed
+    ms_per_step = elapsed * 1e3 / args.steps
+
+    # ---- roofline of the dominant kernel: HIP events inside the library, on the launch stream ----
+    kms = eng.profile_step(mem, iters=50, dropout_mode=_lib.DROPOUT_PHILOX, masks=None, seed=123)
+    bytes_k = step_bytes(B, L, LJSPEECH["model"]["decoder"])
+    grp = {"prenet": ["prenet0", "prenet1"], "lstm_att": ["lstm_att"], "query": ["query"], "attention": ["attention"],
+           "lstm_dec": ["lstm_dec"], "proj": ["proj"]}
+    per_kernel = {}
+    for k, names in grp.items():
+        ms = sum(kms[n] for n in names)
+        per_kernel[k] = {"ms": round(ms, 5), "alg_bytes": bytes_k[k], "GBps": round(bytes_k[k] / (ms * 1e-3) / 1e9, 1)}
+    dom = max(per_kernel, key=lambda k: per_kernel[k]["ms"])
+    step_ms_kernels = sum(v["ms"] for v in per_kernel.values())
+    decode_step_ms = dec_ms / args.steps / NF
+    roofline = {
+        "bound": "hbm",
+        "kernel": dom,
+        "achieved": per_kernel[dom]["GBps"],
+        "peak": HBM_PEAK_GBS,
+        "unit": "GB/s",
+        "frac": round(per_kernel[dom]["GBps"] / HBM_PEAK_GBS, 4),
+        "traffic": None,
+        "alg_bytes_per_launch": per_kernel[dom]["alg_bytes"],
+        "kernel_ms": per_kernel[dom]["ms"],
+        "decode_step": {
+            "alg_bytes": bytes_k["step"],
+            "ms_in_loop": round(decode_step_ms, 5),
+            "GBps": round(bytes_k["step"] / (decode_step_ms * 1e-3) / 1e9, 1),
+            "frac": round(bytes_k["step"] / (decode_step_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+            "sum_kernel_ms": round(step_ms_kernels, 5),
+        },
+        "per_kernel": per_kernel,
+    }
+
+    out = {
+        "metric": "mel-frames/s (whole node) + real-time-factor, LJSpeech 22.05kHz hop256",
+        "value": round(value, 1),
+        "unit": "mel-frames/s",
+        "n_gpus": world,
+        "steps": args.steps,
+        "warmup": args.warmup,
+        "ms_per_step": round(ms_per_step, 3),
+        "higher_is_better": True,
+        "scaling": "weak",
+        "vs_baseline": None,
+        "dtype": "f32",
+        "data": "synthetic",
+        "config": {
+            "workload": f"LJSpeech dims, batch={B}/GPU (global {Bg}), L={L}, {NF} decode frames + Postnet({args.postnet}); "
+                        "BASELINE.json configs[2] per GPU, configs[3] at 8 GPUs",
+            "global_batch": Bg, "mem_len": L, "frames": NF, "dropout": "philox", "parallelism": f"utterance-shard x{world}",
+        },
+        "rtf": round((elapsed / args.steps) / (NF * FRAME_SEC), 6),
+        "audio_seconds_per_s": round(value * FRAME_SEC, 1),
+        "decode_only_frames_per_s": round(Bg * NF / (dec_ms / args.steps * 1e-3), 1),
+        "roofline": roofline,
+    }
+
+    # ---- CPU baseline: the oracle (a port of the reference's CPU path) on this box's host cores ----
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        from oracle import tacotron_oracle as O
+
+        dims = O.DecoderDims()
+        sd = {k: v.detach().cpu() for k, v in dec.state_dict().items()}
+        pw = {k: v.detach().cpu() for k, v in post.state_dict().items()}
+        memc = mem.cpu()
+        cores = torch.get_num_threads()
+        tc = args.cpu_frames
+        if tc <= 0:
+            t1 = time.perf_counter()
+            O.decode(sd, dims, memc, max_steps=1, masks=O.synthetic_masks(2, B, 256))
+            per = (time.perf_counter() - t1) / 2
+            tc = max(4, min(NF, int(15.0 / max(per, 1e-4))))
+        masks = O.synthetic_masks(tc, B, 256)
+        t1 = time.perf_counter()
+        with torch.no_grad():
+            cy, _, _ = O.decode(sd, dims, memc, max_steps=tc - 1, masks=masks)
+            O.mel_postnet(cy, pw, 3)
+        ct = time.perf_counter() - t1
+        out["cpu_baseline"] = {
+            "value": round(B * tc / ct, 1), "unit": "mel-frames/s", "cores": cores, "kind": "port",
+            "sample": f"oracle (torch-CPU restatement of the reference path) on B={B}, L={L}, {tc} decode frames + Postnet, {cores} threads",
+        }
+    if rank == 0:
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,203 @@
+/*
+ * ttsdec.h - C ABI of libttsdec.so: the MI355X (gfx950) implementation of the
+ * Tacotron autoregressive mel-decoder hot path of kgoba/torch-tts.
+ *
+ * The reference has no FFI / plugin interface for this path: its boundary is the
+ * Python module API (tacotron/decoder.py:6-18 Decoder, tacotron/decoder_cell.py:143-195
+ * Taco2ProdDecoderCell, tacotron/modules/modules.py:155-184 MelPostnet).  This C ABI is
+ * what the host-side mirror of those modules (the Python files of torch-tts_amd/, ctypes) binds; each
+ * entry point below names the reference code it replaces.  INTEGRATION.md shows the
+ * reference-side stub.
+ *
+ * Conventions
+ *   - plain pointers and sizes only; every data pointer is a DEVICE pointer (fp32,
+ *     row-major contiguous) unless it says "host".
+ *   - the caller owns every buffer (weights blob, workspace, inputs, outputs); the
+ *     library allocates nothing on the device and keeps only the pointers bound with
+ *     ttsdec_bind_weights().
+ *   - all work is enqueued on the hipStream_t passed in (as void*); no hidden
+ *     synchronisation.  Calls on one handle must be serialised by the caller.
+ *   - return value: 0 = TTSDEC_OK, negative = error (ttsdec_strerror()).  Nothing
+ *     throws or aborts across this boundary.
+ *   - the handle is bound to the HIP device that was current at ttsdec_create();
+ *     that device must be current for every later call.
+ */
+#ifndef TTSDEC_H
+#define TTSDEC_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define TTSDEC_VERSION 1
+
+enum {
+  TTSDEC_OK = 0,
+  TTSDEC_ERR_INVALID_ARG = -1, /* null pointer, negative size, bad enum */
+  TTSDEC_ERR_DIMS = -2,        /* a feature dimension is not a multiple of 4 / out of range */
+  TTSDEC_ERR_HIP = -3,         /* a HIP runtime call failed (hipGetLastError text via ttsdec_last_hip_error) */
+  TTSDEC_ERR_NOT_BOUND = -4,   /* decode/postnet before ttsdec_bind_weights */
+  TTSDEC_ERR_WORKSPACE = -5,   /* workspace too small or misaligned */
+  TTSDEC_ERR_DEVICE = -6       /* current device differs from the handle's, or is not gfx950 */
+};
+
+/* Model dimensions.  Source of truth: configs/config-ljspeech.yaml:47-69 via
+ * build_tacotron (tacotron/tacotron.py:165-214). */
+typedef struct ttsdec_dims {
+  int32_t d_mel;           /* audio.num_mels                     (80)   */
+  int32_t r;               /* decoder.r, frames per step          (1)   */
+  int32_t d_pre;           /* decoder.dim_pre, both PreNet layers (256) */
+  int32_t d_ctx;           /* encoder.dim_out                     (512) */
+  int32_t h_att;           /* decoder.dim_rnn[0]                  (1024)*/
+  int32_t h_dec;           /* decoder.dim_rnn[1]                  (1024)*/
+  float p_zoneout;         /* decoder_cell.py:145                 (0.1) */
+  float p_dropout;         /* modules.py:25 PreNet p_dropout      (0.5) */
+  int32_t postnet_layers;  /* model.postnet.num_layers            (3); 0 = no postnet */
+  int32_t postnet_hidden;  /* model.postnet.dim_hidden            (512) */
+  int32_t postnet_kernel;  /* MelPostnet kernel_size              (5)   */
+  float bn_eps;            /* nn.BatchNorm1d eps                  (1e-5)*/
+} ttsdec_dims;
+
+typedef struct ttsdec_handle ttsdec_handle;
+
+/* Order of the source tensors handed to ttsdec_pack_weights: the reference's
+ * state-dict order.  Postnet entries repeat per layer. */
+enum {
+  TTSDEC_W_PRE0_W = 0, /* decoder.decoder_cell.pre_net.layers.0.weight [d_pre, d_mel]        */
+  TTSDEC_W_PRE0_B,     /* ...layers.0.bias   [d_pre]                                          */
+  TTSDEC_W_PRE1_W,     /* ...layers.1.weight [d_pre, d_pre]                                   */
+  TTSDEC_W_PRE1_B,     /* ...layers.1.bias   [d_pre]                                          */
+  TTSDEC_W_QUERY_W,    /* decoder_cell.attention_module.query_layer.weight [d_ctx, h_att]     */
+  TTSDEC_W_ATT_IH,     /* decoder_cell.attention_rnn.weight_ih [4*h_att, d_pre+d_ctx]         */
+  TTSDEC_W_ATT_HH,     /* ...weight_hh [4*h_att, h_att]                                       */
+  TTSDEC_W_ATT_BIH,    /* ...bias_ih   [4*h_att]                                              */
+  TTSDEC_W_ATT_BHH,    /* ...bias_hh   [4*h_att]                                              */
+  TTSDEC_W_DEC_IH,     /* decoder_cell.decoder_rnn.weight_ih [4*h_dec, h_att+d_ctx]           */
+  TTSDEC_W_DEC_HH,     /* ...weight_hh [4*h_dec, h_dec]                                       */
+  TTSDEC_W_DEC_BIH,    /* ...bias_ih   [4*h_dec]                                              */
+  TTSDEC_W_DEC_BHH,    /* ...bias_hh   [4*h_dec]                                              */
+  TTSDEC_W_INIT_H0,    /* decoder_cell.initial_decoder_h.0 [1, h_att]                         */
+  TTSDEC_W_INIT_H1,    /* decoder_cell.initial_decoder_h.1 [1, h_dec]                         */
+  TTSDEC_W_INIT_C0,    /* decoder_cell.initial_decoder_c.0 [1, h_att]                         */
+  TTSDEC_W_INIT_C1,    /* decoder_cell.initial_decoder_c.1 [1, h_dec]                         */
+  TTSDEC_W_MEL_W,      /* decoder.fc_mel.weight  [r*d_mel, h_dec+d_ctx]                       */
+  TTSDEC_W_MEL_B,      /* decoder.fc_mel.bias    [r*d_mel]                                    */
+  TTSDEC_W_STOP_W,     /* decoder.fc_stop.weight [r, h_dec+d_ctx]                             */
+  TTSDEC_W_STOP_B,     /* decoder.fc_stop.bias   [r]                                          */
+  TTSDEC_W_DECODER_COUNT, /* = 21; postnet tensors follow:                                   */
+  /* per layer i (5 each): postnet.conv.i.0.weight [C_out, C_in, k], conv.i.1.weight [C_out],
+   * conv.i.1.bias, conv.i.1.running_mean, conv.i.1.running_var; then postnet.fc_out.weight
+   * [d_mel, hidden].  Total = 21 + 5*postnet_layers + 1 (or 21 when postnet_layers == 0). */
+  TTSDEC_W_POSTNET_PER_LAYER = 5
+};
+
+/* Prenet dropout modes (the reference's dropout is always on, modules.py:40). */
+enum {
+  TTSDEC_DROPOUT_OFF = 0,   /* no dropout (not reference behaviour; for analysis)              */
+  TTSDEC_DROPOUT_MASKS = 1, /* keep-masks injected: uint8 [steps, 2, B, d_pre], 1 = keep       */
+  TTSDEC_DROPOUT_PHILOX = 2 /* on-device Philox4x32-10 keyed by (seed; step, layer, b, unit)   */
+};
+
+/* Postnet arithmetic. */
+enum {
+  TTSDEC_POSTNET_F32 = 0,   /* exact fp32 (fp32-input MFMA)                                   */
+  TTSDEC_POSTNET_BF16 = 1   /* bf16 MFMA, fp32 accumulate (BASELINE.json configs[2])          */
+};
+
+int ttsdec_version(void);
+const char* ttsdec_strerror(int code);
+/* Text of the last HIP error seen on this handle ("" if none).  Host string, owned by the library. */
+const char* ttsdec_last_hip_error(const ttsdec_handle* h);
+
+/* Replaces: module construction in build_tacotron (tacotron/tacotron.py:178-206). */
+int ttsdec_create(const ttsdec_dims* dims, ttsdec_handle** out);
+int ttsdec_destroy(ttsdec_handle* h);
+
+/* Number of source tensors ttsdec_pack_weights expects for these dims. */
+int ttsdec_num_weight_tensors(const ttsdec_handle* h);
+/* Size of the packed weight blob (bytes, multiple of 256). */
+size_t ttsdec_packed_bytes(const ttsdec_handle* h);
+
+/* Packs the reference-layout parameters into the kernel layout inside `blob`
+ * (caller-allocated, ttsdec_packed_bytes(), 256-B aligned): sums the LSTM bias
+ * pairs, stacks fc_mel/fc_stop, transposes conv weights to [C_out][tap][C_in],
+ * turns BatchNorm running stats into per-channel (alpha, beta).  The blob is
+ * position-independent: it can be broadcast to other GPUs (RCCL) and bound there.
+ * Replaces: nn.Module parameter storage / load_state_dict (train_util.py:23-45). */
+int ttsdec_pack_weights(ttsdec_handle* h, const float* const* src /*host array of device ptrs; NULL entry = skip*/, int n_src,
+                        void* blob, void* stream);
+/* Binds a packed blob (from ttsdec_pack_weights here or on another rank). */
+int ttsdec_bind_weights(ttsdec_handle* h, const void* blob);
+
+/* Decoder workspace (recurrent state + scratch) for a batch of B utterances with
+ * memory length L.  The state persists in the workspace between ttsdec_decode calls. */
+size_t ttsdec_workspace_bytes(const ttsdec_handle* h, int B, int L);
+
+/*
+ * Runs decode steps t_begin .. t_begin+n_steps-1 of Decoder.forward
+ * (tacotron/decoder.py:47-71) for the whole batch; one step = PreNet ->
+ * attention LSTM -> stepwise-monotonic attention -> context -> decoder LSTM ->
+ * mel/stop projection (tacotron/decoder_cell.py:180-195).
+ *
+ *   memory        [B, L, d_ctx] encoder outputs (zero on padded rows)
+ *   t_begin       global index of the first step of this call; 0 (re)initialises
+ *                 the recurrent state from the initial_decoder_{h,c} parameters
+ *                 (decoder_cell.py:165-178) and the GO frame (decoder.py:35)
+ *   n_steps       steps to run at most in this call
+ *   t_stride      capacity (in steps) of the output buffers of this call, >= n_steps
+ *   stop_threshold / check_stop
+ *                 inference stop rule (decoder.py:68): the first step at which ANY
+ *                 utterance's stop logit < threshold is the last one produced
+ *                 (inclusive, batch-global); later steps of this and following
+ *                 calls are skipped.  check_stop = 0 disables it (teacher mode).
+ *   dropout_mode  TTSDEC_DROPOUT_*; masks [n_steps, 2, B, d_pre] uint8 for MASKS
+ *                 (relative to t_begin); seed for PHILOX
+ *   teacher       optional [B, teacher_T, d_mel] ground-truth frames (decoder.py:38-42);
+ *   teacher_flags optional uint8 [>= t_begin+n_steps]: flags[t-1] != 0 => the input of
+ *                 step t (t >= 1) is teacher frame t*r-1 instead of the model's own
+ *                 last frame (decoder.py:65-66).  NULL teacher = free-running.
+ *   y [B, t_stride*r, d_mel], s [B, t_stride*r], w [B, t_stride, L]
+ *                 outputs of this call, step t stored at row (t - t_begin)
+ *   T_out         device int32[2]: [0] = total number of steps produced so far
+ *                 (= stop step + 1 if the rule fired, else t_begin+n_steps),
+ *                 [1] = 1 if the stop rule has fired.
+ */
+int ttsdec_decode(ttsdec_handle* h, const float* memory, int B, int L, int t_begin, int n_steps, int t_stride,
+                  float stop_threshold, int check_stop, int dropout_mode, const uint8_t* masks, uint64_t seed,
+                  const float* teacher, int teacher_T, const uint8_t* teacher_flags, float* y, float* s, float* w,
+                  int32_t* T_out, void* workspace, size_t workspace_bytes, void* stream);
+
+/* Postnet scratch for B*T frames. */
+size_t ttsdec_postnet_workspace_bytes(const ttsdec_handle* h, int B, int T);
+
+/* MelPostnet.forward in eval mode (tacotron/modules/modules.py:178-184):
+ * y [B, T, d_mel] -> y_post [B, T, d_mel] = y + fc_out(isru(BN(conv(...)))). */
+int ttsdec_postnet(ttsdec_handle* h, const float* y, int B, int T, int precision, float* y_post, void* workspace,
+                   size_t workspace_bytes, void* stream);
+
+/* One decoder-cell step on caller-held state (Taco2ProdDecoderCell.forward,
+ * tacotron/decoder_cell.py:180-195), for callers that drive the cell directly.
+ * Not needed by Decoder.forward; provided for API completeness.  State tensors are
+ * updated in place: w [B,L], ctx [B,d_ctx], h_att/c_att [B,h_att], h_dec/c_dec [B,h_dec];
+ * x [B, d_mel] is the input frame; x_dec [B, h_dec+d_ctx] receives cat[h_dec, ctx].
+ * masks: [2, B, d_pre] uint8 or NULL per dropout_mode; step only keys the Philox stream. */
+int ttsdec_cell_step(ttsdec_handle* h, const float* x, const float* memory, int B, int L, float* w, float* ctx,
+                     float* h_att, float* c_att, float* h_dec, float* c_dec, int dropout_mode, const uint8_t* masks,
+                     uint64_t seed, int step, float* x_dec, void* workspace, size_t workspace_bytes, void* stream);
+
+/* Measurement aid for bench.py: runs `iters` decode steps on the current
+ * workspace state and reports the mean duration (ms, HIP events on `stream`) of each
+ * kernel of the step, in launch order, into ms_out[0..n_out) (host array); returns the
+ * number of kernels per step in *n_kernels and their names (static strings) in names_out. */
+int ttsdec_profile_step(ttsdec_handle* h, const float* memory, int B, int L, int iters, int dropout_mode,
+                        const uint8_t* masks, uint64_t seed, float* y, float* s, float* w, void* workspace,
+                        size_t workspace_bytes, void* stream, float* ms_out, const char** names_out, int n_out,
+                        int* n_kernels);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* TTSDEC_H */

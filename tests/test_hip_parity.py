@@ -1,0 +1,288 @@
+"""GPU parity tests: the HIP path (through the C ABI / the drop-in modules) against
+(a) golden vectors produced by the reference itself and (b) the CPU oracle on the same
+seeded inputs.  Tolerance (BASELINE.json north_star): mel / stop logits within 1e-4
+relative (atol 1e-5 for values near zero), attention argmax indices bit-exact."""
+import pytest
+import torch
+
+from oracle import tacotron_oracle as O
+
+pytestmark = pytest.mark.gpu
+
+RTOL, ATOL = 1e-4, 1e-5
+
+
+@pytest.fixture(scope="module")
+def H():
+    assert torch.cuda.is_available(), "GPU tests need a ROCm device"
+    import hip_helpers
+
+    return hip_helpers
+
+
+def _small_dims(g):
+    d = g["meta"]["small_dims"]
+    return O.DecoderDims(d_mel=d["d_mel"], r=d["r"], d_pre=d["d_pre"], d_ctx=d["d_ctx"], h_att=d["h_att"], h_dec=d["h_dec"])
+
+
+# --------------------------------------------------------------------------
+# golden vectors from the reference (reduced dims, ragged lengths, B=3, L=17)
+# --------------------------------------------------------------------------
+def test_golden_inference(golden, H):
+    c, m = golden["cases"], golden["meta"]["infer"]
+    dec = H.make_decoder(_small_dims(golden), golden["dec"])
+    y, s, w, fired = H.run_decoder_with_masks(dec, golden["memory"], c["infer/masks"], max_steps=m["max_steps"])
+    assert not fired and y.shape[1] == m["T"]
+    H.assert_close(y, c["infer/y"], RTOL, ATOL, "y")
+    H.assert_close(s, c["infer/s"], RTOL, ATOL, "s")
+    H.assert_close(w, c["infer/w"], RTOL, ATOL, "w")
+    assert torch.equal(w.argmax(-1), c["infer/w"].argmax(-1))
+    d = golden["meta"]["small_dims"]
+    pn = H.make_postnet(d["d_mel"], d["postnet_hidden"], d["postnet_layers"], golden["post"])
+    with torch.no_grad():
+        yp = pn(c["infer/y"].cuda()).cpu()
+    H.assert_close(yp, c["infer/y_post"], RTOL, ATOL, "y_post")
+
+
+def test_golden_stop_rule(golden, H):
+    c, m = golden["cases"], golden["meta"]["stop"]
+    dec = H.make_decoder(_small_dims(golden), golden["dec"], stop_threshold=m["threshold"])
+    y, s, w, fired = H.run_decoder_with_masks(dec, golden["memory"], c["infer/masks"], max_steps=m["max_steps"])
+    assert fired
+    assert y.shape[1] == m["T"], "stop rule must be batch-global and inclusive of the firing step"
+    H.assert_close(y, c["stop/y"], RTOL, ATOL, "y")
+    H.assert_close(s, c["stop/s"], RTOL, ATOL, "s")
+    H.assert_close(w, c["stop/w"], RTOL, ATOL, "w")
+
+
+def test_golden_max_steps_one(golden, H):
+    c = golden["cases"]
+    dec = H.make_decoder(_small_dims(golden), golden["dec"])
+    y, s, w, _ = H.run_decoder_with_masks(dec, golden["memory"], c["infer/masks"], max_steps=1)
+    assert y.shape[1] == 2
+    H.assert_close(y, c["t2/y"], RTOL, ATOL, "y")
+    H.assert_close(w, c["t2/w"], RTOL, ATOL, "w")
+
+
+def test_golden_teacher_forced(golden, H):
+    c = golden["cases"]
+    dec = H.make_decoder(_small_dims(golden), golden["dec"])
+    y, s, w, _ = H.run_decoder_with_masks(dec, golden["memory"], c["teacher/masks"], x=c["teacher/x"])
+    H.assert_close(y, c["teacher/y"], RTOL, ATOL, "y")
+    H.assert_close(s, c["teacher/s"], RTOL, ATOL, "s")
+    H.assert_close(w, c["teacher/w"], RTOL, ATOL, "w")
+
+
+def test_golden_teacher_partial_forcing(golden, H):
+    c = golden["cases"]
+    dec = H.make_decoder(_small_dims(golden), golden["dec"])
+    y, s, w, _ = H.run_decoder_with_masks(dec, golden["memory"], c["teacher_p/masks"], x=c["teacher/x"], flags=c["teacher_p/flags"])
+    H.assert_close(y, c["teacher_p/y"], RTOL, ATOL, "y")
+    H.assert_close(w, c["teacher_p/w"], RTOL, ATOL, "w")
+
+
+def test_golden_through_module_forward_with_reference_rng(golden, H):
+    """Decoder.forward with dropout_source='reference_rng' under the reference's seed
+    reproduces the reference's own run (masks replayed from torch's CPU generator),
+    for inference, the stop rule and teacher forcing with p_no_forcing."""
+    c, meta = golden["cases"], golden["meta"]
+    dims = _small_dims(golden)
+    mem = golden["memory"].cuda()
+    dec = H.make_decoder(dims, golden["dec"])
+    with torch.no_grad():
+        torch.manual_seed(meta["infer"]["seed"])
+        y, s, w = dec(mem, None, None, meta["infer"]["max_steps"])
+        H.assert_close(y.cpu(), c["infer/y"], RTOL, ATOL, "y")
+        assert s.shape == c["infer/s"].shape
+        # generator state afterwards equals the reference's (T steps of draws consumed)
+        after = torch.rand(1)
+        torch.manual_seed(meta["infer"]["seed"])
+        for _ in range(meta["infer"]["T"]):
+            O.draw_prenet_masks(3, dims.d_pre, dims.d_pre)
+        assert torch.equal(after, torch.rand(1))
+
+        dec2 = H.make_decoder(dims, golden["dec"], stop_threshold=meta["stop"]["threshold"])
+        torch.manual_seed(meta["stop"]["seed"])
+        y2, s2, w2 = dec2(mem, None, None, meta["stop"]["max_steps"])
+        assert y2.shape[1] == meta["stop"]["T"]
+        H.assert_close(y2.cpu(), c["stop/y"], RTOL, ATOL, "y stop")
+        after = torch.rand(1)
+        torch.manual_seed(meta["stop"]["seed"])
+        for _ in range(meta["stop"]["T"]):
+            O.draw_prenet_masks(3, dims.d_pre, dims.d_pre)
+        assert torch.equal(after, torch.rand(1)), "early stop must leave the CPU generator where the reference leaves it"
+
+        torch.manual_seed(meta["teacher_p"]["seed"])
+        y5, s5, w5 = dec(mem, None, c["teacher/x"].cuda(), 0, p_no_forcing=meta["teacher_p"]["p_no_forcing"])
+        H.assert_close(y5.cpu(), c["teacher_p/y"], RTOL, ATOL, "y teacher_p")
+        H.assert_close(w5.cpu(), c["teacher_p/w"], RTOL, ATOL, "w teacher_p")
+
+
+def test_golden_unbounded_decode_chunks(golden, H):
+    """max_steps=0 decodes in chunks until the stop rule fires; chunking must not change results."""
+    c, m = golden["cases"], golden["meta"]["stop"]
+    dec = H.make_decoder(_small_dims(golden), golden["dec"], stop_threshold=m["threshold"])
+    dec.chunk_steps = 3  # forces several ttsdec_decode calls with state carried in the workspace
+    with torch.no_grad():
+        torch.manual_seed(m["seed"])
+        y, s, w = dec(golden["memory"].cuda(), None, None, 0)
+    assert y.shape[1] == m["T"]
+    H.assert_close(y.cpu(), c["stop/y"], RTOL, ATOL, "y")
+    H.assert_close(w.cpu(), c["stop/w"], RTOL, ATOL, "w")
+
+
+def test_golden_postnet_unit(golden, H):
+    c, d = golden["cases"], golden["meta"]["small_dims"]
+    pn = H.make_postnet(d["d_mel"], d["postnet_hidden"], d["postnet_layers"], golden["post"])
+    with torch.no_grad():
+        out = pn(c["unit/post_y"].cuda()).cpu()
+    H.assert_close(out, c["unit/post_out"], RTOL, ATOL, "postnet")
+
+
+def test_golden_cell_step(golden, H):
+    """Taco2ProdDecoderCell.forward (ttsdec_cell_step) against the oracle's single step."""
+    dims = _small_dims(golden)
+    dec = H.make_decoder(dims, golden["dec"])
+    cell = dec.decoder_cell
+    cell.dropout_source = "reference_rng"
+    mem = golden["memory"]
+    B, L, _ = mem.shape
+    g = torch.Generator().manual_seed(17)
+    x = torch.randn(B, 1, dims.d_mel, generator=g)
+    w = torch.rand(B, L, generator=g)
+    w = w / w.sum(1, keepdim=True)
+    ctx = torch.randn(B, dims.d_ctx, generator=g) * 0.3
+    ha, ca = torch.randn(B, dims.h_att, generator=g) * 0.3, torch.randn(B, dims.h_att, generator=g) * 0.3
+    hd, cd = torch.randn(B, dims.h_dec, generator=g) * 0.3, torch.randn(B, dims.h_dec, generator=g) * 0.3
+    torch.manual_seed(5)
+    m0, m1 = O.draw_prenet_masks(B, dims.d_pre, dims.d_pre)
+    ox, (ow, octx, (oha, oca), (ohd, ocd)) = O.decoder_cell_step(
+        x[:, -1], (w, ctx, (ha, ca), (hd, cd)), mem, golden["dec"], dims, torch.stack([m0, m1])
+    )
+    dev = "cuda:0"
+    with torch.no_grad():
+        torch.manual_seed(5)
+        xd, cx, (w2, ctx2, ((ha2, ca2), (hd2, cd2))) = cell(
+            x.to(dev), (w.to(dev), ctx.to(dev), ((ha.to(dev), ca.to(dev)), (hd.to(dev), cd.to(dev)))), mem.to(dev), None
+        )
+    H.assert_close(xd.cpu(), ox, RTOL, ATOL, "x_dec")
+    H.assert_close(w2.cpu(), ow, RTOL, ATOL, "w")
+    H.assert_close(ctx2.cpu(), octx, RTOL, ATOL, "ctx")
+    H.assert_close(ha2.cpu(), oha, RTOL, ATOL, "h_att")
+    H.assert_close(cd2.cpu(), ocd, RTOL, ATOL, "c_dec")
+
+
+# --------------------------------------------------------------------------
+# oracle on the same seeded inputs, LJSpeech dims (BASELINE.json configs[1] and [2])
+# --------------------------------------------------------------------------
+@pytest.mark.parametrize("B,L,T,lengths", [(64, 120, 24, None), (256, 120, 6, None), (5, 37, 10, [37, 30, 12, 37, 1]), (1, 9, 12, None)])
+def test_ljspeech_dims_vs_oracle(H, B, L, T, lengths):
+    dims = O.DecoderDims()
+    wts = O.random_decoder_weights(dims, seed=42, nonzero_init_state=True)
+    mem = O.synthetic_memory(B, L, dims.d_ctx, lengths=lengths, seed=1234)
+    masks = O.synthetic_masks(T, B, dims.d_pre, seed=123)
+    torch.set_num_threads(max(1, torch.get_num_threads()))
+    oy, os_, ow = O.decode(wts, dims, mem, max_steps=T - 1, masks=masks)
+    dec = H.make_decoder(dims, wts)
+    y, s, w, fired = H.run_decoder_with_masks(dec, mem, masks, max_steps=T - 1)
+    assert not fired and y.shape == oy.shape
+    H.assert_close(y, oy, RTOL, ATOL, "y")
+    H.assert_close(s, os_, RTOL, ATOL, "s")
+    H.assert_close(w, ow, RTOL, ATOL, "w")
+    assert torch.equal(w.argmax(-1), ow.argmax(-1)), "attention argmax must be bit-exact"
+
+
+def test_postnet_ljspeech_dims_vs_oracle(H):
+    pw = O.random_postnet_weights(80, 512, 3, seed=9)
+    g = torch.Generator().manual_seed(2)
+    y = torch.randn(3, 57, 80, generator=g)
+    ref = O.mel_postnet(y, pw, 3)
+    pn = H.make_postnet(80, 512, 3, pw)
+    with torch.no_grad():
+        out = pn(y.cuda()).cpu()
+    H.assert_close(out, ref, RTOL, ATOL, "postnet")
+
+
+def test_philox_mode_matches_oracle_masks(H):
+    """On-device dropout: the same Philox function restated in the oracle gives the masks;
+    the decode must match the oracle run with those masks injected."""
+    dims = O.DecoderDims(d_mel=20, d_pre=36, d_ctx=40, h_att=72, h_dec=88)
+    wts = O.random_decoder_weights(dims, seed=4)
+    B, L, T, seed = 7, 11, 9, 0x1234567890ABCDEF
+    mem = O.synthetic_memory(B, L, dims.d_ctx, lengths=[11, 11, 4, 9, 11, 2, 7])
+    masks = torch.stack([O.philox_keep_masks(seed, t, B, dims.d_pre) for t in range(T)])
+    oy, os_, ow = O.decode(wts, dims, mem, max_steps=T - 1, masks=masks)
+    dec = H.make_decoder(dims, wts)
+    dec.dropout_source, dec.dropout_seed = "philox", seed
+    with torch.no_grad():
+        y, s, w = dec(mem.cuda(), None, None, T - 1)
+    H.assert_close(y.cpu(), oy, RTOL, ATOL, "y")
+    H.assert_close(w.cpu(), ow, RTOL, ATOL, "w")
+
+
+# --------------------------------------------------------------------------
+# size-independent properties at BASELINE.json's full size (B=256, L=120, T=600)
+# --------------------------------------------------------------------------
+def test_full_size_properties(H):
+    dims = O.DecoderDims()
+    wts = O.random_decoder_weights(dims, seed=42)
+    B, L, T = 256, 120, 600
+    mem = O.synthetic_memory(B, L, dims.d_ctx, seed=1234).cuda()
+    dec = H.make_decoder(dims, wts)
+    dec.dropout_source, dec.dropout_seed = "philox", 123
+    with torch.no_grad():
+        y, s, w = dec(mem, None, None, T - 1)
+        y2, s2, w2 = dec(mem, None, None, T - 1)
+    assert y.shape == (B, T, 80) and s.shape == (B, T, 1) and w.shape == (B, T, L)
+    assert torch.isfinite(y).all() and torch.isfinite(s).all()
+    # run-to-run determinism, bit for bit
+    assert torch.equal(y, y2) and torch.equal(w, w2) and torch.equal(s, s2)
+    # attention.py:117-123: rows sum to 1; mass only stays or moves one slot forward
+    assert float((w.sum(-1) - 1).abs().max()) < 1e-4
+    pos = (w * torch.arange(L, device=w.device, dtype=w.dtype)).sum(-1)
+    assert bool((pos[:, 1:] >= pos[:, :-1] - 1e-4).all()), "expected attention position must be non-decreasing"
+    for k in range(4):
+        assert float(w[:, k, k + 2 :].abs().max()) == 0.0, "support after k steps lies within [0, k+1]"
+
+
+def test_shard_equivalence_bitwise(H):
+    """Utterances never interact inside the step (decoder_cell.py:180-195 is row-wise), so
+    decoding a batch in two shards must equal decoding it whole, bit for bit.
+    Shards of >= 192 rows use the same GEMM tiling as the whole batch."""
+    dims = O.DecoderDims()
+    wts = O.random_decoder_weights(dims, seed=1)
+    B, L, T = 384, 64, 12
+    mem = O.synthetic_memory(B, L, dims.d_ctx, seed=5).cuda()
+    masks = O.synthetic_masks(T, B, dims.d_pre, seed=6)
+    dec = H.make_decoder(dims, wts)
+    y, s, w, _ = H.run_decoder_with_masks(dec, mem, masks, max_steps=T - 1)
+    ya, sa, wa, _ = H.run_decoder_with_masks(dec, mem[:192], masks[:, :, :192].contiguous(), max_steps=T - 1)
+    yb, sb, wb, _ = H.run_decoder_with_masks(dec, mem[192:], masks[:, :, 192:].contiguous(), max_steps=T - 1)
+    assert torch.equal(y, torch.cat([ya, yb])) and torch.equal(w, torch.cat([wa, wb])) and torch.equal(s, torch.cat([sa, sb]))
+
+
+def test_tacotron_forward_glue(H):
+    """Tacotron.forward / build_tacotron (tacotron.py:29-56,165-224) end to end on the GPU:
+    shapes, dict keys, and y_post == postnet(y)."""
+    import torch_tts_amd as T
+
+    cfg = {
+        "text": {"alphabet": "abcdefghijklmnopqrstuvwxyz '.,?!"},
+        "audio": {"num_mels": 80},
+        "model": {
+            "encoder": {"dim_emb": 64, "dim_out": 512},
+            "decoder": {"type": "tacotron2prod", "r": 1, "dim_pre": 256, "dim_att": 1024, "dim_rnn": [1024, 1024]},
+            "postnet": {"type": "tacotron2", "dim_hidden": 512, "num_layers": 3},
+        },
+    }
+    torch.manual_seed(0)
+    model = T.build_tacotron(cfg).cuda().eval()
+    ids = torch.randint(1, 30, (4, 21)).cuda()
+    lens = torch.tensor([21, 17, 9, 21]).cuda()
+    ids[1, 17:] = 0
+    ids[2, 9:] = 0
+    with torch.no_grad():
+        y, y_post, s, out = model(ids, lens, max_steps=15)
+        assert y.shape == (4, 16, 80) and y_post.shape == y.shape and s.shape == (4, 16, 1)
+        assert out["w"].shape == (4, 16, 21) and float(out["kl_loss"]) == 0.0
+        assert torch.equal(y_post, model.postnet(y))

@@ -1,0 +1,187 @@
+"""CPU tests of the host side: the C-ABI library loads and exports every symbol the
+header declares (no compute without a GPU), host-only queries, the reference-compatible
+RNG replay, the module API surface / state-dict keys, and the loud failure on CPU tensors."""
+import os
+import re
+
+import pytest
+import torch
+
+import torch_tts_amd as T
+from oracle import tacotron_oracle as O
+from torch_tts_amd import _lib
+from torch_tts_amd.rng import MaskStream
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_library_exports_every_declared_symbol():
+    hdr = open(os.path.join(ROOT, "include", "ttsdec.h")).read()
+    hdr = re.sub(r"/\*.*?\*/", "", hdr, flags=re.S)
+    declared = set(re.findall(r"\b(ttsdec_[a-z_0-9]+)\s*\(", hdr))
+    assert declared == set(_lib.SYMBOLS), declared ^ set(_lib.SYMBOLS)
+    lib = _lib.load()
+    for sym in declared:
+        assert hasattr(lib, sym), sym
+    assert lib.ttsdec_version() == 1
+    assert lib.ttsdec_strerror(0) == b"ok"
+    assert b"multiples of 4" in lib.ttsdec_strerror(_lib.ERR_DIMS)
+
+
+def test_host_only_queries_and_layout_sizes():
+    e = T.Engine(T.EngineDims(postnet_layers=3), None)
+    assert e.num_weight_tensors() == 21 + 5 * 3 + 1
+    # 18 577 489 decoder params + 4 initial-state vectors + postnet, padded per tensor to 256 B
+    n_dec = 86528 + 7348224 + 524288 + 10493952 + 124497
+    assert n_dec == 18577489
+    assert e.packed_bytes() >= 4 * n_dec and e.packed_bytes() % 256 == 0
+    assert e.packed_bytes() < 4 * (n_dec + 2870272) * 1.01 + 64 * 256
+    w1, w2 = e.workspace_bytes(64, 120), e.workspace_bytes(256, 120)
+    assert 0 < w1 < w2 and w2 % 256 == 0
+    assert e.postnet_workspace_bytes(256, 600) == 2 * 256 * 600 * 512 * 4
+    assert T.Engine(T.EngineDims(), None).num_weight_tensors() == 21
+    e.close()
+
+
+def test_bad_dims_and_unbound_handle_are_errors_not_crashes():
+    with pytest.raises(_lib.TtsdecError) as ei:
+        T.Engine(T.EngineDims(d_pre=255), None)
+    assert ei.value.code == _lib.ERR_DIMS
+    with pytest.raises(_lib.TtsdecError):
+        T.Engine(T.EngineDims(postnet_layers=9), None)
+    e = T.Engine(T.EngineDims(), None)
+    lib = _lib.load()
+    dummy = 256  # never dereferenced: the call must stop at the unbound-weights check
+    rc = lib.ttsdec_decode(e._h, dummy, 2, 3, 0, 1, 1, -2.0, 1, 0, None, 0, None, 0, None, dummy, dummy, dummy, None, dummy, 1 << 30, None)
+    assert rc == _lib.ERR_NOT_BOUND
+    assert lib.ttsdec_decode(e._h, None, 2, 3, 0, 1, 1, -2.0, 1, 0, None, 0, None, 0, None, dummy, dummy, dummy, None, dummy, 0, None) == _lib.ERR_INVALID_ARG
+    assert lib.ttsdec_postnet(e._h, dummy, 1, 1, 0, dummy, dummy, 0, None) == _lib.ERR_DIMS  # no postnet in these dims
+    e.close()
+
+
+def test_modules_refuse_cpu_tensors_loudly():
+    dims = O.DecoderDims(d_mel=8, d_pre=16, d_ctx=32, h_att=32, h_dec=32)
+    cell = T.Taco2ProdDecoderCell(dims.d_ctx, dims.d_mel, 1, [dims.h_att, dims.h_dec], dim_pre=dims.d_pre)
+    dec = T.Decoder(cell, 1, dims.d_mel).eval()
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        dec(torch.zeros(2, 5, 32), None, None, 3)
+    with pytest.raises(RuntimeError, match="HIP path only"):
+        T.MelPostnet(8, 16, 5, 2).eval()(torch.zeros(1, 4, 8))
+    with pytest.raises(NotImplementedError):
+        cell.pre_net(torch.zeros(1, 8))
+
+
+def test_state_dict_keys_match_the_reference(golden):
+    d = golden["meta"]["small_dims"]
+    cell = T.Taco2ProdDecoderCell(d["d_ctx"], d["d_mel"], d["r"], [d["h_att"], d["h_dec"]], dim_pre=d["d_pre"], dim_att=d["h_att"])
+    dec = T.Decoder(cell, d["r"], d["d_mel"])
+    assert set(dec.state_dict().keys()) == set(golden["dec"].keys())
+    for k, v in dec.state_dict().items():
+        assert tuple(v.shape) == tuple(golden["dec"][k].shape), k
+    dec.load_state_dict(golden["dec"], strict=True)
+    pn = T.MelPostnet(d["d_mel"], d["postnet_hidden"], 5, d["postnet_layers"])
+    keys = {k for k in pn.state_dict().keys() if not k.endswith("num_batches_tracked")}
+    assert keys == set(golden["post"].keys())
+    # attribute surface the callers read (decoder.py:6-14, decoder_cell.py:150)
+    for attr in ("decoder_cell", "r", "dim_mel", "stop_threshold", "fc_mel", "fc_stop"):
+        assert hasattr(dec, attr)
+    assert cell.dim_output == d["h_dec"] + d["d_ctx"]
+    w0, ctx0, hc = cell.initial_state(3, 7, torch.float32, "cpu")
+    assert w0.shape == (3, 7) and float(w0[:, 0].min()) == 1.0 and float(w0[:, 1:].abs().max()) == 0.0
+    assert ctx0.shape == (3, d["d_ctx"]) and hc[0][0].shape == (3, d["h_att"]) and hc[1][1].shape == (3, d["h_dec"])
+
+
+def test_weight_tensor_order_matches_header_enum(golden):
+    d = golden["meta"]["small_dims"]
+    cell = T.Taco2ProdDecoderCell(d["d_ctx"], d["d_mel"], d["r"], [d["h_att"], d["h_dec"]], dim_pre=d["d_pre"])
+    dec = T.Decoder(cell, d["r"], d["d_mel"])
+    ts = dec.weight_tensors()
+    assert len(ts) == _lib.W_DECODER_COUNT
+    shapes = [tuple(t.shape) for t in ts]
+    P, D, Ha, Hd, M = d["d_pre"], d["d_ctx"], d["h_att"], d["h_dec"], d["d_mel"]
+    assert shapes == [
+        (P, M), (P,), (P, P), (P,), (D, Ha),
+        (4 * Ha, P + D), (4 * Ha, Ha), (4 * Ha,), (4 * Ha,),
+        (4 * Hd, Ha + D), (4 * Hd, Hd), (4 * Hd,), (4 * Hd,),
+        (1, Ha), (1, Hd), (1, Ha), (1, Hd),
+        (M, Hd + D), (M,), (1, Hd + D), (1,),
+    ]
+    pn = T.MelPostnet(M, 64, 5, 3)
+    pts = pn.weight_tensors()
+    assert len(pts) == 21 + 16 and all(t is None for t in pts[:21]) and tuple(pts[21].shape) == (64, M, 5)
+
+
+def test_mask_stream_replays_reference_draws_and_rewinds():
+    B, P = 3, 36
+    torch.manual_seed(7)
+    ref = [torch.stack(O.draw_prenet_masks(B, P, P)) for _ in range(6)]
+    ref_next = torch.rand(1)
+    torch.manual_seed(7)
+    ms = MaskStream(B, P)
+    m1, f1 = ms.draw(4)
+    m2, _ = ms.draw(2)
+    assert torch.equal(torch.cat([m1, m2]), torch.stack(ref)) and bool(f1.all())
+    assert torch.equal(torch.rand(1), ref_next)
+    # early stop after 3 of 10 drawn steps: generator must be where the reference leaves it
+    torch.manual_seed(7)
+    ms = MaskStream(B, P)
+    ms.draw(10)
+    ms.rewind_to(3)
+    torch.manual_seed(7)
+    for _ in range(3):
+        O.draw_prenet_masks(B, P, P)
+    expect = torch.rand(1)
+    torch.manual_seed(7)
+    ms = MaskStream(B, P)
+    ms.draw(10)
+    ms.rewind_to(3)
+    assert torch.equal(torch.rand(1), expect)
+
+
+def test_mask_stream_teacher_flags_follow_decoder_py_65(golden):
+    c, m = golden["cases"], golden["meta"]["teacher_p"]
+    torch.manual_seed(m["seed"])
+    ms = MaskStream(3, 36, 0.5, p_no_forcing=m["p_no_forcing"], teacher_steps=m["Tx"])
+    masks, flags = ms.draw(m["Tx"])
+    assert torch.equal(masks, c["teacher_p/masks"])
+    assert torch.equal(flags[:-1], c["teacher_p/flags"]) and int(flags[-1]) == 1
+
+
+def test_philox_restatement_is_balanced_and_keyed():
+    a = O.philox_keep_masks(1, 0, 64, 256)
+    b = O.philox_keep_masks(1, 1, 64, 256)
+    c = O.philox_keep_masks(2, 0, 64, 256)
+    assert a.shape == (2, 64, 256)
+    assert 0.45 < float(a.float().mean()) < 0.55
+    assert not torch.equal(a, b) and not torch.equal(a, c) and not torch.equal(a[0], a[1])
+    assert torch.equal(a, O.philox_keep_masks(1, 0, 64, 256))
+
+
+def test_lengths_to_mask_and_build_tacotron_surface():
+    m = T.lengths_to_mask(torch.tensor([3, 1, 2]))
+    assert m.tolist() == [[True, True, True], [True, False, False], [True, True, False]]
+    cfg = {
+        "text": {"alphabet": "abc"},
+        "audio": {"num_mels": 8},
+        "model": {
+            "encoder": {"dim_emb": 8, "dim_out": 16},
+            "decoder": {"type": "tacotron2prod", "r": 1, "dim_pre": 8, "dim_att": 16, "dim_rnn": [16, 12]},
+            "postnet": {"type": "tacotron2", "dim_hidden": 16, "num_layers": 2},
+        },
+    }
+    model = T.build_tacotron(cfg)
+    assert isinstance(model.decoder, T.Decoder) and isinstance(model.postnet, T.MelPostnet)
+    assert model.decoder.decoder_cell.dim_output == 12 + 16
+    # encoder is stock PyTorch and runs on CPU (outside the hot path); padded rows are exactly zero
+    ids = torch.tensor([[1, 2, 3, 1], [2, 1, 0, 0]])
+    mem = model.eval().encoder(ids, torch.tensor([4, 2]))
+    assert mem.shape == (2, 4, 16) and float(mem[1, 2:].abs().max()) == 0.0
+    import copy
+    import pickle
+
+    model2 = pickle.loads(pickle.dumps(model))  # nn.DataParallel / checkpointing need this
+    assert set(model2.state_dict().keys()) == set(model.state_dict().keys())
+    copy.deepcopy(model)
+    cfg["model"]["decoder"]["type"] = "tacotron2"
+    with pytest.raises(NotImplementedError):
+        T.build_tacotron(cfg)

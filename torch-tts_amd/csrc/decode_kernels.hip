@@ -1,0 +1,433 @@
+// Decode-step kernels for gfx950 (MI355X).  One decode step of the reference
+// (tacotron/decoder.py:47-58 around tacotron/decoder_cell.py:180-195) is the launch
+// sequence  prenet0 -> prenet1 -> lstm(att) -> query -> attention+context -> lstm(dec) -> proj.
+// Kernel boundaries are the all-to-all seams of the step (every output row needs a whole
+// hidden vector produced by all workgroups of the previous phase).
+#include "gemm_tile.h"
+#include "kernels.h"
+
+namespace ttsdec {
+
+// ===========================================================================
+// generic row GEMM:  out[m, n] = epi( sum_k A[m, k] * W[n, k] )
+// ===========================================================================
+struct LoaderPlain {
+  Seg3 s;
+  int m0, M;
+  __device__ __forceinline__ float4 load(int r, int k) const {
+    const int m = m0 + r;
+    if (m >= M) return make_float4(0.f, 0.f, 0.f, 0.f);
+    return seg_load4(s, m, k);
+  }
+};
+
+// implicit im2col for Conv1d(k, padding=(k-1)/2) on channel-last activations
+struct LoaderConv {
+  const float* x;
+  int m0, M, T, Cin, taps, K;
+  __device__ __forceinline__ float4 load(int r, int k) const {
+    const int m = m0 + r;
+    if (m >= M || k >= K) return make_float4(0.f, 0.f, 0.f, 0.f);
+    const int tap = k / Cin;
+    const int c = k - tap * Cin;
+    const int t = m % T;
+    const int tt = t + tap - (taps >> 1);
+    if (tt < 0 || tt >= T) return make_float4(0.f, 0.f, 0.f, 0.f);
+    return *reinterpret_cast<const float4*>(x + (size_t)(m - t + tt) * Cin + c);
+  }
+};
+
+struct LoaderW {
+  const float* W;
+  int ldw, n0, N, K;
+  __device__ __forceinline__ float4 load(int r, int k) const {
+    const int n = n0 + r;
+    if (n >= N || k >= K) return make_float4(0.f, 0.f, 0.f, 0.f);
+    return *reinterpret_cast<const float4*>(W + (size_t)n * ldw + k);
+  }
+};
+
+template <class Cfg, int AK, int EK>
+__global__ __launch_bounds__(kGemmThreads) void gemm_rows_kernel(GemmArgs g) {
+  if (g.ctrl != nullptr && g.t > g.ctrl->stop_t) return;
+  __shared__ __attribute__((aligned(16))) float smem[Cfg::kLdsFloats];
+  constexpr int BM = Cfg::BM, BN = Cfg::BN, LDO = Cfg::LDO;
+  const int m0 = blockIdx.y * BM;
+  const int n0 = blockIdx.x * BN;
+  const LoaderW lb{g.W, g.ldw, n0, g.N, g.K};
+  if (AK == A_CONV) {
+    const LoaderConv la{g.a.p0, m0, g.M, g.T, g.Cin, g.taps, g.K};
+    gemm_tile_f32<Cfg>(la, lb, g.K, smem);
+  } else {
+    Seg3 s = g.a;
+    if (g.teacher != nullptr && g.t > 0 && g.teacher_flags[g.t - 1] != 0) {
+      // decoder.py:65-66: next input = last frame of teacher group t-1 = teacher frame t*r - 1
+      s = make_seg1(g.teacher + (size_t)(g.t * g.r - 1) * g.d_mel, g.teacher_T * g.d_mel, g.d_mel);
+    }
+    const LoaderPlain la{s, m0, g.M};
+    gemm_tile_f32<Cfg>(la, lb, g.K, smem);
+  }
+
+  for (int e = threadIdx.x; e < BM * BN; e += kGemmThreads) {
+    const int row = e / BN, col = e % BN;
+    const int m = m0 + row, n = n0 + col;
+    if (m >= g.M || n >= g.N) continue;
+    float v = smem[row * LDO + col];
+    if (g.bias != nullptr) v = add_rn(v, g.bias[n]);
+    if (EK == EPI_PLAIN) {
+      g.out[(size_t)m * g.ldo + n] = v;
+    } else if (EK == EPI_RELU_DROPOUT) {
+      // modules.py:39-40: relu then dropout(p, always): kept units scaled by 1/(1-p)
+      v = v > 0.f ? v : 0.f;
+      if (g.dropout_mode == TTSDEC_DROPOUT_MASKS) {
+        v = g.masks[(size_t)m * g.N + n] ? mul_rn(v, g.keep_scale) : 0.f;
+      } else if (g.dropout_mode == TTSDEC_DROPOUT_PHILOX) {
+        v = philox_keep(g.seed, (uint32_t)g.t, (uint32_t)g.layer, (uint32_t)m, (uint32_t)n) ? mul_rn(v, g.keep_scale) : 0.f;
+      }
+      g.out[(size_t)m * g.ldo + n] = v;
+    } else if (EK == EPI_PROJ) {
+      const int nm = g.r * g.d_mel;
+      if (n < nm) {
+        // decoder.py:53-54: leaky_relu(fc_mel(d_t), 0.01) viewed as [B, r, d_mel]
+        v = v > 0.f ? v : mul_rn(v, 0.01f);
+        const int j = n / g.d_mel, c = n - j * g.d_mel;
+        g.y_out[((size_t)m * g.t_stride * g.r + (size_t)g.t_rel * g.r + j) * g.d_mel + c] = v;
+        if (j == g.r - 1) g.ynext[(size_t)m * g.d_mel + c] = v;  // decoder.py:48 y_t[:, -1, :]
+      } else {
+        // decoder.py:52 stop logit; decoder.py:68 batch-global rule
+        const int j = n - nm;
+        g.s_out[(size_t)m * g.t_stride * g.r + (size_t)g.t_rel * g.r + j] = v;
+        if (g.check_stop && v < g.stop_thr) atomicMin(&g.ctrl->stop_t, g.t);
+      }
+    } else if (EK == EPI_BN_ISRU) {
+      // modules.py:181 isru(BatchNorm1d(conv(x))) with eval-mode BN as x*alpha + beta
+      v = isru(add_rn(mul_rn(v, g.alpha[n]), g.beta[n]));
+      g.out[(size_t)m * g.ldo + n] = v;
+    } else if (EK == EPI_RESIDUAL) {
+      // modules.py:184 x + fc_out(...)
+      g.out[(size_t)m * g.ldo + n] = add_rn(g.resid[(size_t)m * g.ldo + n], v);
+    }
+  }
+}
+
+template <int AK, int EK>
+static void launch_gemm_cfg(const GemmArgs& a, hipStream_t st) {
+  // Pick the tile so the grid covers the 256 CUs when it can; small M uses 32x32 tiles
+  // with the four waves splitting K.
+  const long tiles_big = (long)((a.M + 63) / 64) * ((a.N + 63) / 64);
+  if (a.M >= 64 && tiles_big >= 512) {
+    using Cfg = TileCfg<2, 2, 1>;
+    dim3 grid((a.N + Cfg::BN - 1) / Cfg::BN, (a.M + Cfg::BM - 1) / Cfg::BM);
+    hipLaunchKernelGGL((gemm_rows_kernel<Cfg, AK, EK>), grid, dim3(kGemmThreads), 0, st, a);
+  } else {
+    using Cfg = TileCfg<1, 1, 4>;
+    dim3 grid((a.N + Cfg::BN - 1) / Cfg::BN, (a.M + Cfg::BM - 1) / Cfg::BM);
+    hipLaunchKernelGGL((gemm_rows_kernel<Cfg, AK, EK>), grid, dim3(kGemmThreads), 0, st, a);
+  }
+}
+
+void launch_gemm(const GemmArgs& a, AKind ak, EpiKind ek, hipStream_t st) {
+  if (a.M <= 0 || a.N <= 0) return;
+  if (ak == A_CONV && ek == EPI_BN_ISRU) return launch_gemm_cfg<A_CONV, EPI_BN_ISRU>(a, st);
+  switch (ek) {
+    case EPI_PLAIN: return launch_gemm_cfg<A_PLAIN, EPI_PLAIN>(a, st);
+    case EPI_RELU_DROPOUT: return launch_gemm_cfg<A_PLAIN, EPI_RELU_DROPOUT>(a, st);
+    case EPI_PROJ: return launch_gemm_cfg<A_PLAIN, EPI_PROJ>(a, st);
+    case EPI_RESIDUAL: return launch_gemm_cfg<A_PLAIN, EPI_RESIDUAL>(a, st);
+    default: return;
+  }
+}
+
+// ===========================================================================
+// LSTMZoneoutCell (eval), tacotron/modules/rnn.py:24-39.  A workgroup owns BU hidden
+// units x BM batch rows and computes all four gates of those units (B-tile rows are
+// gathered from the i/f/g/o row blocks of the PyTorch-layout weights), so the cell
+// update happens in the epilogue without another pass.
+// ===========================================================================
+template <int BU>
+struct LoaderWLstm {
+  Seg3 w;
+  int u0, H;
+  __device__ __forceinline__ float4 load(int r, int k) const {
+    const int gate = r / BU;
+    const int unit = u0 + (r - gate * BU);
+    if (unit >= H) return make_float4(0.f, 0.f, 0.f, 0.f);
+    return seg_load4(w, gate * H + unit, k);
+  }
+};
+
+template <class Cfg>
+__global__ __launch_bounds__(kGemmThreads) void lstm_kernel(LstmArgs g) {
+  if (g.ctrl != nullptr && g.t > g.ctrl->stop_t) return;
+  __shared__ __attribute__((aligned(16))) float smem[Cfg::kLdsFloats];
+  constexpr int BM = Cfg::BM, BN = Cfg::BN, LDO = Cfg::LDO, BU = BN / 4;
+  const int m0 = blockIdx.y * BM;
+  const int u0 = blockIdx.x * BU;
+  const LoaderPlain la{g.a, m0, g.M};
+  const LoaderWLstm<BU> lb{g.w, u0, g.H};
+  gemm_tile_f32<Cfg>(la, lb, g.K, smem);
+
+  const int H = g.H;
+  for (int e = threadIdx.x; e < BM * BU; e += kGemmThreads) {
+    const int row = e / BU, u = e % BU;
+    const int m = m0 + row, unit = u0 + u;
+    if (m >= g.M || unit >= H) continue;
+    const float* tr = smem + row * LDO;
+    const float gi = add_rn(tr[0 * BU + u], g.bsum[0 * H + unit]);
+    const float gf = add_rn(tr[1 * BU + u], g.bsum[1 * H + unit]);
+    const float gg = add_rn(tr[2 * BU + u], g.bsum[2 * H + unit]);
+    const float go = add_rn(tr[3 * BU + u], g.bsum[3 * H + unit]);
+    const size_t idx = (size_t)m * H + unit;
+    const float c_prev = g.c[idx];
+    const float h_prev = g.h_prev[idx];
+    // nn.LSTMCell: c' = sigmoid(f)*c + sigmoid(i)*tanh(g); h' = sigmoid(o)*tanh(c')
+    const float c_new = add_rn(mul_rn(sigmoid_f(gf), c_prev), mul_rn(sigmoid_f(gi), tanhf(gg)));
+    const float h_new = mul_rn(sigmoid_f(go), tanhf(c_new));
+    // rnn.py:36-38 eval-mode zoneout: p*prev + (1-p)*new
+    const float q = sub_rn(1.0f, g.pz);
+    g.h_out[idx] = add_rn(mul_rn(g.pz, h_prev), mul_rn(q, h_new));
+    g.c[idx] = add_rn(mul_rn(g.pz, c_prev), mul_rn(q, c_new));
+  }
+}
+
+void launch_lstm(const LstmArgs& a, hipStream_t st) {
+  if (a.M <= 0) return;
+  if (a.M >= 192) {
+    using Cfg = TileCfg<2, 2, 1>;  // 64 rows x 16 units
+    dim3 grid((a.H + 15) / 16, (a.M + 63) / 64);
+    hipLaunchKernelGGL((lstm_kernel<Cfg>), grid, dim3(kGemmThreads), 0, st, a);
+  } else if (a.M >= 96) {
+    using Cfg = TileCfg<2, 1, 2>;  // 64 rows x 8 units
+    dim3 grid((a.H + 7) / 8, (a.M + 63) / 64);
+    hipLaunchKernelGGL((lstm_kernel<Cfg>), grid, dim3(kGemmThreads), 0, st, a);
+  } else {
+    using Cfg = TileCfg<1, 1, 4>;  // 32 rows x 8 units
+    dim3 grid((a.H + 7) / 8, (a.M + 31) / 32);
+    hipLaunchKernelGGL((lstm_kernel<Cfg>), grid, dim3(kGemmThreads), 0, st, a);
+  }
+}
+
+// ===========================================================================
+// StepwiseMonotonicAttention + context (tacotron/modules/attention.py:104-126,
+// tacotron/decoder_cell.py:189).  One workgroup per utterance, 8 waves; a wave
+// owns a contiguous range of memory rows and makes ONE pass over them: each row
+// is loaded once (float4 per lane, coalesced), dotted with q (wave butterfly),
+// turned into p0 and the new weight, and accumulated into the context while it
+// is still in registers.  Row l needs p0[l-1], so a wave recomputes the energy
+// of the row just before its range.
+// ===========================================================================
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int off = 32; off >= 1; off >>= 1) v += __shfl_xor(v, off, 64);
+  return v;
+}
+
+template <int NJ>
+__global__ __launch_bounds__(kAttnThreads) void attn_kernel(AttnArgs g) {
+  if (g.ctrl != nullptr && g.t > g.ctrl->stop_t) return;
+  constexpr int NW = kAttnThreads / 64;
+  __shared__ __attribute__((aligned(16))) float part[NW * NJ * 256];
+  const int b = blockIdx.x;
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const int L = g.L, D = g.D, D4 = D >> 2;
+  const float* mem = g.memory + (size_t)b * L * D;
+  const float* wprev = g.w_prev + (size_t)b * L;
+  float* wnew = g.w_new + (size_t)b * L;
+  float* wout = g.w_out ? g.w_out + ((size_t)b * g.t_stride + g.t_rel) * L : nullptr;
+
+  float4 qv[NJ];
+#pragma unroll
+  for (int j = 0; j < NJ; ++j) {
+    const int c4 = lane + 64 * j;
+    qv[j] = (c4 < D4) ? *reinterpret_cast<const float4*>(g.q + (size_t)b * D + c4 * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
+  }
+  auto load_row = [&](int l, float4 (&r)[NJ]) {
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) {
+      const int c4 = lane + 64 * j;
+      r[j] = (c4 < D4) ? *reinterpret_cast<const float4*>(mem + (size_t)l * D + c4 * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+  };
+  auto dot_row = [&](const float4 (&r)[NJ]) {
+    float s = 0.f;
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) {
+      s = fmaf(r[j].x, qv[j].x, s);
+      s = fmaf(r[j].y, qv[j].y, s);
+      s = fmaf(r[j].z, qv[j].z, s);
+      s = fmaf(r[j].w, qv[j].w, s);
+    }
+    return wave_sum(s);
+  };
+
+  const int chunk = (L + NW - 1) / NW;
+  const int l0 = wv * chunk;
+  const int l1 = (l0 + chunk < L) ? l0 + chunk : L;
+
+  float4 acc[NJ];
+#pragma unroll
+  for (int j = 0; j < NJ; ++j) acc[j] = make_float4(0.f, 0.f, 0.f, 0.f);
+
+  if (l0 < l1) {
+    float w1_prev = 0.f;  // w[l-1] * (1 - p0[l-1])   attention.py:120
+    if (l0 > 0) {
+      float4 r[NJ];
+      load_row(l0 - 1, r);
+      const float p0 = isru_sigmoid(dot_row(r));  // l0-1 < L-1, never the overridden column
+      w1_prev = mul_rn(wprev[l0 - 1], sub_rn(1.0f, p0));
+    }
+    constexpr int G = 4;  // rows in flight per wave
+    for (int lb = l0; lb < l1; lb += G) {
+      float4 r[G][NJ];
+      float e[G];
+#pragma unroll
+      for (int i = 0; i < G; ++i)
+        if (lb + i < l1) load_row(lb + i, r[i]);
+#pragma unroll
+      for (int i = 0; i < G; ++i)
+        if (lb + i < l1) e[i] = dot_row(r[i]);
+#pragma unroll
+      for (int i = 0; i < G; ++i) {
+        const int l = lb + i;
+        if (l < l1) {
+          const float en = (l == L - 1) ? 1e4f : e[i];  // attention.py:117
+          const float p0 = isru_sigmoid(en);            // attention.py:118
+          const float wl = wprev[l];
+          const float w0 = mul_rn(wl, p0);                      // :119
+          const float wn = (l > 0) ? add_rn(w0, w1_prev) : w0;  // :122-123
+          w1_prev = mul_rn(wl, sub_rn(1.0f, p0));               // :120
+          if (lane == 0) {
+            wnew[l] = wn;
+            if (wout) wout[l] = wn;
+          }
+#pragma unroll
+          for (int j = 0; j < NJ; ++j) {
+            acc[j].x = fmaf(wn, r[i][j].x, acc[j].x);
+            acc[j].y = fmaf(wn, r[i][j].y, acc[j].y);
+            acc[j].z = fmaf(wn, r[i][j].z, acc[j].z);
+            acc[j].w = fmaf(wn, r[i][j].w, acc[j].w);
+          }
+        }
+      }
+    }
+  }
+  // cross-wave sum of the context partials in a fixed order (deterministic)
+#pragma unroll
+  for (int j = 0; j < NJ; ++j)
+    *reinterpret_cast<float4*>(part + ((wv * NJ + j) * 64 + lane) * 4) = acc[j];
+  __syncthreads();
+  for (int d = threadIdx.x; d < D; d += kAttnThreads) {
+    const int c4 = d >> 2, comp = d & 3;
+    const int j = c4 >> 6, ln = c4 & 63;
+    float s = 0.f;
+#pragma unroll
+    for (int w = 0; w < NW; ++w) s += part[((w * NJ + j) * 64 + ln) * 4 + comp];
+    g.ctx[(size_t)b * D + d] = s;
+  }
+}
+
+void launch_attn(const AttnArgs& a, hipStream_t st) {
+  if (a.B <= 0) return;
+  const int d4 = a.D / 4;
+  dim3 grid(a.B), block(kAttnThreads);
+  if (d4 <= 64) hipLaunchKernelGGL((attn_kernel<1>), grid, block, 0, st, a);
+  else if (d4 <= 128) hipLaunchKernelGGL((attn_kernel<2>), grid, block, 0, st, a);
+  else hipLaunchKernelGGL((attn_kernel<4>), grid, block, 0, st, a);
+}
+
+// ===========================================================================
+// state init (decoder_cell.py:9-17,165-178; decoder.py:35) and bookkeeping
+// ===========================================================================
+__global__ void init_state_kernel(InitArgs g) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i == 0) {
+    g.ctrl->stop_t = kStopNever;
+    g.ctrl->steps_done = 0;
+  }
+  const size_t nHa = (size_t)g.B * g.Ha, nHd = (size_t)g.B * g.Hd;
+  if (i < nHa) {
+    g.h_att[i] = g.h0_att[i % g.Ha];
+    g.c_att[i] = g.c0_att[i % g.Ha];
+  }
+  if (i < nHd) {
+    g.h_dec[i] = g.h0_dec[i % g.Hd];
+    g.c_dec[i] = g.c0_dec[i % g.Hd];
+  }
+  if (i < (size_t)g.B * g.D) g.ctx[i] = 0.f;
+  if (i < (size_t)g.B * g.L) g.w[i] = (i % g.L == 0) ? 1.0f : 0.f;
+  if (i < (size_t)g.B * g.d_mel) g.ynext[i] = 0.f;
+}
+
+void launch_init(const InitArgs& a, hipStream_t st) {
+  size_t n = (size_t)a.B * a.Ha;
+  const size_t c[] = {(size_t)a.B * a.Hd, (size_t)a.B * a.D, (size_t)a.B * a.L, (size_t)a.B * a.d_mel};
+  for (size_t v : c) n = v > n ? v : n;
+  hipLaunchKernelGGL(init_state_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, a);
+}
+
+__global__ void finish_kernel(Ctrl* ctrl, int t_end, int32_t* T_out) {
+  const int stop = ctrl->stop_t;
+  const int fired = (stop != kStopNever && stop < t_end) ? 1 : 0;
+  const int done = fired ? stop + 1 : t_end;
+  ctrl->steps_done = done;
+  if (T_out) {
+    T_out[0] = done;
+    T_out[1] = fired;
+  }
+}
+
+void launch_finish(Ctrl* ctrl, int t_end, int32_t* T_out, hipStream_t st) {
+  hipLaunchKernelGGL(finish_kernel, dim3(1), dim3(1), 0, st, ctrl, t_end, T_out);
+}
+
+// ===========================================================================
+// weight packing helpers
+// ===========================================================================
+__global__ void add_vec_kernel(const float* a, const float* b, float* out, int n) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) out[i] = add_rn(a[i], b[i]);
+}
+void launch_add_vec(const float* a, const float* b, float* out, int n, hipStream_t st) {
+  hipLaunchKernelGGL(add_vec_kernel, dim3((n + 255) / 256), dim3(256), 0, st, a, b, out, n);
+}
+
+__global__ void copy_kernel(const float* src, float* dst, size_t n) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) dst[i] = src[i];
+}
+void launch_copy(const float* src, float* dst, size_t n, hipStream_t st) {
+  if (n == 0 || src == nullptr) return;
+  hipLaunchKernelGGL(copy_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, src, dst, n);
+}
+
+__global__ void conv_transpose_kernel(const float* w, float* out, int Co, int Ci, int k) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const size_t n = (size_t)Co * Ci * k;
+  if (i >= n) return;
+  // out[co][tap][ci] = w[co][ci][tap]
+  const int ci = (int)(i % Ci);
+  const int tap = (int)((i / Ci) % k);
+  const int co = (int)(i / ((size_t)Ci * k));
+  out[i] = w[((size_t)co * Ci + ci) * k + tap];
+}
+void launch_conv_transpose(const float* w, float* out, int Co, int Ci, int k, hipStream_t st) {
+  const size_t n = (size_t)Co * Ci * k;
+  hipLaunchKernelGGL(conv_transpose_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, w, out, Co, Ci, k);
+}
+
+__global__ void bn_fold_kernel(const float* gamma, const float* betap, const float* mean, const float* var, float eps,
+                               float* alpha, float* beta, int n) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  // eval-mode BatchNorm1d as y = x*alpha + beta, alpha = gamma/sqrt(var+eps), beta = b - mean*alpha
+  const float invstd = div_rn(1.0f, sqrt_rn(add_rn(var[i], eps)));
+  const float a = mul_rn(invstd, gamma[i]);
+  alpha[i] = a;
+  beta[i] = sub_rn(betap[i], mul_rn(mean[i], a));
+}
+void launch_bn_fold(const float* gamma, const float* betap, const float* mean, const float* var, float eps, float* alpha,
+                    float* beta, int n, hipStream_t st) {
+  hipLaunchKernelGGL(bn_fold_kernel, dim3((n + 255) / 256), dim3(256), 0, st, gamma, betap, mean, var, eps, alpha, beta, n);
+}
+
+}  // namespace ttsdec

@@ -1,0 +1,101 @@
+// Internal launch interface between the C ABI (api.hip) and the kernels.
+#pragma once
+#include "common.h"
+
+namespace ttsdec {
+
+// ---- generic row-GEMM (PreNet layers, query projection, mel/stop projection, postnet) ----
+enum AKind { A_PLAIN = 0, A_CONV = 1 };
+enum EpiKind { EPI_PLAIN = 0, EPI_RELU_DROPOUT = 1, EPI_PROJ = 2, EPI_BN_ISRU = 3, EPI_RESIDUAL = 4 };
+
+struct GemmArgs {
+  // A operand.  A_PLAIN: up to three K segments of an [M, K] activation.
+  // A_CONV: implicit im2col of x [Bc*T, Cin] with `taps` taps centred on the row's frame:
+  //         A[m][tap*Cin + c] = x[b, t + tap - taps/2, c] (zero outside [0, T)).
+  Seg3 a;
+  int T, Cin, taps;
+  // B operand: W [N, K] row-major with leading dimension ldw.
+  const float* W;
+  int ldw;
+  int M, N, K;
+  // epilogue operands
+  const float* bias;   // [N] or nullptr
+  const float* alpha;  // EPI_BN_ISRU: out = isru(acc * alpha[n] + beta[n])
+  const float* beta;
+  const float* resid;  // EPI_RESIDUAL: out = resid[m, n] + acc
+  float* out;          // [M, ldo]
+  int ldo;
+  // EPI_RELU_DROPOUT
+  int dropout_mode;
+  const uint8_t* masks;  // [M, N] keep-mask of this (step, layer)
+  uint64_t seed;
+  int layer;
+  float keep_scale;  // 1 / (1 - p)
+  // EPI_PROJ: columns [0, r*d_mel) -> leaky_relu -> y, columns [r*d_mel, r*d_mel + r) -> stop logits
+  float* y_out;  // [B, t_stride*r, d_mel]
+  float* s_out;  // [B, t_stride*r]
+  float* ynext;  // [B, d_mel] last frame of the group (next step's PreNet input)
+  int r, d_mel, t_rel, t_stride;
+  float stop_thr;
+  int check_stop;
+  // teacher forcing (PreNet layer 0 only): input row source switches to the teacher frame
+  const float* teacher;  // [B, teacher_T, d_mel] or nullptr
+  int teacher_T;
+  const uint8_t* teacher_flags;
+  // step control
+  Ctrl* ctrl;  // nullptr: no stop check (postnet)
+  int t;       // absolute step index
+};
+
+void launch_gemm(const GemmArgs& a, AKind ak, EpiKind ek, hipStream_t st);
+
+// ---- LSTM zoneout cell: gates GEMM + cell update fused ----
+struct LstmArgs {
+  Seg3 a;  // [x | ctx | h_prev] segments, M rows
+  Seg3 w;  // matching segments of [W_ih | W_hh], rows = 4*H in PyTorch gate order i,f,g,o
+  const float* bsum;    // [4H] = b_ih + b_hh
+  const float* h_prev;  // [M, H]
+  float* c;             // [M, H] updated in place
+  float* h_out;         // [M, H]
+  int M, H, K;
+  float pz;  // zoneout probability (eval-mode blend)
+  Ctrl* ctrl;
+  int t;
+};
+void launch_lstm(const LstmArgs& a, hipStream_t st);
+
+// ---- stepwise monotonic attention + context ----
+struct AttnArgs {
+  const float* memory;  // [B, L, D]
+  const float* q;       // [B, D]
+  const float* w_prev;  // [B, L]
+  float* w_new;         // [B, L]
+  float* w_out;         // [B, t_stride, L] (row t_rel) or nullptr
+  float* ctx;           // [B, D]
+  int B, L, D, t_rel, t_stride;
+  Ctrl* ctrl;
+  int t;
+};
+void launch_attn(const AttnArgs& a, hipStream_t st);
+
+// ---- state init / bookkeeping ----
+struct InitArgs {
+  Ctrl* ctrl;
+  const float *h0_att, *c0_att, *h0_dec, *c0_dec;  // [H] initial_decoder_{h,c}
+  float *h_att, *c_att, *h_dec, *c_dec;            // [B, H]
+  float* ctx;                                      // [B, D]
+  float* w;                                        // [B, L]
+  float* ynext;                                    // [B, d_mel]
+  int B, L, D, Ha, Hd, d_mel;
+};
+void launch_init(const InitArgs& a, hipStream_t st);
+void launch_finish(Ctrl* ctrl, int t_end, int32_t* T_out, hipStream_t st);
+
+// ---- weight packing ----
+void launch_add_vec(const float* a, const float* b, float* out, int n, hipStream_t st);
+void launch_copy(const float* src, float* dst, size_t n, hipStream_t st);
+void launch_conv_transpose(const float* w /*[Co,Ci,k]*/, float* out /*[Co,k,Ci]*/, int Co, int Ci, int k, hipStream_t st);
+void launch_bn_fold(const float* gamma, const float* betap, const float* mean, const float* var, float eps, float* alpha,
+                    float* beta, int n, hipStream_t st);
+
+}  // namespace ttsdec

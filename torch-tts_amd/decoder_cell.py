@@ -1,0 +1,153 @@
+"""Drop-in for the reference's ``decoder_cell.Taco2ProdDecoderCell``
+(tacotron/decoder_cell.py:143-195): same constructor, attributes, parameter tree
+(state-dict keys) and ``initial_state`` / ``forward`` signatures; one step runs as
+HIP kernels through libttsdec (``ttsdec_cell_step``)."""
+from __future__ import annotations
+
+from typing import List, Optional, Sequence
+
+import torch
+import torch.nn as nn
+
+from . import _lib
+from .engine import EngineCache, EngineDims
+
+
+def _fused_only(name: str):
+    raise NotImplementedError(
+        f"{name} holds parameters only: on the HIP path it runs fused inside Taco2ProdDecoderCell / Decoder"
+    )
+
+
+class PreNet(nn.Module):
+    """Parameter holder for tacotron/modules/modules.py:15-41 (keys layers.{0,1}.{weight,bias})."""
+
+    def __init__(self, dim_input, dim_output, dim_hidden=256, p_dropout=0.5, always_dropout=False):
+        super().__init__()
+        self.p_dropout = p_dropout
+        self.always_dropout = always_dropout
+        self.layers = nn.ModuleList([nn.Linear(dim_input, dim_hidden), nn.Linear(dim_hidden, dim_output)])
+
+    def forward(self, x):
+        _fused_only("PreNet")
+
+
+class LSTMZoneoutCell(nn.LSTMCell):
+    """Parameter holder for tacotron/modules/rnn.py:19-39 (nn.LSTMCell keys and default init)."""
+
+    def __init__(self, input_size, hidden_size, bias=True, p_zoneout=None):
+        super().__init__(input_size, hidden_size, bias=bias)
+        self.p_zoneout = p_zoneout
+
+    def forward(self, x, hidden):
+        _fused_only("LSTMZoneoutCell")
+
+
+class StepwiseMonotonicAttention(nn.Module):
+    """Parameter holder for tacotron/modules/attention.py:96-126 (keys query_layer.weight, bias;
+    ``bias`` is unused by the reference's forward, kept for checkpoint compatibility)."""
+
+    def __init__(self, dim_input, dim_context, sigmoid_noise=1.0):
+        super().__init__()
+        self.sigmoid_noise = sigmoid_noise
+        self.query_layer = nn.Linear(dim_input, dim_context, bias=False)
+        self.bias = nn.Parameter(torch.Tensor([1.0]))
+
+    def forward(self, x, w, memory, cmask=None):
+        _fused_only("StepwiseMonotonicAttention")
+
+
+class Taco2ProdDecoderCell(nn.Module):
+    def __init__(self, dim_ctx, dim_mel, r, dim_rnn, dim_pre=128, dim_att=128, p_zoneout=0.1):
+        super().__init__()
+        dim_att_hidden, dim_dec_hidden = dim_rnn[0], dim_rnn[1]
+        self.dim_output = dim_dec_hidden + dim_ctx
+        self.dim_ctx, self.dim_mel, self.r, self.dim_pre = dim_ctx, dim_mel, r, dim_pre
+        self.p_zoneout = p_zoneout
+
+        self.pre_net = PreNet(dim_mel, dim_pre, always_dropout=True, dim_hidden=dim_pre)
+        self.attention_module = StepwiseMonotonicAttention(dim_att_hidden, dim_ctx)
+        self.attention_rnn = LSTMZoneoutCell(dim_pre + dim_ctx, dim_att_hidden, p_zoneout=p_zoneout)
+        self.decoder_rnn = LSTMZoneoutCell(dim_att_hidden + dim_ctx, dim_dec_hidden, p_zoneout=p_zoneout)
+        self.initial_decoder_h = nn.ParameterList(
+            [nn.Parameter(torch.zeros(1, dim_att_hidden)), nn.Parameter(torch.zeros(1, dim_dec_hidden))]
+        )
+        self.initial_decoder_c = nn.ParameterList(
+            [nn.Parameter(torch.zeros(1, dim_att_hidden)), nn.Parameter(torch.zeros(1, dim_dec_hidden))]
+        )
+        self.initial_ctx_0 = torch.zeros(1, dim_ctx)
+
+        # how the always-on PreNet dropout is sourced when the cell is driven directly:
+        #   "reference_rng": replay of the reference's CPU generator draws (default)
+        #   "philox":        on-device counter RNG keyed by (dropout_seed, step)
+        #   "off"
+        self.dropout_source = "reference_rng"
+        self.dropout_seed = 0
+        self._step_counter = 0
+        self._engines = EngineCache()
+
+    # ---- parameters in TTSDEC_W_* order (None for what the cell does not own) ----
+    def weight_tensors(self) -> List[Optional[torch.Tensor]]:
+        pn, at, ar, dr = self.pre_net, self.attention_module, self.attention_rnn, self.decoder_rnn
+        return [
+            pn.layers[0].weight, pn.layers[0].bias, pn.layers[1].weight, pn.layers[1].bias,
+            at.query_layer.weight,
+            ar.weight_ih, ar.weight_hh, ar.bias_ih, ar.bias_hh,
+            dr.weight_ih, dr.weight_hh, dr.bias_ih, dr.bias_hh,
+            self.initial_decoder_h[0], self.initial_decoder_h[1], self.initial_decoder_c[0], self.initial_decoder_c[1],
+        ]
+
+    def engine_dims(self) -> EngineDims:
+        return EngineDims(
+            d_mel=self.dim_mel, r=self.r, d_pre=self.dim_pre, d_ctx=self.dim_ctx,
+            h_att=self.attention_rnn.hidden_size, h_dec=self.decoder_rnn.hidden_size,
+            p_zoneout=float(self.p_zoneout or 0.0), p_dropout=float(self.pre_net.p_dropout),
+        )
+
+    def initial_state(self, batch_size, memory_size, dtype, device):
+        """(w_0 one-hot at position 0, ctx_0 zeros, [(h,c) attention rnn, (h,c) decoder rnn])
+        - decoder_cell.py:9-17,165-178."""
+        w_0 = torch.zeros(batch_size, memory_size, dtype=dtype, device=device)
+        w_0[:, 0] = 1.0
+        ctx_0 = self.initial_ctx_0.to(dtype=dtype, device=device).expand(batch_size, -1)
+        h_rnn_0 = [
+            (h.to(dtype=dtype, device=device).expand(batch_size, -1), c.to(dtype=dtype, device=device).expand(batch_size, -1))
+            for h, c in zip(self.initial_decoder_h, self.initial_decoder_c)
+        ]
+        return w_0, ctx_0, h_rnn_0
+
+    def forward(self, x, dec_state, memory, mmask):
+        """x [B, r, D_mel]; dec_state = (w, ctx, ((h_att,c_att),(h_dec,c_dec))); memory [B, L, D_ctx].
+        Returns (x_dec, ctx_att, dec_state) like decoder_cell.py:180-195.  Inference only."""
+        if not memory.is_cuda:
+            raise RuntimeError("Taco2ProdDecoderCell runs on the HIP path only: move the module and inputs to a ROCm device")
+        if torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters()):
+            raise NotImplementedError(
+                "autograd through the decoder cell is outside the HIP hot path (forward only): call under torch.no_grad()"
+            )
+        w_att, ctx_att, (hc_att, hc_dec) = dec_state[0], dec_state[1], dec_state[2]
+        B = memory.shape[0]
+        eng = self._engines.get(self.engine_dims(), memory.device)
+        tensors = self.weight_tensors() + [None, None, None, None]
+        eng.ensure_packed(tensors)
+        f = lambda t: t.to(torch.float32).contiguous().clone()
+        w, ctx = f(w_att), f(ctx_att)
+        h_att, c_att, h_dec, c_dec = f(hc_att[0]), f(hc_att[1]), f(hc_dec[0]), f(hc_dec[1])
+        xin = x.flatten(1, 2)[:, -self.dim_mel :].to(torch.float32).contiguous() if x.dim() == 3 else x.contiguous()
+        masks = None
+        if self.dropout_source == "reference_rng":
+            m = torch.empty(2, B, self.dim_pre)
+            m[0].bernoulli_(1.0 - self.pre_net.p_dropout)
+            m[1].bernoulli_(1.0 - self.pre_net.p_dropout)
+            masks = m.to(torch.uint8).to(memory.device)
+            mode = _lib.DROPOUT_MASKS
+        elif self.dropout_source == "philox":
+            mode = _lib.DROPOUT_PHILOX
+        else:
+            mode = _lib.DROPOUT_OFF
+        x_dec = eng.cell_step(
+            xin, memory.to(torch.float32).contiguous(), w, ctx, h_att, c_att, h_dec, c_dec, mode, masks,
+            self.dropout_seed, self._step_counter,
+        )
+        self._step_counter += 1
+        return x_dec, ctx, (w, ctx, ((h_att, c_att), (h_dec, c_dec)))
