@@ -1,6 +1,7 @@
 // C ABI of libttsdec.so (see include/ttsdec.h).  Host-side orchestration only:
 // argument checks, blob / workspace carving, and the per-step launch sequence.
 #include <stdio.h>
+#include <stdlib.h>
 #include <string.h>
 
 #include <new>
@@ -181,6 +182,7 @@ struct StepIo {
   const uint8_t* teacher_flags;
   float *y, *s, *w;
   bool use_ctrl;
+  int dbg;
 };
 
 constexpr int kKernelsPerStep = 7;
@@ -225,7 +227,7 @@ void launch_step(const ttsdec_handle* h, const StepBufs& sb, const StepIo& io, i
     a.a = make_seg3(sb.xpre, P, P, sb.ctx, D, D, sb.h_att[p], Ha, Ha);
     a.w = make_seg3(blob + bl.att_ih, P + D, P, blob + bl.att_ih + P, P + D, D, blob + bl.att_hh, Ha, Ha);
     a.bsum = blob + bl.att_b; a.h_prev = sb.h_att[p]; a.c = sb.c_att; a.h_out = sb.h_att[1 - p];
-    a.M = B; a.H = Ha; a.K = P + D + Ha; a.pz = d.p_zoneout; a.ctrl = ctrl; a.t = io.t;
+    a.M = B; a.H = Ha; a.K = P + D + Ha; a.pz = d.p_zoneout; a.ctrl = ctrl; a.t = io.t; a.dbg = io.dbg;
     launch_lstm(a, st);
   }
   if (which < 0 || which == 3) {
@@ -247,7 +249,7 @@ void launch_step(const ttsdec_handle* h, const StepBufs& sb, const StepIo& io, i
     a.a = make_seg3(sb.h_att[1 - p], Ha, Ha, sb.ctx, D, D, sb.h_dec[p], Hd, Hd);
     a.w = make_seg3(blob + bl.dec_ih, Ha + D, Ha, blob + bl.dec_ih + Ha, Ha + D, D, blob + bl.dec_hh, Hd, Hd);
     a.bsum = blob + bl.dec_b; a.h_prev = sb.h_dec[p]; a.c = sb.c_dec; a.h_out = sb.h_dec[1 - p];
-    a.M = B; a.H = Hd; a.K = Ha + D + Hd; a.pz = d.p_zoneout; a.ctrl = ctrl; a.t = io.t;
+    a.M = B; a.H = Hd; a.K = Ha + D + Hd; a.pz = d.p_zoneout; a.ctrl = ctrl; a.t = io.t; a.dbg = io.dbg;
     launch_lstm(a, st);
   }
   if (which < 0 || which == 6) {
@@ -415,7 +417,7 @@ int ttsdec_decode(ttsdec_handle* h, const float* memory, int B, int L, int t_beg
   io.stop_thr = stop_threshold; io.check_stop = check_stop;
   io.dropout_mode = dropout_mode; io.masks = masks; io.seed = seed;
   io.teacher = teacher; io.teacher_T = teacher_T; io.teacher_flags = teacher_flags;
-  io.y = y; io.s = s; io.w = w; io.use_ctrl = true;
+  io.y = y; io.s = s; io.w = w; io.use_ctrl = true; io.dbg = 0;
   for (int i = 0; i < n_steps; ++i) {
     io.t = t_begin + i;
     io.t_rel = i;
@@ -534,6 +536,7 @@ int ttsdec_profile_step(ttsdec_handle* h, const float* memory, int B, int L, int
   io.memory = memory; io.B = B; io.L = L; io.t = 0; io.t_rel = 0; io.t_stride = 1;
   io.dropout_mode = dropout_mode; io.masks = masks; io.seed = seed;
   io.y = y; io.s = s; io.w = w; io.use_ctrl = false;
+  if (const char* e = getenv("TTSDEC_PROFILE_ABLATION")) io.dbg = atoi(e);  // measurement only
   hipEvent_t e0, e1;
   HIP_TRY(h, hipEventCreate(&e0));
   HIP_TRY(h, hipEventCreate(&e1));

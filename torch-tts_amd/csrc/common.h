@@ -3,6 +3,8 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <type_traits>
+
 #include "../../include/ttsdec.h"
 
 namespace ttsdec {
@@ -10,7 +12,7 @@ namespace ttsdec {
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
-constexpr int kGemmThreads = 256;
+constexpr int kGemmThreads = 512;  // 4 MFMA waves + 4 loader waves
 constexpr int kAttnThreads = 512;
 constexpr int kStopNever = 0x7fffffff;
 
@@ -89,16 +91,37 @@ __host__ __device__ inline Seg3 make_seg1(const float* p0, int ld0, int k0) {
   return make_seg3(p0, ld0, k0, p0, ld0, 0, p0, ld0, 0);
 }
 
-// 4 consecutive k of row `row`; k is a multiple of 4 and segments are multiples of 4
-// long, so a float4 never straddles segments.  Out-of-range -> zeros.
-__device__ __forceinline__ float4 seg_load4(const Seg3& s, int row, int k) {
-  if (k >= s.e2) return make_float4(0.f, 0.f, 0.f, 0.f);
-  const float* p;
-  int ld, kb;
-  if (k < s.e0) { p = s.p0; ld = s.ld0; kb = 0; }
-  else if (k < s.e1) { p = s.p1; ld = s.ld1; kb = s.e0; }
-  else { p = s.p2; ld = s.ld2; kb = s.e1; }
-  return *reinterpret_cast<const float4*>(p + (size_t)row * ld + (k - kb));
+// Global-address-space pointer types.  Pointers that reach a kernel inside a by-value
+// struct are generic to the compiler, which then emits flat_load (uncountable in vmcnt,
+// so every wait becomes vmcnt(0)); casting to address_space(1) gives global_load.
+typedef __attribute__((address_space(1))) const float gfloat;
+typedef __attribute__((address_space(1))) const f32x4 gf32x4;
+__device__ __forceinline__ gfloat* as_global(const float* p) { return (gfloat*)p; }
+__device__ __forceinline__ f32x4 gload4(gfloat* p) { return *(gf32x4*)p; }
+
+// 16 zero bytes in device memory: out-of-range tile elements are loaded from here, so
+// a loader only ever selects an ADDRESS and the loaded value is first touched when it
+// is written to LDS (keeps several tiles of loads in flight; no select behind a load).
+__device__ __attribute__((aligned(16))) float g_zero4[4] = {0.f, 0.f, 0.f, 0.f};
+__device__ __forceinline__ gfloat* zero_addr() { return (gfloat*)g_zero4; }
+
+// segment s of a Seg3: pointer to (row, k = 0) and length
+__device__ __forceinline__ gfloat* seg_row_ptr(const Seg3& s, int row, int seg) {
+  const float* p = seg == 0 ? s.p0 : (seg == 1 ? s.p1 : s.p2);
+  const int ld = seg == 0 ? s.ld0 : (seg == 1 ? s.ld1 : s.ld2);
+  return as_global(p) + (long)row * ld;
+}
+__device__ __forceinline__ int seg_len(const Seg3& s, int seg) {
+  return seg == 0 ? s.e0 : (seg == 1 ? s.e1 - s.e0 : s.e2 - s.e1);
+}
+__device__ __forceinline__ int seg_count(const Seg3& s) { return s.e2 > s.e1 ? 3 : (s.e1 > s.e0 ? 2 : 1); }
+
+template <int N, class F>
+__device__ __forceinline__ void static_for(F&& f) {
+  if constexpr (N > 0) {
+    static_for<N - 1>(f);
+    f(std::integral_constant<int, N - 1>{});
+  }
 }
 
 }  // namespace ttsdec

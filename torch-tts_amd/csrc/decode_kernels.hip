@@ -11,40 +11,52 @@ namespace ttsdec {
 // ===========================================================================
 // generic row GEMM:  out[m, n] = epi( sum_k A[m, k] * W[n, k] )
 // ===========================================================================
+// rows m0.. of an [M, K] activation made of up to three K segments
 struct LoaderPlain {
   Seg3 s;
   int m0, M;
-  __device__ __forceinline__ float4 load(int r, int k) const {
-    const int m = m0 + r;
-    if (m >= M) return make_float4(0.f, 0.f, 0.f, 0.f);
-    return seg_load4(s, m, k);
-  }
+  static constexpr bool kRange = false;
+  __device__ __forceinline__ int nseg() const { return seg_count(s); }
+  __device__ __forceinline__ int seglen(int i) const { return seg_len(s, i); }
+  __device__ __forceinline__ bool row_ok(int r) const { return m0 + r < M; }
+  __device__ __forceinline__ gfloat* row_ptr(int r, int i) const { return seg_row_ptr(s, m0 + r, i); }
+  __device__ __forceinline__ int k_lo(int) const { return 0; }
+  __device__ __forceinline__ int k_hi(int) const { return 0; }
 };
 
-// implicit im2col for Conv1d(k, padding=(k-1)/2) on channel-last activations
+// implicit im2col for Conv1d(k, padding=(k-1)/2) on channel-last activations x [B*T, Cin]:
+// with k = tap*Cin + c the im2col row of frame m is the contiguous window
+// x[(m - taps/2)*Cin + k], valid while the tapped frame stays inside the utterance.
 struct LoaderConv {
   const float* x;
   int m0, M, T, Cin, taps, K;
-  __device__ __forceinline__ float4 load(int r, int k) const {
-    const int m = m0 + r;
-    if (m >= M || k >= K) return make_float4(0.f, 0.f, 0.f, 0.f);
-    const int tap = k / Cin;
-    const int c = k - tap * Cin;
-    const int t = m % T;
-    const int tt = t + tap - (taps >> 1);
-    if (tt < 0 || tt >= T) return make_float4(0.f, 0.f, 0.f, 0.f);
-    return *reinterpret_cast<const float4*>(x + (size_t)(m - t + tt) * Cin + c);
+  static constexpr bool kRange = true;
+  __device__ __forceinline__ int nseg() const { return 1; }
+  __device__ __forceinline__ int seglen(int i) const { return i == 0 ? K : 0; }
+  __device__ __forceinline__ bool row_ok(int r) const { return m0 + r < M; }
+  __device__ __forceinline__ gfloat* row_ptr(int r, int) const {
+    return as_global(x) + ((long)(m0 + r) - (taps >> 1)) * Cin;
+  }
+  __device__ __forceinline__ int k_lo(int r) const {
+    const int t = (m0 + r) % T, half = taps >> 1;
+    return (half - t > 0 ? half - t : 0) * Cin;
+  }
+  __device__ __forceinline__ int k_hi(int r) const {
+    const int t = (m0 + r) % T, half = taps >> 1;
+    const int hi = (T - t + half) * Cin;
+    return hi < K ? hi : K;
   }
 };
 
+// rows n0.. of a PyTorch-layout weight [N, K] cut into the same K segments as A
 struct LoaderW {
-  const float* W;
-  int ldw, n0, N, K;
-  __device__ __forceinline__ float4 load(int r, int k) const {
-    const int n = n0 + r;
-    if (n >= N || k >= K) return make_float4(0.f, 0.f, 0.f, 0.f);
-    return *reinterpret_cast<const float4*>(W + (size_t)n * ldw + k);
-  }
+  Seg3 w;
+  int n0, N;
+  static constexpr bool kRange = false;
+  __device__ __forceinline__ int nseg() const { return seg_count(w); }
+  __device__ __forceinline__ int seglen(int i) const { return seg_len(w, i); }
+  __device__ __forceinline__ bool row_ok(int r) const { return n0 + r < N; }
+  __device__ __forceinline__ gfloat* row_ptr(int r, int i) const { return seg_row_ptr(w, n0 + r, i); }
 };
 
 template <class Cfg, int AK, int EK>
@@ -54,18 +66,21 @@ __global__ __launch_bounds__(kGemmThreads) void gemm_rows_kernel(GemmArgs g) {
   constexpr int BM = Cfg::BM, BN = Cfg::BN, LDO = Cfg::LDO;
   const int m0 = blockIdx.y * BM;
   const int n0 = blockIdx.x * BN;
-  const LoaderW lb{g.W, g.ldw, n0, g.N, g.K};
   if (AK == A_CONV) {
     const LoaderConv la{g.a.p0, m0, g.M, g.T, g.Cin, g.taps, g.K};
-    gemm_tile_f32<Cfg>(la, lb, g.K, smem);
+    const LoaderW lb{make_seg1(g.W, g.ldw, g.K), n0, g.N};
+    gemm_tile_f32<Cfg>(la, lb, smem);
   } else {
     Seg3 s = g.a;
     if (g.teacher != nullptr && g.t > 0 && g.teacher_flags[g.t - 1] != 0) {
       // decoder.py:65-66: next input = last frame of teacher group t-1 = teacher frame t*r - 1
       s = make_seg1(g.teacher + (size_t)(g.t * g.r - 1) * g.d_mel, g.teacher_T * g.d_mel, g.d_mel);
     }
+    // W is one [N, K] matrix: cut it at A's segment boundaries
+    const int k0 = s.e0, k1 = s.e1 - s.e0, k2 = s.e2 - s.e1;
+    const LoaderW lb{make_seg3(g.W, g.ldw, k0, g.W + k0, g.ldw, k1, g.W + k0 + k1, g.ldw, k2), n0, g.N};
     const LoaderPlain la{s, m0, g.M};
-    gemm_tile_f32<Cfg>(la, lb, g.K, smem);
+    gemm_tile_f32<Cfg>(la, lb, smem);
   }
 
   for (int e = threadIdx.x; e < BM * BN; e += kGemmThreads) {
@@ -116,11 +131,11 @@ static void launch_gemm_cfg(const GemmArgs& a, hipStream_t st) {
   // with the four waves splitting K.
   const long tiles_big = (long)((a.M + 63) / 64) * ((a.N + 63) / 64);
   if (a.M >= 64 && tiles_big >= 512) {
-    using Cfg = TileCfg<2, 2, 1>;
+    using Cfg = TileCfg<2, 2, 1, 4>;  // 64 KiB ring: two workgroups per CU on the big (postnet) grids
     dim3 grid((a.N + Cfg::BN - 1) / Cfg::BN, (a.M + Cfg::BM - 1) / Cfg::BM);
     hipLaunchKernelGGL((gemm_rows_kernel<Cfg, AK, EK>), grid, dim3(kGemmThreads), 0, st, a);
   } else {
-    using Cfg = TileCfg<1, 1, 4>;
+    using Cfg = TileCfg<1, 1, 4, 4>;
     dim3 grid((a.N + Cfg::BN - 1) / Cfg::BN, (a.M + Cfg::BM - 1) / Cfg::BM);
     hipLaunchKernelGGL((gemm_rows_kernel<Cfg, AK, EK>), grid, dim3(kGemmThreads), 0, st, a);
   }
@@ -148,11 +163,12 @@ template <int BU>
 struct LoaderWLstm {
   Seg3 w;
   int u0, H;
-  __device__ __forceinline__ float4 load(int r, int k) const {
-    const int gate = r / BU;
-    const int unit = u0 + (r - gate * BU);
-    if (unit >= H) return make_float4(0.f, 0.f, 0.f, 0.f);
-    return seg_load4(w, gate * H + unit, k);
+  static constexpr bool kRange = false;
+  __device__ __forceinline__ int nseg() const { return seg_count(w); }
+  __device__ __forceinline__ int seglen(int i) const { return seg_len(w, i); }
+  __device__ __forceinline__ bool row_ok(int r) const { return u0 + (r % BU) < H; }
+  __device__ __forceinline__ gfloat* row_ptr(int r, int i) const {
+    return seg_row_ptr(w, (r / BU) * H + u0 + (r % BU), i);  // PyTorch gate blocks i,f,g,o
   }
 };
 
@@ -165,7 +181,7 @@ __global__ __launch_bounds__(kGemmThreads) void lstm_kernel(LstmArgs g) {
   const int u0 = blockIdx.x * BU;
   const LoaderPlain la{g.a, m0, g.M};
   const LoaderWLstm<BU> lb{g.w, u0, g.H};
-  gemm_tile_f32<Cfg>(la, lb, g.K, smem);
+  gemm_tile_f32<Cfg>(la, lb, smem, g.dbg);
 
   const int H = g.H;
   for (int e = threadIdx.x; e < BM * BU; e += kGemmThreads) {
@@ -193,15 +209,15 @@ __global__ __launch_bounds__(kGemmThreads) void lstm_kernel(LstmArgs g) {
 void launch_lstm(const LstmArgs& a, hipStream_t st) {
   if (a.M <= 0) return;
   if (a.M >= 192) {
-    using Cfg = TileCfg<2, 2, 1>;  // 64 rows x 16 units
+    using Cfg = TileCfg<2, 2, 1, 6>;  // 64 rows x 16 units, 5 x 16 KiB tiles in flight
     dim3 grid((a.H + 15) / 16, (a.M + 63) / 64);
     hipLaunchKernelGGL((lstm_kernel<Cfg>), grid, dim3(kGemmThreads), 0, st, a);
   } else if (a.M >= 96) {
-    using Cfg = TileCfg<2, 1, 2>;  // 64 rows x 8 units
+    using Cfg = TileCfg<2, 1, 2, 4>;  // 64 rows x 8 units, 3 x 24 KiB in flight
     dim3 grid((a.H + 7) / 8, (a.M + 63) / 64);
     hipLaunchKernelGGL((lstm_kernel<Cfg>), grid, dim3(kGemmThreads), 0, st, a);
   } else {
-    using Cfg = TileCfg<1, 1, 4>;  // 32 rows x 8 units
+    using Cfg = TileCfg<1, 1, 4, 4>;  // 32 rows x 8 units, 3 x 32 KiB in flight
     dim3 grid((a.H + 7) / 8, (a.M + 31) / 32);
     hipLaunchKernelGGL((lstm_kernel<Cfg>), grid, dim3(kGemmThreads), 0, st, a);
   }

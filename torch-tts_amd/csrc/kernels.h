@@ -61,6 +61,7 @@ struct LstmArgs {
   float pz;  // zoneout probability (eval-mode blend)
   Ctrl* ctrl;
   int t;
+  int dbg;  // measurement ablations (ttsdec_profile_step only): 1 = every load reads the zero block
 };
 void launch_lstm(const LstmArgs& a, hipStream_t st);
 
