@@ -68,6 +68,8 @@ def main():
     ap.add_argument("--mem-len", type=int, default=120)
     ap.add_argument("--frames", type=int, default=600)
     ap.add_argument("--postnet", choices=["f32", "bf16"], default="f32")
+    ap.add_argument("--precision", choices=["f32", "split_f16"], default="split_f16",
+                    help="arithmetic of the LSTM gate GEMMs (include/ttsdec.h TTSDEC_PREC_*)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-frames", type=int, default=0, help="decode frames for the CPU baseline sample (0 = auto)")
     args = ap.parse_args()
@@ -98,6 +100,7 @@ def main():
     model.to(dev)
     dec, post = model.decoder, model.postnet
     dec.dropout_source, dec.dropout_seed = "philox", 123
+    dec.precision = args.precision
     post.precision = args.postnet
 
     # ---- weights: rank 0 packs, one RCCL broadcast of the blob, other ranks bind ----
@@ -110,6 +113,7 @@ def main():
     else:
         eng.ensure_packed(dec.weight_tensors())
         peng.ensure_packed(post.weight_tensors())
+    eng.set_precision(args.precision)
 
     # ---- synthetic input: ids -> stock encoder -> memory, this rank's shard of the global batch ----
     g = torch.Generator().manual_seed(1234)
@@ -209,12 +213,13 @@ def main():
         "higher_is_better": True,
         "scaling": "weak",
         "vs_baseline": None,
-        "dtype": "f32",
+        "dtype": "f32" if args.precision == "f32" else "f32 via split-fp16 (hi+lo fp16 planes, 3 f16 MFMA products, fp32 accumulate) for the LSTM GEMMs; f32 elsewhere",
         "data": "synthetic",
         "config": {
             "workload": f"LJSpeech dims, batch={B}/GPU (global {Bg}), L={L}, {NF} decode frames + Postnet({args.postnet}); "
                         "BASELINE.json configs[2] per GPU, configs[3] at 8 GPUs",
             "global_batch": Bg, "mem_len": L, "frames": NF, "dropout": "philox", "parallelism": f"utterance-shard x{world}",
+            "lstm_precision": eng.precision(),
         },
         "rtf": round((elapsed / args.steps) / (NF * FRAME_SEC), 6),
         "audio_seconds_per_s": round(value * FRAME_SEC, 1),
@@ -230,7 +235,9 @@ def main():
         sd = {k: v.detach().cpu() for k, v in dec.state_dict().items()}
         pw = {k: v.detach().cpu() for k, v in post.state_dict().items()}
         memc = mem.cpu()
-        cores = torch.get_num_threads()
+        # the GPU box gives one GPU a 16-CPU share: do not oversubscribe it
+        cores = max(1, min(16, os.cpu_count() or 1, torch.get_num_threads()))
+        torch.set_num_threads(cores)
         tc = args.cpu_frames
         if tc <= 0:
             t1 = time.perf_counter()

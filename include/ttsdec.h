@@ -101,6 +101,15 @@ enum {
   TTSDEC_DROPOUT_PHILOX = 2 /* on-device Philox4x32-10 keyed by (seed; step, layer, b, unit)   */
 };
 
+/* Arithmetic of the two LSTM gate GEMMs (95 % of the step's FLOPs). */
+enum {
+  TTSDEC_PREC_F32 = 0,       /* exact fp32 on the fp32-input matrix instruction (default)             */
+  TTSDEC_PREC_SPLIT_F16 = 1  /* split-fp16: x = hi + lo*2^-11 (two fp16 planes, 22 significand bits),
+                              * a*b = ah*bh + (ah*bl + al*bh)*2^-11 on the f16 matrix instruction with
+                              * fp32 accumulation; ~2^-22 relative per product.  Needs d_pre, d_ctx,
+                              * h_att, h_dec to be multiples of 8, else the handle stays on F32.      */
+};
+
 /* Postnet arithmetic. */
 enum {
   TTSDEC_POSTNET_F32 = 0,   /* exact fp32 (fp32-input MFMA)                                   */
@@ -115,6 +124,12 @@ const char* ttsdec_last_hip_error(const ttsdec_handle* h);
 /* Replaces: module construction in build_tacotron (tacotron/tacotron.py:178-206). */
 int ttsdec_create(const ttsdec_dims* dims, ttsdec_handle** out);
 int ttsdec_destroy(ttsdec_handle* h);
+
+/* Selects TTSDEC_PREC_* for later decode / cell_step calls (weights of both forms live in
+ * the packed blob, so this can be switched at any time).  ttsdec_get_precision returns the
+ * mode actually in effect for the handle's dims. */
+int ttsdec_set_precision(ttsdec_handle* h, int precision);
+int ttsdec_get_precision(const ttsdec_handle* h);
 
 /* Number of source tensors ttsdec_pack_weights expects for these dims. */
 int ttsdec_num_weight_tensors(const ttsdec_handle* h);

@@ -192,6 +192,49 @@ def test_ljspeech_dims_vs_oracle(H, B, L, T, lengths):
     assert torch.equal(w.argmax(-1), ow.argmax(-1)), "attention argmax must be bit-exact"
 
 
+@pytest.mark.parametrize("B,L,T", [(256, 120, 40), (64, 120, 60), (128, 57, 20), (3, 9, 12)])
+def test_split_f16_precision_mode_vs_oracle(H, B, L, T):
+    """TTSDEC_PREC_SPLIT_F16 (hi/lo fp16 planes, 3 products on the f16 MFMA, fp32 accumulate)
+    must meet the same bar as the exact path: 1e-4 relative on mel / stop / weights, argmax exact."""
+    dims = O.DecoderDims()
+    wts = O.random_decoder_weights(dims, seed=42, nonzero_init_state=True)
+    mem = O.synthetic_memory(B, L, dims.d_ctx, seed=1234)
+    masks = O.synthetic_masks(T, B, dims.d_pre, seed=123)
+    oy, os_, ow = O.decode(wts, dims, mem, max_steps=T - 1, masks=masks)
+    dec = H.make_decoder(dims, wts)
+    dec.precision = "split_f16"
+    y, s, w, fired = H.run_decoder_with_masks(dec, mem, masks, max_steps=T - 1)
+    assert dec.engine(torch.device("cuda:0")).precision() == "split_f16"
+    assert not fired and y.shape == oy.shape
+    H.assert_close(y, oy, RTOL, ATOL, "y")
+    H.assert_close(s, os_, RTOL, ATOL, "s")
+    H.assert_close(w, ow, RTOL, ATOL, "w")
+    assert torch.equal(w.argmax(-1), ow.argmax(-1)), "attention argmax must be bit-exact"
+    # report how close the two arithmetic modes are to each other and to the oracle
+    dec.precision = "f32"
+    y32, _, _, _ = H.run_decoder_with_masks(dec, mem, masks, max_steps=T - 1)
+    print(f"B={B} T={T}: max|y_split - oracle| = {float((y - oy).abs().max()):.3e}, "
+          f"max|y_f32 - oracle| = {float((y32 - oy).abs().max()):.3e}, max|y| = {float(oy.abs().max()):.3f}")
+
+
+def test_split_f16_handles_tiny_and_large_values(H):
+    """Operand magnitudes across the fp16 range edges: subnormal-range activations (hi plane
+    forced to zero) and weights scaled up/down."""
+    dims = O.DecoderDims(d_mel=16, d_pre=32, d_ctx=64, h_att=64, h_dec=96)
+    wts = O.random_decoder_weights(dims, seed=3)
+    wts["decoder_cell.attention_rnn.weight_hh"] = wts["decoder_cell.attention_rnn.weight_hh"] * 1e-4
+    wts["decoder_cell.decoder_rnn.weight_ih"][:, :7] *= 30.0
+    B, L, T = 5, 13, 10
+    mem = O.synthetic_memory(B, L, dims.d_ctx, lengths=[13, 2, 13, 7, 1]) * 1e-3
+    masks = O.synthetic_masks(T, B, dims.d_pre)
+    oy, os_, ow = O.decode(wts, dims, mem, max_steps=T - 1, masks=masks)
+    dec = H.make_decoder(dims, wts)
+    dec.precision = "split_f16"
+    y, s, w, _ = H.run_decoder_with_masks(dec, mem, masks, max_steps=T - 1)
+    H.assert_close(y, oy, RTOL, ATOL, "y")
+    H.assert_close(w, ow, RTOL, ATOL, "w")
+
+
 def test_postnet_ljspeech_dims_vs_oracle(H):
     pw = O.random_postnet_weights(80, 512, 3, seed=9)
     g = torch.Generator().manual_seed(2)

@@ -34,12 +34,21 @@ def test_host_only_queries_and_layout_sizes():
     # 18 577 489 decoder params + 4 initial-state vectors + postnet, padded per tensor to 256 B
     n_dec = 86528 + 7348224 + 524288 + 10493952 + 124497
     assert n_dec == 18577489
-    assert e.packed_bytes() >= 4 * n_dec and e.packed_bytes() % 256 == 0
-    assert e.packed_bytes() < 4 * (n_dec + 2870272) * 1.01 + 64 * 256
+    # + the split-fp16 planes (hi, lo) of the four LSTM weight matrices: another 4 bytes per LSTM weight
+    n_lstm_w = 4096 * (768 + 1024) + 4096 * (1536 + 1024)
+    assert e.packed_bytes() >= 4 * (n_dec + n_lstm_w) and e.packed_bytes() % 256 == 0
+    assert e.packed_bytes() < 4 * (n_dec + n_lstm_w + 2870272) * 1.01 + 64 * 256
     w1, w2 = e.workspace_bytes(64, 120), e.workspace_bytes(256, 120)
     assert 0 < w1 < w2 and w2 % 256 == 0
     assert e.postnet_workspace_bytes(256, 600) == 2 * 256 * 600 * 512 * 4
     assert T.Engine(T.EngineDims(), None).num_weight_tensors() == 21
+    # precision switch: split-fp16 needs 8-aligned feature dims, otherwise the handle stays on fp32
+    assert e.precision() == "f32"
+    e.set_precision("split_f16")
+    assert e.precision() == "split_f16"
+    e2 = T.Engine(T.EngineDims(d_pre=36, d_ctx=40, h_att=72, h_dec=88), None)
+    e2.set_precision("split_f16")
+    assert e2.precision() == "f32"
     e.close()
 
 

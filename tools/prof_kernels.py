@@ -18,6 +18,7 @@ ap = argparse.ArgumentParser()
 ap.add_argument("--batch", type=int, default=256)
 ap.add_argument("--mem-len", type=int, default=120)
 ap.add_argument("--iters", type=int, default=20)
+ap.add_argument("--precision", default="f32", choices=["f32", "split_f16"])
 args = ap.parse_args()
 dev = torch.device("cuda:0")
 torch.manual_seed(42)
@@ -27,6 +28,7 @@ for m in dec.modules():
     if isinstance(m, torch.nn.Linear):
         torch.nn.init.xavier_normal_(m.weight, gain=1.5)
 dec = dec.to(dev).eval()
+dec.precision = args.precision
 eng = dec.engine(dev)
 mem = torch.tanh(torch.randn(args.batch, args.mem_len, 512, device=dev) * 0.5)
 ms = eng.profile_step(mem, iters=args.iters, dropout_mode=_lib.DROPOUT_PHILOX, masks=None, seed=1)

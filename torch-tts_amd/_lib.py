@@ -14,6 +14,7 @@ OK = 0
 ERR_INVALID_ARG, ERR_DIMS, ERR_HIP, ERR_NOT_BOUND, ERR_WORKSPACE, ERR_DEVICE = -1, -2, -3, -4, -5, -6
 DROPOUT_OFF, DROPOUT_MASKS, DROPOUT_PHILOX = 0, 1, 2
 POSTNET_F32, POSTNET_BF16 = 0, 1
+PREC_F32, PREC_SPLIT_F16 = 0, 1
 W_DECODER_COUNT = 21
 W_POSTNET_PER_LAYER = 5
 
@@ -24,6 +25,8 @@ SYMBOLS = (
     "ttsdec_last_hip_error",
     "ttsdec_create",
     "ttsdec_destroy",
+    "ttsdec_set_precision",
+    "ttsdec_get_precision",
     "ttsdec_num_weight_tensors",
     "ttsdec_packed_bytes",
     "ttsdec_pack_weights",
@@ -100,6 +103,10 @@ def load() -> C.CDLL:
         lib.ttsdec_create.argtypes = [C.POINTER(Dims), C.POINTER(vp)]
         lib.ttsdec_destroy.restype = i32
         lib.ttsdec_destroy.argtypes = [vp]
+        lib.ttsdec_set_precision.restype = i32
+        lib.ttsdec_set_precision.argtypes = [vp, i32]
+        lib.ttsdec_get_precision.restype = i32
+        lib.ttsdec_get_precision.argtypes = [vp]
         lib.ttsdec_num_weight_tensors.restype = i32
         lib.ttsdec_num_weight_tensors.argtypes = [vp]
         lib.ttsdec_packed_bytes.restype = sz

@@ -21,6 +21,7 @@ inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 struct BlobLayout {  // offsets in floats
   size_t pre0_w, pre0_b, pre1_w, pre1_b, wq;
   size_t att_ih, att_hh, att_b, dec_ih, dec_hh, dec_b;
+  size_t att_ih_h, att_ih_l, att_hh_h, att_hh_l, dec_ih_h, dec_ih_l, dec_hh_h, dec_hh_l;  // split-fp16 planes
   size_t h0a, c0a, h0d, c0d;
   size_t proj_w, proj_b;
   size_t conv_w[kMaxPostnetLayers], conv_alpha[kMaxPostnetLayers], conv_beta[kMaxPostnetLayers];
@@ -30,6 +31,7 @@ struct BlobLayout {  // offsets in floats
 
 struct WsLayout {  // offsets in bytes
   size_t ctrl, xpre0, xpre, ctx, h_att[2], c_att, h_dec[2], c_dec, q, ynext, w[2];
+  size_t xpre_h, xpre_l, ctx_h, ctx_l, h_att_h[2], h_att_l[2], h_dec_h[2], h_dec_l[2];  // split-fp16 planes
   size_t total;
 };
 
@@ -37,6 +39,7 @@ struct WsLayout {  // offsets in bytes
 
 struct ttsdec_handle {
   ttsdec_dims d;
+  int precision;  // TTSDEC_PREC_*
   int device;  // -1: no HIP device was available at create (host-only queries still work)
   BlobLayout bl;
   const float* blob;
@@ -66,6 +69,11 @@ BlobLayout make_blob_layout(const ttsdec_dims& d) {
   L.dec_ih = take(4 * Hd * (Ha + D));
   L.dec_hh = take(4 * Hd * Hd);
   L.dec_b = take(4 * Hd);
+  // fp16 planes occupy half a float per element
+  L.att_ih_h = take(2 * Ha * (P + D)); L.att_ih_l = take(2 * Ha * (P + D));
+  L.att_hh_h = take(2 * Ha * Ha);      L.att_hh_l = take(2 * Ha * Ha);
+  L.dec_ih_h = take(2 * Hd * (Ha + D)); L.dec_ih_l = take(2 * Hd * (Ha + D));
+  L.dec_hh_h = take(2 * Hd * Hd);      L.dec_hh_l = take(2 * Hd * Hd);
   L.h0a = take(Ha);
   L.c0a = take(Ha);
   L.h0d = take(Hd);
@@ -108,6 +116,13 @@ WsLayout make_ws_layout(const ttsdec_dims& d, int B, int Lm) {
   W.ynext = take(b * d.d_mel);
   W.w[0] = take(b * Lm);
   W.w[1] = take(b * Lm);
+  auto takeh = [&](size_t nhalfs) { return take((nhalfs + 1) / 2); };
+  W.xpre_h = takeh(b * d.d_pre); W.xpre_l = takeh(b * d.d_pre);
+  W.ctx_h = takeh(b * d.d_ctx); W.ctx_l = takeh(b * d.d_ctx);
+  for (int i = 0; i < 2; ++i) {
+    W.h_att_h[i] = takeh(b * d.h_att); W.h_att_l[i] = takeh(b * d.h_att);
+    W.h_dec_h[i] = takeh(b * d.h_dec); W.h_dec_l[i] = takeh(b * d.h_dec);
+  }
   W.total = off;
   return W;
 }
@@ -154,6 +169,7 @@ int check_launch(ttsdec_handle* h, const char* where) {
 struct StepBufs {
   Ctrl* ctrl;
   float *xpre0, *xpre, *ctx, *h_att[2], *c_att, *h_dec[2], *c_dec, *q, *ynext, *w[2];
+  f16 *xpre_h, *xpre_l, *ctx_h, *ctx_l, *h_att_h[2], *h_att_l[2], *h_dec_h[2], *h_dec_l[2];
 };
 
 StepBufs carve(const WsLayout& W, void* ws) {
@@ -165,6 +181,12 @@ StepBufs carve(const WsLayout& W, void* ws) {
   s.h_att[0] = f(W.h_att[0]); s.h_att[1] = f(W.h_att[1]); s.c_att = f(W.c_att);
   s.h_dec[0] = f(W.h_dec[0]); s.h_dec[1] = f(W.h_dec[1]); s.c_dec = f(W.c_dec);
   s.q = f(W.q); s.ynext = f(W.ynext); s.w[0] = f(W.w[0]); s.w[1] = f(W.w[1]);
+  auto hf = [&](size_t off) { return reinterpret_cast<f16*>(p + off); };
+  s.xpre_h = hf(W.xpre_h); s.xpre_l = hf(W.xpre_l); s.ctx_h = hf(W.ctx_h); s.ctx_l = hf(W.ctx_l);
+  for (int i = 0; i < 2; ++i) {
+    s.h_att_h[i] = hf(W.h_att_h[i]); s.h_att_l[i] = hf(W.h_att_l[i]);
+    s.h_dec_h[i] = hf(W.h_dec_h[i]); s.h_dec_l[i] = hf(W.h_dec_l[i]);
+  }
   return s;
 }
 
@@ -185,6 +207,10 @@ struct StepIo {
   int dbg;
 };
 
+// split-fp16 needs every K segment to be whole 16-byte columns of fp16 (multiples of 8)
+bool split_ok(const ttsdec_dims& d) { return !((d.d_pre | d.d_ctx | d.h_att | d.h_dec) & 7); }
+int lstm_prec(const ttsdec_handle* h) { return (h->precision == TTSDEC_PREC_SPLIT_F16 && split_ok(h->d)) ? 1 : 0; }
+
 constexpr int kKernelsPerStep = 7;
 const char* const kKernelNames[kKernelsPerStep] = {"prenet0", "prenet1", "lstm_att", "query", "attention", "lstm_dec", "proj"};
 
@@ -197,6 +223,10 @@ void launch_step(const ttsdec_handle* h, const StepBufs& sb, const StepIo& io, i
   Ctrl* ctrl = io.use_ctrl ? sb.ctrl : nullptr;
   const int B = io.B, P = d.d_pre, D = d.d_ctx, Ha = d.h_att, Hd = d.h_dec;
   const float keep_scale = 1.0f / (1.0f - d.p_dropout);
+  const int prec = lstm_prec(h);
+  const f16* bh = reinterpret_cast<const f16*>(blob);  // fp16 planes live at float offsets of the same blob
+  auto plane = [&](size_t float_off) { return reinterpret_cast<const f16*>(blob + float_off); };
+  (void)bh;
 
   if (which < 0 || which == 0 || which == 1) {
     for (int layer = 0; layer < 2; ++layer) {
@@ -212,6 +242,7 @@ void launch_step(const ttsdec_handle* h, const StepBufs& sb, const StepIo& io, i
         g.a = make_seg1(sb.xpre0, P, P);
         g.W = blob + bl.pre1_w; g.ldw = P; g.K = P; g.bias = blob + bl.pre1_b;
         g.out = sb.xpre;
+        if (prec) { g.out_h = sb.xpre_h; g.out_l = sb.xpre_l; }
       }
       g.M = B; g.N = P; g.ldo = P;
       g.dropout_mode = io.dropout_mode;
@@ -224,8 +255,19 @@ void launch_step(const ttsdec_handle* h, const StepBufs& sb, const StepIo& io, i
   }
   if (which < 0 || which == 2) {
     LstmArgs a;
-    a.a = make_seg3(sb.xpre, P, P, sb.ctx, D, D, sb.h_att[p], Ha, Ha);
-    a.w = make_seg3(blob + bl.att_ih, P + D, P, blob + bl.att_ih + P, P + D, D, blob + bl.att_hh, Ha, Ha);
+    memset(&a, 0, sizeof(a));
+    a.prec = prec;
+    if (prec) {
+      a.a = make_seg3(sb.xpre_h, P, P, sb.ctx_h, D, D, sb.h_att_h[p], Ha, Ha);
+      a.a_lo = make_seg3(sb.xpre_l, P, P, sb.ctx_l, D, D, sb.h_att_l[p], Ha, Ha);
+      a.w = make_seg3(plane(bl.att_ih_h), P + D, P, plane(bl.att_ih_h) + P, P + D, D, plane(bl.att_hh_h), Ha, Ha);
+      a.w_lo = make_seg3(plane(bl.att_ih_l), P + D, P, plane(bl.att_ih_l) + P, P + D, D, plane(bl.att_hh_l), Ha, Ha);
+      a.h_out_h = sb.h_att_h[1 - p]; a.h_out_l = sb.h_att_l[1 - p];
+    } else {
+      a.a = make_seg3(sb.xpre, P, P, sb.ctx, D, D, sb.h_att[p], Ha, Ha);
+      a.w = make_seg3(blob + bl.att_ih, P + D, P, blob + bl.att_ih + P, P + D, D, blob + bl.att_hh, Ha, Ha);
+      a.a_lo = a.a; a.w_lo = a.w;
+    }
     a.bsum = blob + bl.att_b; a.h_prev = sb.h_att[p]; a.c = sb.c_att; a.h_out = sb.h_att[1 - p];
     a.M = B; a.H = Ha; a.K = P + D + Ha; a.pz = d.p_zoneout; a.ctrl = ctrl; a.t = io.t; a.dbg = io.dbg;
     launch_lstm(a, st);
@@ -240,14 +282,27 @@ void launch_step(const ttsdec_handle* h, const StepBufs& sb, const StepIo& io, i
   }
   if (which < 0 || which == 4) {
     AttnArgs a;
+    memset(&a, 0, sizeof(a));
+    if (prec) { a.ctx_h = sb.ctx_h; a.ctx_l = sb.ctx_l; }
     a.memory = io.memory; a.q = sb.q; a.w_prev = sb.w[p]; a.w_new = sb.w[1 - p]; a.w_out = io.w; a.ctx = sb.ctx;
     a.B = B; a.L = io.L; a.D = D; a.t_rel = io.t_rel; a.t_stride = io.t_stride; a.ctrl = ctrl; a.t = io.t;
     launch_attn(a, st);
   }
   if (which < 0 || which == 5) {
     LstmArgs a;
-    a.a = make_seg3(sb.h_att[1 - p], Ha, Ha, sb.ctx, D, D, sb.h_dec[p], Hd, Hd);
-    a.w = make_seg3(blob + bl.dec_ih, Ha + D, Ha, blob + bl.dec_ih + Ha, Ha + D, D, blob + bl.dec_hh, Hd, Hd);
+    memset(&a, 0, sizeof(a));
+    a.prec = prec;
+    if (prec) {
+      a.a = make_seg3(sb.h_att_h[1 - p], Ha, Ha, sb.ctx_h, D, D, sb.h_dec_h[p], Hd, Hd);
+      a.a_lo = make_seg3(sb.h_att_l[1 - p], Ha, Ha, sb.ctx_l, D, D, sb.h_dec_l[p], Hd, Hd);
+      a.w = make_seg3(plane(bl.dec_ih_h), Ha + D, Ha, plane(bl.dec_ih_h) + Ha, Ha + D, D, plane(bl.dec_hh_h), Hd, Hd);
+      a.w_lo = make_seg3(plane(bl.dec_ih_l), Ha + D, Ha, plane(bl.dec_ih_l) + Ha, Ha + D, D, plane(bl.dec_hh_l), Hd, Hd);
+      a.h_out_h = sb.h_dec_h[1 - p]; a.h_out_l = sb.h_dec_l[1 - p];
+    } else {
+      a.a = make_seg3(sb.h_att[1 - p], Ha, Ha, sb.ctx, D, D, sb.h_dec[p], Hd, Hd);
+      a.w = make_seg3(blob + bl.dec_ih, Ha + D, Ha, blob + bl.dec_ih + Ha, Ha + D, D, blob + bl.dec_hh, Hd, Hd);
+      a.a_lo = a.a; a.w_lo = a.w;
+    }
     a.bsum = blob + bl.dec_b; a.h_prev = sb.h_dec[p]; a.c = sb.c_dec; a.h_out = sb.h_dec[1 - p];
     a.M = B; a.H = Hd; a.K = Ha + D + Hd; a.pz = d.p_zoneout; a.ctrl = ctrl; a.t = io.t; a.dbg = io.dbg;
     launch_lstm(a, st);
@@ -294,6 +349,7 @@ int ttsdec_create(const ttsdec_dims* dims, ttsdec_handle** out) {
   ttsdec_handle* h = new (std::nothrow) ttsdec_handle();
   if (!h) return TTSDEC_ERR_INVALID_ARG;
   h->d = *dims;
+  h->precision = TTSDEC_PREC_F32;
   h->bl = make_blob_layout(*dims);
   h->blob = nullptr;
   int ndev = 0, dev = -1;
@@ -315,6 +371,17 @@ int ttsdec_destroy(ttsdec_handle* h) {
 int ttsdec_num_weight_tensors(const ttsdec_handle* h) {
   if (!h) return TTSDEC_ERR_INVALID_ARG;
   return TTSDEC_W_DECODER_COUNT + (h->d.postnet_layers > 0 ? TTSDEC_W_POSTNET_PER_LAYER * h->d.postnet_layers + 1 : 0);
+}
+
+int ttsdec_set_precision(ttsdec_handle* h, int precision) {
+  if (!h || (precision != TTSDEC_PREC_F32 && precision != TTSDEC_PREC_SPLIT_F16)) return TTSDEC_ERR_INVALID_ARG;
+  h->precision = precision;
+  return TTSDEC_OK;
+}
+
+int ttsdec_get_precision(const ttsdec_handle* h) {
+  if (!h) return TTSDEC_ERR_INVALID_ARG;
+  return lstm_prec(h) ? TTSDEC_PREC_SPLIT_F16 : TTSDEC_PREC_F32;
 }
 
 size_t ttsdec_packed_bytes(const ttsdec_handle* h) { return h ? h->bl.total * sizeof(float) : 0; }
@@ -346,6 +413,11 @@ int ttsdec_pack_weights(ttsdec_handle* h, const float* const* src, int n_src, vo
   launch_copy(src[TTSDEC_W_DEC_HH], b + L.dec_hh, 4 * Hd * Hd, st);
   if (src[TTSDEC_W_DEC_BIH] && src[TTSDEC_W_DEC_BHH])
     launch_add_vec(src[TTSDEC_W_DEC_BIH], src[TTSDEC_W_DEC_BHH], b + L.dec_b, (int)(4 * Hd), st);
+  auto hp = [&](size_t float_off) { return reinterpret_cast<f16*>(b + float_off); };
+  launch_split(src[TTSDEC_W_ATT_IH], hp(L.att_ih_h), hp(L.att_ih_l), 4 * Ha * (P + D), st);
+  launch_split(src[TTSDEC_W_ATT_HH], hp(L.att_hh_h), hp(L.att_hh_l), 4 * Ha * Ha, st);
+  launch_split(src[TTSDEC_W_DEC_IH], hp(L.dec_ih_h), hp(L.dec_ih_l), 4 * Hd * (Ha + D), st);
+  launch_split(src[TTSDEC_W_DEC_HH], hp(L.dec_hh_h), hp(L.dec_hh_l), 4 * Hd * Hd, st);
   launch_copy(src[TTSDEC_W_INIT_H0], b + L.h0a, Ha, st);
   launch_copy(src[TTSDEC_W_INIT_C0], b + L.c0a, Ha, st);
   launch_copy(src[TTSDEC_W_INIT_H1], b + L.h0d, Hd, st);
@@ -409,6 +481,8 @@ int ttsdec_decode(ttsdec_handle* h, const float* memory, int B, int L, int t_beg
     ia.h0_dec = h->blob + h->bl.h0d; ia.c0_dec = h->blob + h->bl.c0d;
     ia.h_att = sb.h_att[0]; ia.c_att = sb.c_att; ia.h_dec = sb.h_dec[0]; ia.c_dec = sb.c_dec;
     ia.ctx = sb.ctx; ia.w = sb.w[0]; ia.ynext = sb.ynext;
+    ia.h_att_h = sb.h_att_h[0]; ia.h_att_l = sb.h_att_l[0]; ia.h_dec_h = sb.h_dec_h[0]; ia.h_dec_l = sb.h_dec_l[0];
+    ia.ctx_h = sb.ctx_h; ia.ctx_l = sb.ctx_l;
     ia.B = B; ia.L = L; ia.D = d.d_ctx; ia.Ha = d.h_att; ia.Hd = d.h_dec; ia.d_mel = d.d_mel;
     launch_init(ia, st);
   }
@@ -495,6 +569,11 @@ int ttsdec_cell_step(ttsdec_handle* h, const float* x, const float* memory, int 
   launch_copy(c_att, sb.c_att, b * d.h_att, st);
   launch_copy(h_dec, sb.h_dec[p], b * d.h_dec, st);
   launch_copy(c_dec, sb.c_dec, b * d.h_dec, st);
+  if (lstm_prec(h)) {
+    launch_split(ctx, sb.ctx_h, sb.ctx_l, b * d.d_ctx, st);
+    launch_split(h_att, sb.h_att_h[p], sb.h_att_l[p], b * d.h_att, st);
+    launch_split(h_dec, sb.h_dec_h[p], sb.h_dec_l[p], b * d.h_dec, st);
+  }
   StepIo io;
   memset(&io, 0, sizeof(io));
   io.memory = memory; io.B = B; io.L = L; io.t = step; io.t_rel = 0; io.t_stride = 1;

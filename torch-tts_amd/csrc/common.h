@@ -71,50 +71,64 @@ __host__ __device__ __forceinline__ uint32_t philox_keep(uint64_t seed, uint32_t
 // the reference: decoder_cell.py:187,191,192).  kend[] are cumulative ends.
 // ---------------------------------------------------------------------------
 struct Seg3 {
-  const float *p0, *p1, *p2;
-  int ld0, ld1, ld2;
-  int e0, e1, e2;  // cumulative segment ends in the virtual K axis
+  const void *p0, *p1, *p2;  // element type (fp32 or fp16 plane) is the kernel's business
+  int ld0, ld1, ld2;         // leading dimensions in elements
+  int e0, e1, e2;            // cumulative segment ends in the virtual K axis (elements)
 };
 
-__host__ __device__ inline Seg3 make_seg3(const float* p0, int ld0, int k0, const float* p1, int ld1, int k1,
-                                          const float* p2, int ld2, int k2) {
+__host__ __device__ inline Seg3 make_seg3(const void* p0, int ld0, int k0, const void* p1, int ld1, int k1,
+                                          const void* p2, int ld2, int k2) {
   Seg3 s;
   s.p0 = p0; s.ld0 = ld0; s.e0 = k0;
   s.p1 = p1; s.ld1 = ld1; s.e1 = k0 + k1;
   s.p2 = p2; s.ld2 = ld2; s.e2 = k0 + k1 + k2;
   return s;
 }
-__host__ __device__ inline Seg3 make_seg2(const float* p0, int ld0, int k0, const float* p1, int ld1, int k1) {
+__host__ __device__ inline Seg3 make_seg2(const void* p0, int ld0, int k0, const void* p1, int ld1, int k1) {
   return make_seg3(p0, ld0, k0, p1, ld1, k1, p1, ld1, 0);
 }
-__host__ __device__ inline Seg3 make_seg1(const float* p0, int ld0, int k0) {
+__host__ __device__ inline Seg3 make_seg1(const void* p0, int ld0, int k0) {
   return make_seg3(p0, ld0, k0, p0, ld0, 0, p0, ld0, 0);
 }
 
 // Global-address-space pointer types.  Pointers that reach a kernel inside a by-value
 // struct are generic to the compiler, which then emits flat_load (uncountable in vmcnt,
 // so every wait becomes vmcnt(0)); casting to address_space(1) gives global_load.
-typedef __attribute__((address_space(1))) const float gfloat;
-typedef __attribute__((address_space(1))) const f32x4 gf32x4;
-__device__ __forceinline__ gfloat* as_global(const float* p) { return (gfloat*)p; }
-__device__ __forceinline__ f32x4 gload4(gfloat* p) { return *(gf32x4*)p; }
+typedef __attribute__((address_space(1))) const char gbyte;
+__device__ __forceinline__ gbyte* as_global(const void* p) { return (gbyte*)p; }
 
 // 16 zero bytes in device memory: out-of-range tile elements are loaded from here, so
-// a loader only ever selects an ADDRESS and the loaded value is first touched when it
-// is written to LDS (keeps several tiles of loads in flight; no select behind a load).
+// a loader only ever selects an ADDRESS (every lane always issues its load).
 __device__ __attribute__((aligned(16))) float g_zero4[4] = {0.f, 0.f, 0.f, 0.f};
-__device__ __forceinline__ gfloat* zero_addr() { return (gfloat*)g_zero4; }
+__device__ __forceinline__ gbyte* zero_addr() { return (gbyte*)g_zero4; }
 
-// segment s of a Seg3: pointer to (row, k = 0) and length
-__device__ __forceinline__ gfloat* seg_row_ptr(const Seg3& s, int row, int seg) {
-  const float* p = seg == 0 ? s.p0 : (seg == 1 ? s.p1 : s.p2);
+// segment s of a Seg3 with EB-byte elements: pointer to (row, k = 0) and length in elements
+template <int EB>
+__device__ __forceinline__ gbyte* seg_row_ptr(const Seg3& s, int row, int seg) {
+  const void* p = seg == 0 ? s.p0 : (seg == 1 ? s.p1 : s.p2);
   const int ld = seg == 0 ? s.ld0 : (seg == 1 ? s.ld1 : s.ld2);
-  return as_global(p) + (long)row * ld;
+  return as_global(p) + (long)row * ld * EB;
 }
 __device__ __forceinline__ int seg_len(const Seg3& s, int seg) {
   return seg == 0 ? s.e0 : (seg == 1 ? s.e1 - s.e0 : s.e2 - s.e1);
 }
 __device__ __forceinline__ int seg_count(const Seg3& s) { return s.e2 > s.e1 ? 3 : (s.e1 > s.e0 ? 2 : 1); }
+
+// ---------------------------------------------------------------------------
+// Split-fp16 representation of an fp32 value: x ~= hi + lo * 2^-11 with hi = fp16(x)
+// (forced to 0 when it would be subnormal) and lo = fp16((x - hi) * 2^11).  22 significand
+// bits; exact products of such halves accumulate in fp32 on the f16 MFMA:
+//   a*b ~= ah*bh + (ah*bl + al*bh) * 2^-11        (dropped al*bl term: 2^-22 relative)
+// ---------------------------------------------------------------------------
+typedef _Float16 f16;
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+constexpr float kSplitScale = 2048.0f;
+__device__ __forceinline__ void split_f16(float x, f16& hi, f16& lo) {
+  f16 h = (f16)x;
+  if (fabsf(x) < 6.103515625e-05f) h = (f16)0.0f;
+  hi = h;
+  lo = (f16)((x - (float)h) * kSplitScale);
+}
 
 template <int N, class F>
 __device__ __forceinline__ void static_for(F&& f) {

@@ -11,15 +11,19 @@ namespace ttsdec {
 // ===========================================================================
 // generic row GEMM:  out[m, n] = epi( sum_k A[m, k] * W[n, k] )
 // ===========================================================================
-// rows m0.. of an [M, K] activation made of up to three K segments
+// rows m0.. of an [M, K] activation made of up to three K segments; EB-byte elements,
+// plane 1 (fp16 lo) comes from a second Seg3 of identical shape
+template <int EB>
 struct LoaderPlain {
-  Seg3 s;
+  Seg3 s, s_lo;
   int m0, M;
   static constexpr bool kRange = false;
   __device__ __forceinline__ int nseg() const { return seg_count(s); }
   __device__ __forceinline__ int seglen(int i) const { return seg_len(s, i); }
   __device__ __forceinline__ bool row_ok(int r) const { return m0 + r < M; }
-  __device__ __forceinline__ gfloat* row_ptr(int r, int i) const { return seg_row_ptr(s, m0 + r, i); }
+  __device__ __forceinline__ gbyte* row_ptr(int r, int i, int plane) const {
+    return seg_row_ptr<EB>(plane == 0 ? s : s_lo, m0 + r, i);
+  }
   __device__ __forceinline__ int k_lo(int) const { return 0; }
   __device__ __forceinline__ int k_hi(int) const { return 0; }
 };
@@ -34,8 +38,8 @@ struct LoaderConv {
   __device__ __forceinline__ int nseg() const { return 1; }
   __device__ __forceinline__ int seglen(int i) const { return i == 0 ? K : 0; }
   __device__ __forceinline__ bool row_ok(int r) const { return m0 + r < M; }
-  __device__ __forceinline__ gfloat* row_ptr(int r, int) const {
-    return as_global(x) + ((long)(m0 + r) - (taps >> 1)) * Cin;
+  __device__ __forceinline__ gbyte* row_ptr(int r, int, int) const {
+    return as_global(x) + (((long)(m0 + r) - (taps >> 1)) * Cin) * 4;
   }
   __device__ __forceinline__ int k_lo(int r) const {
     const int t = (m0 + r) % T, half = taps >> 1;
@@ -49,14 +53,17 @@ struct LoaderConv {
 };
 
 // rows n0.. of a PyTorch-layout weight [N, K] cut into the same K segments as A
+template <int EB>
 struct LoaderW {
-  Seg3 w;
+  Seg3 w, w_lo;
   int n0, N;
   static constexpr bool kRange = false;
   __device__ __forceinline__ int nseg() const { return seg_count(w); }
   __device__ __forceinline__ int seglen(int i) const { return seg_len(w, i); }
   __device__ __forceinline__ bool row_ok(int r) const { return n0 + r < N; }
-  __device__ __forceinline__ gfloat* row_ptr(int r, int i) const { return seg_row_ptr(w, n0 + r, i); }
+  __device__ __forceinline__ gbyte* row_ptr(int r, int i, int plane) const {
+    return seg_row_ptr<EB>(plane == 0 ? w : w_lo, n0 + r, i);
+  }
 };
 
 template <class Cfg, int AK, int EK>
@@ -67,9 +74,10 @@ __global__ __launch_bounds__(kGemmThreads) void gemm_rows_kernel(GemmArgs g) {
   const int m0 = blockIdx.y * BM;
   const int n0 = blockIdx.x * BN;
   if (AK == A_CONV) {
-    const LoaderConv la{g.a.p0, m0, g.M, g.T, g.Cin, g.taps, g.K};
-    const LoaderW lb{make_seg1(g.W, g.ldw, g.K), n0, g.N};
-    gemm_tile_f32<Cfg>(la, lb, smem);
+    const LoaderConv la{static_cast<const float*>(g.a.p0), m0, g.M, g.T, g.Cin, g.taps, g.K};
+    const Seg3 ws = make_seg1(g.W, g.ldw, g.K);
+    const LoaderW<4> lb{ws, ws, n0, g.N};
+    gemm_tile<Cfg>(la, lb, smem);
   } else {
     Seg3 s = g.a;
     if (g.teacher != nullptr && g.t > 0 && g.teacher_flags[g.t - 1] != 0) {
@@ -78,9 +86,10 @@ __global__ __launch_bounds__(kGemmThreads) void gemm_rows_kernel(GemmArgs g) {
     }
     // W is one [N, K] matrix: cut it at A's segment boundaries
     const int k0 = s.e0, k1 = s.e1 - s.e0, k2 = s.e2 - s.e1;
-    const LoaderW lb{make_seg3(g.W, g.ldw, k0, g.W + k0, g.ldw, k1, g.W + k0 + k1, g.ldw, k2), n0, g.N};
-    const LoaderPlain la{s, m0, g.M};
-    gemm_tile_f32<Cfg>(la, lb, smem);
+    const Seg3 ws = make_seg3(g.W, g.ldw, k0, g.W + k0, g.ldw, k1, g.W + k0 + k1, g.ldw, k2);
+    const LoaderW<4> lb{ws, ws, n0, g.N};
+    const LoaderPlain<4> la{s, s, m0, g.M};
+    gemm_tile<Cfg>(la, lb, smem);
   }
 
   for (int e = threadIdx.x; e < BM * BN; e += kGemmThreads) {
@@ -100,6 +109,7 @@ __global__ __launch_bounds__(kGemmThreads) void gemm_rows_kernel(GemmArgs g) {
         v = philox_keep(g.seed, (uint32_t)g.t, (uint32_t)g.layer, (uint32_t)m, (uint32_t)n) ? mul_rn(v, g.keep_scale) : 0.f;
       }
       g.out[(size_t)m * g.ldo + n] = v;
+      if (g.out_h != nullptr) split_f16(v, g.out_h[(size_t)m * g.ldo + n], g.out_l[(size_t)m * g.ldo + n]);
     } else if (EK == EPI_PROJ) {
       const int nm = g.r * g.d_mel;
       if (n < nm) {
@@ -159,16 +169,16 @@ void launch_gemm(const GemmArgs& a, AKind ak, EpiKind ek, hipStream_t st) {
 // gathered from the i/f/g/o row blocks of the PyTorch-layout weights), so the cell
 // update happens in the epilogue without another pass.
 // ===========================================================================
-template <int BU>
+template <int BU, int EB>
 struct LoaderWLstm {
-  Seg3 w;
+  Seg3 w, w_lo;
   int u0, H;
   static constexpr bool kRange = false;
   __device__ __forceinline__ int nseg() const { return seg_count(w); }
   __device__ __forceinline__ int seglen(int i) const { return seg_len(w, i); }
   __device__ __forceinline__ bool row_ok(int r) const { return u0 + (r % BU) < H; }
-  __device__ __forceinline__ gfloat* row_ptr(int r, int i) const {
-    return seg_row_ptr(w, (r / BU) * H + u0 + (r % BU), i);  // PyTorch gate blocks i,f,g,o
+  __device__ __forceinline__ gbyte* row_ptr(int r, int i, int plane) const {
+    return seg_row_ptr<EB>(plane == 0 ? w : w_lo, (r / BU) * H + u0 + (r % BU), i);  // PyTorch gate blocks i,f,g,o
   }
 };
 
@@ -176,12 +186,12 @@ template <class Cfg>
 __global__ __launch_bounds__(kGemmThreads) void lstm_kernel(LstmArgs g) {
   if (g.ctrl != nullptr && g.t > g.ctrl->stop_t) return;
   __shared__ __attribute__((aligned(16))) float smem[Cfg::kLdsFloats];
-  constexpr int BM = Cfg::BM, BN = Cfg::BN, LDO = Cfg::LDO, BU = BN / 4;
+  constexpr int BM = Cfg::BM, BN = Cfg::BN, LDO = Cfg::LDO, BU = BN / 4, EB = Cfg::EB;
   const int m0 = blockIdx.y * BM;
   const int u0 = blockIdx.x * BU;
-  const LoaderPlain la{g.a, m0, g.M};
-  const LoaderWLstm<BU> lb{g.w, u0, g.H};
-  gemm_tile_f32<Cfg>(la, lb, smem, g.dbg);
+  const LoaderPlain<EB> la{g.a, g.a_lo, m0, g.M};
+  const LoaderWLstm<BU, EB> lb{g.w, g.w_lo, u0, g.H};
+  gemm_tile<Cfg>(la, lb, smem, g.dbg);
 
   const int H = g.H;
   for (int e = threadIdx.x; e < BM * BU; e += kGemmThreads) {
@@ -201,23 +211,37 @@ __global__ __launch_bounds__(kGemmThreads) void lstm_kernel(LstmArgs g) {
     const float h_new = mul_rn(sigmoid_f(go), tanhf(c_new));
     // rnn.py:36-38 eval-mode zoneout: p*prev + (1-p)*new
     const float q = sub_rn(1.0f, g.pz);
-    g.h_out[idx] = add_rn(mul_rn(g.pz, h_prev), mul_rn(q, h_new));
+    const float h = add_rn(mul_rn(g.pz, h_prev), mul_rn(q, h_new));
+    g.h_out[idx] = h;
+    if (g.h_out_h != nullptr) split_f16(h, g.h_out_h[idx], g.h_out_l[idx]);
     g.c[idx] = add_rn(mul_rn(g.pz, c_prev), mul_rn(q, c_new));
   }
 }
 
 void launch_lstm(const LstmArgs& a, hipStream_t st) {
   if (a.M <= 0) return;
+  if (a.prec == 1) {
+    if (a.M >= 192) {
+      using Cfg = TileCfg<2, 2, 1, 4, PREC_F16S>;  // 64 rows x 16 units, 32 KiB stages (64 k each)
+      dim3 grid((a.H + 15) / 16, (a.M + 63) / 64);
+      hipLaunchKernelGGL((lstm_kernel<Cfg>), grid, dim3(kGemmThreads), 0, st, a);
+    } else {
+      using Cfg = TileCfg<2, 1, 2, 3, PREC_F16S>;  // 64 rows x 8 units, 48 KiB stages (128 k each)
+      dim3 grid((a.H + 7) / 8, (a.M + 63) / 64);
+      hipLaunchKernelGGL((lstm_kernel<Cfg>), grid, dim3(kGemmThreads), 0, st, a);
+    }
+    return;
+  }
   if (a.M >= 192) {
-    using Cfg = TileCfg<2, 2, 1, 6>;  // 64 rows x 16 units, 5 x 16 KiB tiles in flight
+    using Cfg = TileCfg<2, 2, 1, 6>;  // 64 rows x 16 units, 16 KiB stages
     dim3 grid((a.H + 15) / 16, (a.M + 63) / 64);
     hipLaunchKernelGGL((lstm_kernel<Cfg>), grid, dim3(kGemmThreads), 0, st, a);
   } else if (a.M >= 96) {
-    using Cfg = TileCfg<2, 1, 2, 4>;  // 64 rows x 8 units, 3 x 24 KiB in flight
+    using Cfg = TileCfg<2, 1, 2, 4>;  // 64 rows x 8 units, 24 KiB stages
     dim3 grid((a.H + 7) / 8, (a.M + 63) / 64);
     hipLaunchKernelGGL((lstm_kernel<Cfg>), grid, dim3(kGemmThreads), 0, st, a);
   } else {
-    using Cfg = TileCfg<1, 1, 4, 4>;  // 32 rows x 8 units, 3 x 32 KiB in flight
+    using Cfg = TileCfg<1, 1, 4, 4>;  // 32 rows x 8 units, 32 KiB stages
     dim3 grid((a.H + 7) / 8, (a.M + 31) / 32);
     hipLaunchKernelGGL((lstm_kernel<Cfg>), grid, dim3(kGemmThreads), 0, st, a);
   }
@@ -339,6 +363,7 @@ __global__ __launch_bounds__(kAttnThreads) void attn_kernel(AttnArgs g) {
 #pragma unroll
     for (int w = 0; w < NW; ++w) s += part[((w * NJ + j) * 64 + ln) * 4 + comp];
     g.ctx[(size_t)b * D + d] = s;
+    if (g.ctx_h != nullptr) split_f16(s, g.ctx_h[(size_t)b * D + d], g.ctx_l[(size_t)b * D + d]);
   }
 }
 
@@ -364,12 +389,20 @@ __global__ void init_state_kernel(InitArgs g) {
   if (i < nHa) {
     g.h_att[i] = g.h0_att[i % g.Ha];
     g.c_att[i] = g.c0_att[i % g.Ha];
+    if (g.h_att_h != nullptr) split_f16(g.h0_att[i % g.Ha], g.h_att_h[i], g.h_att_l[i]);
   }
   if (i < nHd) {
     g.h_dec[i] = g.h0_dec[i % g.Hd];
     g.c_dec[i] = g.c0_dec[i % g.Hd];
+    if (g.h_dec_h != nullptr) split_f16(g.h0_dec[i % g.Hd], g.h_dec_h[i], g.h_dec_l[i]);
   }
-  if (i < (size_t)g.B * g.D) g.ctx[i] = 0.f;
+  if (i < (size_t)g.B * g.D) {
+    g.ctx[i] = 0.f;
+    if (g.ctx_h != nullptr) {
+      g.ctx_h[i] = (f16)0.0f;
+      g.ctx_l[i] = (f16)0.0f;
+    }
+  }
   if (i < (size_t)g.B * g.L) g.w[i] = (i % g.L == 0) ? 1.0f : 0.f;
   if (i < (size_t)g.B * g.d_mel) g.ynext[i] = 0.f;
 }
@@ -414,6 +447,15 @@ __global__ void copy_kernel(const float* src, float* dst, size_t n) {
 void launch_copy(const float* src, float* dst, size_t n, hipStream_t st) {
   if (n == 0 || src == nullptr) return;
   hipLaunchKernelGGL(copy_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, src, dst, n);
+}
+
+__global__ void split_kernel(const float* src, f16* hi, f16* lo, size_t n) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) split_f16(src[i], hi[i], lo[i]);
+}
+void launch_split(const float* src, f16* hi, f16* lo, size_t n, hipStream_t st) {
+  if (n == 0 || src == nullptr) return;
+  hipLaunchKernelGGL(split_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, src, hi, lo, n);
 }
 
 __global__ void conv_transpose_kernel(const float* w, float* out, int Co, int Ci, int k) {

@@ -1,27 +1,30 @@
-// LDS-tiled fp32 GEMM main loop on the CDNA4 fp32-input matrix instruction
-// v_mfma_f32_32x32x2_f32 (exact fp32: a k-ordered fmaf chain per output).
+// LDS-tiled GEMM main loop for gfx950, two arithmetic modes behind one data path:
+//
+//   PREC_F32   exact fp32 on v_mfma_f32_32x32x2_f32 (a k-ordered fmaf chain per output);
+//   PREC_F16S  split-fp16: every operand is two fp16 planes (hi, lo*2^11, see common.h) and
+//              a*b = ah*bh + (ah*bl + al*bh)*2^-11 on v_mfma_f32_32x32x16_f16 with fp32
+//              accumulation - 3 MFMAs of 32 cycles per 16 k instead of 8 of 64 cycles,
+//              ~2^-22 relative per product.
 //
 //   C[BM x BN] = sum_k A[row, k] * B[col, k]        (both operands K-contiguous,
 //                                                   i.e. activations [M, K] and
 //                                                   PyTorch-layout weights [N, K])
 //
-// One workgroup = 4 MFMA waves arranged WM x WN x WK (+ 4 loader waves, see below); every
-// MFMA wave owns one 32x32 accumulator (16 VGPRs).  BM = 32*WM, BN = 32*WN; each main-loop iteration
-// consumes KT = 32*WK of K, wave (.,.,wk) taking the wk-th 32-wide slice (intra-
-// workgroup split-K, summed through LDS in the epilogue).
+// One workgroup = 4 MFMA waves arranged WM x WN x WK (+ 4 loader waves, below); every MFMA
+// wave owns one 32x32 output block.  BM = 32*WM, BN = 32*WN; each main-loop iteration
+// consumes one tile row of ROWB = 128*WK bytes per plane (32*WK fp32 or 64*WK fp16 of K),
+// wave (.,.,wk) taking the wk-th 128-byte slice (intra-workgroup split-K, summed through
+// LDS in the epilogue).
 //
 // Staging: direct-to-LDS loads (global_load_lds_dwordx4, 16 B per lane, 1 KiB per wave
-// instruction) into a ring of S stages, S-1 K-tiles in flight.  At ~1 workgroup per CU
-// the loads in flight are the only latency hiding there is (Little: ~2 us x ~35 GB/s per
-// CU = ~64 KiB), so the ring is deep and never drained: each iteration waits with a
-// COUNTED s_waitcnt vmcnt(N) for the oldest tile only, crosses one raw s_barrier, refills
-// the stage freed by the previous iteration and runs its 16 MFMAs.  (__syncthreads() would
-// drain the ring: it waits vmcnt(0) while an LDS-DMA is pending.)
+// instruction) into a ring of S stages.  The ring is never drained: each iteration waits
+// with a COUNTED s_waitcnt vmcnt(N) for the oldest tile only and crosses one raw s_barrier.
+// (__syncthreads() would drain it: it waits vmcnt(0) while an LDS-DMA is pending.)
 //
 // An LDS-DMA writes wave-uniform base + lane*16, i.e. the LDS image is linear (unpadded
-// rows of KT floats).  Bank conflicts of the ds_read_b128 fragment reads are removed by an
+// rows of ROWB bytes).  Bank conflicts of the ds_read_b128 fragment reads are removed by an
 // XOR swizzle of the 16-byte column index applied to the per-lane SOURCE address and again
-// on the read:  LDS(row, c4) = global(row, c4 ^ swz(row)),  swz = (row>>1)&7 for 128-B rows
+// on the read:  LDS(row, c) = global(row, c ^ swz(row)),  swz = (row>>1)&7 for 128-B rows
 // (two rows per 256-B bank row), row&15 for 256/512-B rows.  The 16 lanes of a ds_read_b128
 // group then hit 16 distinct 16-B slots.
 //
@@ -29,35 +32,46 @@
 // from a 16-byte zero block, so every lane always issues its load and the per-tile
 // instruction stream - hence the vmcnt arithmetic - is the same for every tile.
 //
-// K permutation: within a 32-wide slice lane half h = lane>>5 supplies k = 16h + 4q + e
-// for MFMA (q, e); A and B use the same map, so each MFMA's two k-slots pair up
-// correctly and every k is consumed exactly once.
+// K order inside a 128-byte slice.  fp32: lane half h = lane>>5 supplies k = 16h + 4q + e
+// for MFMA (q, e).  fp16: k16-step s uses the 16-byte column 2s + h, i.e. k = 16s + 8h + j.
+// A and B use the same map, so every k is consumed exactly once.
 #pragma once
 #include "common.h"
 
 namespace ttsdec {
 
-template <int WM, int WN, int WK, int S>
+enum Prec { PREC_F32 = 0, PREC_F16S = 1 };
+
+template <int WM, int WN, int WK, int S, int PREC = PREC_F32>
 struct TileCfg {
   static_assert(WM * WN * WK == 4, "4 MFMA waves per workgroup");
-  static_assert(S >= 4, "ring needs at least 4 stages (fragment reads run one tile ahead)");
+  static_assert(S >= 3, "ring needs at least 3 stages (fragment reads run one tile ahead of the MFMAs)");
+  static constexpr int kPrec = PREC;
+  static constexpr int EB = (PREC == PREC_F32) ? 4 : 2;      // element bytes
+  static constexpr int NP = (PREC == PREC_F32) ? 1 : 2;      // planes per operand
   static constexpr int BM = 32 * WM;
   static constexpr int BN = 32 * WN;
-  static constexpr int KT = 32 * WK;
-  static constexpr int C4 = KT / 4;                 // 16-byte columns per tile row
-  static constexpr int ROWS_PER_INST = 64 / C4;     // tile rows one wave instruction covers
-  static constexpr int NA = BM * KT / 1024;         // glds instructions per wave per A tile
-  static constexpr int NB = BN * KT / 1024;
+  static constexpr int ROWB = 128 * WK;                      // bytes per tile row per plane
+  static constexpr int KT = ROWB / EB;                       // K elements per tile
+  static constexpr int C16 = ROWB / 16;                      // 16-byte columns per tile row
+  static constexpr int ROWS_PER_INST = 64 / C16;             // tile rows one wave instruction covers
+  static constexpr int NA = BM * ROWB / 4096;                // LDS-DMA instructions per loader wave per A plane tile
+  static constexpr int NB = BN * ROWB / 4096;
+  static constexpr int NLOADS = NP * (NA + NB);              // per loader wave per tile
   static constexpr int STAGES = S;
-  static constexpr int kStageFloats = (BM + BN) * KT;
+  static constexpr int kPlaneABytes = BM * ROWB;
+  static constexpr int kPlaneBBytes = BN * ROWB;
+  static constexpr int kStageBytes = NP * (kPlaneABytes + kPlaneBBytes);
   static constexpr int LDO = BN + 1;
-  static constexpr int kOutFloats = WK * BM * LDO;
-  static constexpr int kRingFloats = S * kStageFloats;
-  static constexpr int kLdsFloats = kRingFloats > kOutFloats ? kRingFloats : kOutFloats;
+  static constexpr int kOutBytes = WK * BM * LDO * 4;
+  static constexpr int kRingBytes = S * kStageBytes;
+  static constexpr int kLdsBytes = kRingBytes > kOutBytes ? kRingBytes : kOutBytes;
+  static constexpr int kLdsFloats = kLdsBytes / 4;
   // loads left in flight when the tile whose fragments are read NEXT (one ahead of the MFMAs) has landed
-  static constexpr int kWaitCnt = (S - 3) * (NA + NB);
-  static_assert(kWaitCnt <= 63, "vmcnt field");
-  __device__ static __forceinline__ int swz(int row) { return KT == 32 ? ((row >> 1) & 7) : (row & 15); }
+  static constexpr int kWaitCnt = (S - 3) * NLOADS;
+  static_assert((S - 2) * NLOADS <= 63, "vmcnt field");
+  static_assert(kLdsBytes <= 160 * 1024, "LDS per workgroup");
+  __device__ static __forceinline__ int swz(int row) { return ROWB == 128 ? ((row >> 1) & 7) : (row & 15); }
 };
 
 typedef __attribute__((address_space(3))) void lds_void;
@@ -69,22 +83,21 @@ __device__ __forceinline__ void wait_vmcnt() {
 }
 
 // Operand loaders (LoaderA / LoaderB) describe rows of a K-segmented operand:
-//   int   nseg() / seglen(s)      uniform: number of K segments and their lengths (the
-//                                 torch.cat pieces of the reference); A and B agree on them
-//   bool  row_ok(r)               tile row r (0 <= r < BM or BN) exists
-//   gfloat* row_ptr(r, s)         address of element k = 0 of segment s in tile row r
-//   kRange / k_lo(r) / k_hi(r)    optional per-row valid k window (conv zero padding)
+//   int   nseg() / seglen(s)       uniform: number of K segments and their lengths in elements
+//                                  (the torch.cat pieces of the reference); A and B agree
+//   bool  row_ok(r)                tile row r (0 <= r < BM or BN) exists
+//   gbyte* row_ptr(r, s, plane)    address of element k = 0 of segment s in tile row r
+//                                  (plane 0 = fp32 or fp16 hi, plane 1 = fp16 lo)
+//   kRange / k_lo(r) / k_hi(r)     optional per-row valid k window in elements (conv padding)
 // The K loop walks the segments tile by tile (each segment zero-padded up to a multiple of
-// KT), so per tile a lane's source address is just "previous + KT": one 64-bit add per
+// KT), so per tile a lane's source address is just "previous + ROWB": one 64-bit add per
 // load.  A lane whose row or k is out of range reads the 16-byte zero block instead.
 //
 // Wave roles (512-thread workgroup, two waves per SIMD):
 //   waves 0-3  MFMA waves: fragment reads (one tile ahead, double-buffered registers) and
 //              the dependent MFMA chain, nothing else in their instruction stream;
-//   waves 4-7  loader waves: address updates and LDS-DMA issue.  An LDS-DMA costs its
-//              issuing wave ~60-185 cycles (one wave sustains only ~25 GB/s), which would
-//              come straight out of the MFMA chain if the MFMA waves issued it; on a
-//              co-resident wave the VMEM issue overlaps the other wave's MFMAs.
+//   waves 4-7  loader waves: address updates and LDS-DMA issue (an LDS-DMA costs its
+//              issuing wave ~60-185 cycles; on a co-resident wave that overlaps the MFMAs).
 // Per K tile there is one workgroup barrier: loaders arrive once their part of tile t+1
 // has landed (counted vmcnt), MFMA waves once tile t-1's MFMAs are issued; after it the
 // loaders refill the stage tile t-1 occupied and the MFMA waves read tile t+1 / run tile t.
@@ -92,10 +105,13 @@ __device__ __forceinline__ void wait_vmcnt() {
 // After the call `smem` holds the BM x BN result, row-major with leading dimension
 // Cfg::LDO, summed over the WK slices, visible to all threads.
 template <class Cfg, class LoaderA, class LoaderB>
-__device__ __forceinline__ void gemm_tile_f32(const LoaderA& la, const LoaderB& lb, float* smem, int dbg = 0) {
-  constexpr int BM = Cfg::BM, BN = Cfg::BN, KT = Cfg::KT, C4 = Cfg::C4, RPI = Cfg::ROWS_PER_INST;
-  constexpr int NA = Cfg::NA, NB = Cfg::NB, LDO = Cfg::LDO, S = Cfg::STAGES;
-  constexpr int WN_ = BN / 32, WK_ = KT / 32;
+__device__ __forceinline__ void gemm_tile(const LoaderA& la, const LoaderB& lb, float* smem, int dbg = 0) {
+  constexpr int BM = Cfg::BM, BN = Cfg::BN, KT = Cfg::KT, C16 = Cfg::C16, RPI = Cfg::ROWS_PER_INST;
+  constexpr int NA = Cfg::NA, NB = Cfg::NB, NP = Cfg::NP, EB = Cfg::EB, ROWB = Cfg::ROWB;
+  constexpr int LDO = Cfg::LDO, S = Cfg::STAGES;
+  constexpr int WN_ = BN / 32, WK_ = ROWB / 128;
+  constexpr int EPC = 16 / EB;  // elements per 16-byte column
+  char* lds = reinterpret_cast<char*>(smem);
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave8 = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -108,9 +124,12 @@ __device__ __forceinline__ void gemm_tile_f32(const LoaderA& la, const LoaderB& 
   const int nt0 = (len0 + KT - 1) / KT, nt1 = (len1 + KT - 1) / KT, nt2 = (len2 + KT - 1) / KT;
   const int nk = nt0 + (nseg > 1 ? nt1 : 0) + (nseg > 2 ? nt2 : 0);
 
-  f32x16 acc;
+  f32x16 acc, acc2;
 #pragma unroll
-  for (int i = 0; i < 16; ++i) acc[i] = 0.f;
+  for (int i = 0; i < 16; ++i) {
+    acc[i] = 0.f;
+    acc2[i] = 0.f;
+  }
   const int wk = wave % WK_;
   const int wn = (wave / WK_) % WN_;
   const int wm = wave / (WK_ * WN_);
@@ -119,22 +138,26 @@ __device__ __forceinline__ void gemm_tile_f32(const LoaderA& la, const LoaderB& 
 
   if (is_loader) {
     // =========================== loader waves ===========================
-    // loader w issues instructions i = 0..NA-1 covering A-tile rows (w*NA + i)*RPI + lane/C4;
-    // this lane's 16-byte column within the row is (lane % C4) ^ swz(row).
-    gfloat *qa0[NA], *qa1[NA], *qa2[NA], *cura[NA];
-    gfloat *qb0[NB], *qb1[NB], *qb2[NB], *curb[NB];
-    int ca[NA], cb[NB], inca[NA], incb[NB];
+    // loader w issues, per plane, instructions i = 0..NA-1 covering A-tile rows
+    // (w*NA + i)*RPI + lane/C16; this lane's 16-byte column is (lane % C16) ^ swz(row).
+    gbyte *qa0[NP][NA], *qa1[NP][NA], *qa2[NP][NA], *cura[NP][NA];
+    gbyte *qb0[NP][NB], *qb1[NP][NB], *qb2[NP][NB], *curb[NP][NB];
+    int ca[NA], cb[NB], inca[NA], incb[NB];  // element offset of the lane's column; byte increment per tile
     int aklo[NA], akhi[NA];
 #pragma unroll
     for (int i = 0; i < NA; ++i) {
-      const int row = (wave * NA + i) * RPI + lane / C4;
+      const int row = (wave * NA + i) * RPI + lane / C16;
       const bool ok = la.row_ok(row) && dbg != 1;
-      ca[i] = ((lane % C4) ^ Cfg::swz(row)) * 4;
-      qa0[i] = ok ? la.row_ptr(row, 0) + ca[i] : zero_addr();
-      qa1[i] = ok ? la.row_ptr(row, 1) + ca[i] : zero_addr();
-      qa2[i] = ok ? la.row_ptr(row, 2) + ca[i] : zero_addr();
-      inca[i] = ok ? KT : 0;
-      cura[i] = qa0[i];
+      const int c16 = (lane % C16) ^ Cfg::swz(row);
+      ca[i] = c16 * EPC;
+      inca[i] = ok ? ROWB : 0;
+#pragma unroll
+      for (int p = 0; p < NP; ++p) {
+        qa0[p][i] = ok ? la.row_ptr(row, 0, p) + c16 * 16 : zero_addr();
+        qa1[p][i] = ok ? la.row_ptr(row, 1, p) + c16 * 16 : zero_addr();
+        qa2[p][i] = ok ? la.row_ptr(row, 2, p) + c16 * 16 : zero_addr();
+        cura[p][i] = qa0[p][i];
+      }
       if (LoaderA::kRange) {
         aklo[i] = ok ? la.k_lo(row) : 0;
         akhi[i] = ok ? la.k_hi(row) : 0;
@@ -142,35 +165,48 @@ __device__ __forceinline__ void gemm_tile_f32(const LoaderA& la, const LoaderB& 
     }
 #pragma unroll
     for (int i = 0; i < NB; ++i) {
-      const int row = (wave * NB + i) * RPI + lane / C4;
+      const int row = (wave * NB + i) * RPI + lane / C16;
       const bool ok = lb.row_ok(row) && dbg != 1;
-      cb[i] = ((lane % C4) ^ Cfg::swz(row)) * 4;
-      qb0[i] = ok ? lb.row_ptr(row, 0) + cb[i] : zero_addr();
-      qb1[i] = ok ? lb.row_ptr(row, 1) + cb[i] : zero_addr();
-      qb2[i] = ok ? lb.row_ptr(row, 2) + cb[i] : zero_addr();
-      incb[i] = ok ? KT : 0;
-      curb[i] = qb0[i];
+      const int c16 = (lane % C16) ^ Cfg::swz(row);
+      cb[i] = c16 * EPC;
+      incb[i] = ok ? ROWB : 0;
+#pragma unroll
+      for (int p = 0; p < NP; ++p) {
+        qb0[p][i] = ok ? lb.row_ptr(row, 0, p) + c16 * 16 : zero_addr();
+        qb1[p][i] = ok ? lb.row_ptr(row, 1, p) + c16 * 16 : zero_addr();
+        qb2[p][i] = ok ? lb.row_ptr(row, 2, p) + c16 * 16 : zero_addr();
+        curb[p][i] = qb0[p][i];
+      }
     }
     int seg = 0, left = nt0, seg_len = len0, kpos = 0, istage = 0;
 
     auto issue_tile = [&]() {
-      float* st = smem + istage * Cfg::kStageFloats;
+      char* st = lds + istage * Cfg::kStageBytes;
       const bool partial = (kpos + KT > seg_len);  // uniform: last, zero-padded tile of a segment (or past the end)
 #pragma unroll
-      for (int i = 0; i < NA; ++i) {
-        gfloat* p = cura[i];
-        if (LoaderA::kRange)  // the seg_len bound also covers the zero-block tiles past the last segment
-          p = (kpos + ca[i] >= aklo[i] && kpos + ca[i] < akhi[i] && kpos + ca[i] < seg_len) ? p : zero_addr();
-        else
-          p = (partial && kpos + ca[i] >= seg_len) ? zero_addr() : p;
-        __builtin_amdgcn_global_load_lds((global_void*)p, (lds_void*)(st + (wave * NA + i) * 256), 16, 0, 0);
-        cura[i] += inca[i];
+      for (int p = 0; p < NP; ++p) {
+#pragma unroll
+        for (int i = 0; i < NA; ++i) {
+          gbyte* ptr = cura[p][i];
+          if (LoaderA::kRange)  // the seg_len bound also covers the zero-block tiles past the last segment
+            ptr = (kpos + ca[i] >= aklo[i] && kpos + ca[i] < akhi[i] && kpos + ca[i] < seg_len) ? ptr : zero_addr();
+          else
+            ptr = (partial && kpos + ca[i] >= seg_len) ? zero_addr() : ptr;
+          __builtin_amdgcn_global_load_lds((global_void*)ptr,
+                                           (lds_void*)(st + p * Cfg::kPlaneABytes + (wave * NA + i) * 1024), 16, 0, 0);
+          cura[p][i] += inca[i];
+        }
       }
 #pragma unroll
-      for (int i = 0; i < NB; ++i) {
-        gfloat* p = (partial && kpos + cb[i] >= seg_len) ? zero_addr() : curb[i];
-        __builtin_amdgcn_global_load_lds((global_void*)p, (lds_void*)(st + BM * KT + (wave * NB + i) * 256), 16, 0, 0);
-        curb[i] += incb[i];
+      for (int p = 0; p < NP; ++p) {
+#pragma unroll
+        for (int i = 0; i < NB; ++i) {
+          gbyte* ptr = (partial && kpos + cb[i] >= seg_len) ? zero_addr() : curb[p][i];
+          __builtin_amdgcn_global_load_lds(
+              (global_void*)ptr,
+              (lds_void*)(st + NP * Cfg::kPlaneABytes + p * Cfg::kPlaneBBytes + (wave * NB + i) * 1024), 16, 0, 0);
+          curb[p][i] += incb[i];
+        }
       }
       istage = (istage + 1 == S) ? 0 : istage + 1;
       kpos += KT;
@@ -180,15 +216,21 @@ __device__ __forceinline__ void gemm_tile_f32(const LoaderA& la, const LoaderB& 
         if (seg == 1 && nseg > 1) {
           left = nt1; seg_len = len1;
 #pragma unroll
-          for (int i = 0; i < NA; ++i) cura[i] = qa1[i];
+          for (int p = 0; p < NP; ++p) {
 #pragma unroll
-          for (int i = 0; i < NB; ++i) curb[i] = qb1[i];
+            for (int i = 0; i < NA; ++i) cura[p][i] = qa1[p][i];
+#pragma unroll
+            for (int i = 0; i < NB; ++i) curb[p][i] = qb1[p][i];
+          }
         } else if (seg == 2 && nseg > 2) {
           left = nt2; seg_len = len2;
 #pragma unroll
-          for (int i = 0; i < NA; ++i) cura[i] = qa2[i];
+          for (int p = 0; p < NP; ++p) {
 #pragma unroll
-          for (int i = 0; i < NB; ++i) curb[i] = qb2[i];
+            for (int i = 0; i < NA; ++i) cura[p][i] = qa2[p][i];
+#pragma unroll
+            for (int i = 0; i < NB; ++i) curb[p][i] = qb2[p][i];
+          }
         } else {
           left = 0x7fffffff; seg_len = 0;  // every further tile is "partial" with nothing valid
         }
@@ -198,60 +240,107 @@ __device__ __forceinline__ void gemm_tile_f32(const LoaderA& la, const LoaderB& 
     // tiles 0 .. S-2 in flight
 #pragma unroll
     for (int t = 0; t < S - 1; ++t) issue_tile();
-    wait_vmcnt<(S - 2) * (NA + NB)>();  // tile 0 landed
-    __builtin_amdgcn_s_barrier();       // B0
+    wait_vmcnt<(S - 2) * Cfg::NLOADS>();  // tile 0 landed
+    __builtin_amdgcn_s_barrier();         // B0
     for (int t = 0; t < nk; ++t) {
-      wait_vmcnt<Cfg::kWaitCnt>();      // this wave's part of tile t+1 has landed
-      __builtin_amdgcn_s_barrier();     // B(t+1): the MFMA waves have issued tile t-1's MFMAs, its stage is free
-      if (dbg != 3) issue_tile();       // tile t+S-1 into that stage (dbg 3: measurement ablation)
+      wait_vmcnt<Cfg::kWaitCnt>();        // this wave's part of tile t+1 has landed
+      __builtin_amdgcn_s_barrier();       // B(t+1): the MFMA waves have issued tile t-1's MFMAs, its stage is free
+      if (dbg != 3) issue_tile();         // tile t+S-1 into that stage (dbg 3: measurement ablation)
     }
     wait_vmcnt<0>();  // trailing zero-block loads must land before the ring is reused
   } else {
     // ============================ MFMA waves ============================
     const int arow = wm * 32 + l32, brow = wn * 32 + l32;
-    int aoff[4], boff[4];
-#pragma unroll
-    for (int q = 0; q < 4; ++q) {
-      const int c4 = wk * 8 + half * 4 + q;
-      aoff[q] = arow * KT + ((c4 ^ Cfg::swz(arow)) << 2);
-      boff[q] = BM * KT + brow * KT + ((c4 ^ Cfg::swz(brow)) << 2);
-    }
-    // Fragment registers are double-buffered: the reads of tile t+1 are issued right after
-    // the barrier that makes it visible and complete underneath tile t's MFMA chain.
-    f32x4 fa[2][4], fb[2][4];
     int rstage = 0;
-    auto read_frags = [&](auto buf_c) {
-      constexpr int buf = decltype(buf_c)::value;
-      const float* st = smem + rstage * Cfg::kStageFloats;
-      rstage = (rstage + 1 == S) ? 0 : rstage + 1;
+    if constexpr (Cfg::kPrec == PREC_F32) {
+      int aoff[4], boff[4];  // byte offsets inside a stage
 #pragma unroll
       for (int q = 0; q < 4; ++q) {
-        fa[buf][q] = *reinterpret_cast<const f32x4*>(st + aoff[q]);
-        fb[buf][q] = *reinterpret_cast<const f32x4*>(st + boff[q]);
+        const int c16 = wk * 8 + half * 4 + q;
+        aoff[q] = arow * ROWB + ((c16 ^ Cfg::swz(arow)) << 4);
+        boff[q] = Cfg::kPlaneABytes + brow * ROWB + ((c16 ^ Cfg::swz(brow)) << 4);
       }
-    };
-    auto tile_step = [&](auto cur_c) {
-      constexpr int cur = decltype(cur_c)::value;
-      __builtin_amdgcn_s_barrier();        // B(t+1): tile t+1 is in LDS
-      // tile t's fragments were requested a whole tile ago: retire them here (no stall), in a
-      // form the compiler's wait-count model sees, so it does not later drain the next reads
-      __builtin_amdgcn_s_waitcnt(0xC07F);  // lgkmcnt(0) only
-      read_frags(std::integral_constant<int, cur ^ 1>{});
-      __builtin_amdgcn_sched_barrier(0);
-      if (dbg != 4) {  // dbg 4: measurement ablation (no MFMAs)
+      // Fragment registers are double-buffered: the reads of tile t+1 are issued right after
+      // the barrier that makes it visible and complete underneath tile t's MFMA chain.
+      f32x4 fa[2][4], fb[2][4];
+      auto read_frags = [&](auto buf_c) {
+        constexpr int buf = decltype(buf_c)::value;
+        const char* st = lds + rstage * Cfg::kStageBytes;
+        rstage = (rstage + 1 == S) ? 0 : rstage + 1;
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
-#pragma unroll
-          for (int e = 0; e < 4; ++e)
-            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[cur][q][e], fb[cur][q][e], acc, 0, 0, 0);
+          fa[buf][q] = *reinterpret_cast<const f32x4*>(st + aoff[q]);
+          fb[buf][q] = *reinterpret_cast<const f32x4*>(st + boff[q]);
         }
+      };
+      auto tile_step = [&](auto cur_c) {
+        constexpr int cur = decltype(cur_c)::value;
+        __builtin_amdgcn_s_barrier();        // B(t+1): tile t+1 is in LDS
+        // tile t's fragments were requested a whole tile ago: retire them here (no stall), in a
+        // form the compiler's wait-count model sees, so it does not later drain the next reads
+        __builtin_amdgcn_s_waitcnt(0xC07F);  // lgkmcnt(0) only
+        read_frags(std::integral_constant<int, cur ^ 1>{});
+        __builtin_amdgcn_sched_barrier(0);
+        if (dbg != 4) {  // dbg 4: measurement ablation (no MFMAs)
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+              acc = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[cur][q][e], fb[cur][q][e], acc, 0, 0, 0);
+          }
+        }
+      };
+      __builtin_amdgcn_s_barrier();  // B0: tile 0 is in LDS
+      read_frags(std::integral_constant<int, 0>{});
+      for (int t = 0; t < nk; t += 2) {
+        tile_step(std::integral_constant<int, 0>{});
+        if (t + 1 < nk) tile_step(std::integral_constant<int, 1>{});
       }
-    };
-    __builtin_amdgcn_s_barrier();  // B0: tile 0 is in LDS
-    read_frags(std::integral_constant<int, 0>{});
-    for (int t = 0; t < nk; t += 2) {
-      tile_step(std::integral_constant<int, 0>{});
-      if (t + 1 < nk) tile_step(std::integral_constant<int, 1>{});
+    } else {
+      // split-fp16: per k16-step s one 16-byte fragment of each of A_hi, A_lo, B_hi, B_lo
+      int aoff[4], boff[4];
+#pragma unroll
+      for (int s = 0; s < 4; ++s) {
+        const int c16 = wk * 8 + s * 2 + half;
+        aoff[s] = arow * ROWB + ((c16 ^ Cfg::swz(arow)) << 4);
+        boff[s] = 2 * Cfg::kPlaneABytes + brow * ROWB + ((c16 ^ Cfg::swz(brow)) << 4);
+      }
+      f16x8 ah[2][4], al[2][4], bh[2][4], bl[2][4];
+      auto read_frags = [&](auto buf_c) {
+        constexpr int buf = decltype(buf_c)::value;
+        const char* st = lds + rstage * Cfg::kStageBytes;
+        rstage = (rstage + 1 == S) ? 0 : rstage + 1;
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+          ah[buf][s] = *reinterpret_cast<const f16x8*>(st + aoff[s]);
+          al[buf][s] = *reinterpret_cast<const f16x8*>(st + Cfg::kPlaneABytes + aoff[s]);
+          bh[buf][s] = *reinterpret_cast<const f16x8*>(st + boff[s]);
+          bl[buf][s] = *reinterpret_cast<const f16x8*>(st + Cfg::kPlaneBBytes + boff[s]);
+        }
+      };
+      auto tile_step = [&](auto cur_c) {
+        constexpr int cur = decltype(cur_c)::value;
+        __builtin_amdgcn_s_barrier();
+        __builtin_amdgcn_s_waitcnt(0xC07F);  // lgkmcnt(0) only (see the fp32 path)
+        read_frags(std::integral_constant<int, cur ^ 1>{});
+        __builtin_amdgcn_sched_barrier(0);
+        if (dbg != 4) {
+#pragma unroll
+          for (int s = 0; s < 4; ++s) {
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[cur][s], bh[cur][s], acc, 0, 0, 0);
+            acc2 = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[cur][s], bl[cur][s], acc2, 0, 0, 0);
+            acc2 = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[cur][s], bh[cur][s], acc2, 0, 0, 0);
+          }
+        }
+      };
+      __builtin_amdgcn_s_barrier();
+      read_frags(std::integral_constant<int, 0>{});
+      for (int t = 0; t < nk; t += 2) {
+        tile_step(std::integral_constant<int, 0>{});
+        if (t + 1 < nk) tile_step(std::integral_constant<int, 1>{});
+      }
+#pragma unroll
+      for (int i = 0; i < 16; ++i) acc[i] = fmaf(acc2[i], 1.0f / kSplitScale, acc[i]);
     }
   }
   __syncthreads();

@@ -25,6 +25,8 @@ struct GemmArgs {
   const float* resid;  // EPI_RESIDUAL: out = resid[m, n] + acc
   float* out;          // [M, ldo]
   int ldo;
+  f16* out_h;          // optional split-fp16 planes of `out` (same shape), or nullptr
+  f16* out_l;
   // EPI_RELU_DROPOUT
   int dropout_mode;
   const uint8_t* masks;  // [M, N] keep-mask of this (step, layer)
@@ -51,8 +53,11 @@ void launch_gemm(const GemmArgs& a, AKind ak, EpiKind ek, hipStream_t st);
 
 // ---- LSTM zoneout cell: gates GEMM + cell update fused ----
 struct LstmArgs {
-  Seg3 a;  // [x | ctx | h_prev] segments, M rows
+  Seg3 a;  // [x | ctx | h_prev] segments, M rows (fp32; or the fp16 hi planes when prec = 1)
   Seg3 w;  // matching segments of [W_ih | W_hh], rows = 4*H in PyTorch gate order i,f,g,o
+  Seg3 a_lo, w_lo;  // fp16 lo planes (prec = 1 only)
+  int prec;         // 0 = exact fp32 MFMA, 1 = split-fp16 MFMA
+  f16 *h_out_h, *h_out_l;  // optional split planes of h_out
   const float* bsum;    // [4H] = b_ih + b_hh
   const float* h_prev;  // [M, H]
   float* c;             // [M, H] updated in place
@@ -73,6 +78,7 @@ struct AttnArgs {
   float* w_new;         // [B, L]
   float* w_out;         // [B, t_stride, L] (row t_rel) or nullptr
   float* ctx;           // [B, D]
+  f16 *ctx_h, *ctx_l;   // optional split-fp16 planes of ctx
   int B, L, D, t_rel, t_stride;
   Ctrl* ctrl;
   int t;
@@ -87,6 +93,7 @@ struct InitArgs {
   float* ctx;                                      // [B, D]
   float* w;                                        // [B, L]
   float* ynext;                                    // [B, d_mel]
+  f16 *h_att_h, *h_att_l, *h_dec_h, *h_dec_l, *ctx_h, *ctx_l;  // split planes of the initial state
   int B, L, D, Ha, Hd, d_mel;
 };
 void launch_init(const InitArgs& a, hipStream_t st);
@@ -95,6 +102,7 @@ void launch_finish(Ctrl* ctrl, int t_end, int32_t* T_out, hipStream_t st);
 // ---- weight packing ----
 void launch_add_vec(const float* a, const float* b, float* out, int n, hipStream_t st);
 void launch_copy(const float* src, float* dst, size_t n, hipStream_t st);
+void launch_split(const float* src, f16* hi, f16* lo, size_t n, hipStream_t st);
 void launch_conv_transpose(const float* w /*[Co,Ci,k]*/, float* out /*[Co,k,Ci]*/, int Co, int Ci, int k, hipStream_t st);
 void launch_bn_fold(const float* gamma, const float* betap, const float* mean, const float* var, float eps, float* alpha,
                     float* beta, int n, hipStream_t st);

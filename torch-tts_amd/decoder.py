@@ -33,6 +33,8 @@ class Decoder(nn.Module):
         #   "off":           no dropout (not what the reference does)
         self.dropout_source = "reference_rng"
         self.dropout_seed = 0
+        # Arithmetic of the LSTM gate GEMMs: "f32" (exact) or "split_f16" (see include/ttsdec.h)
+        self.precision = "f32"
         self.chunk_steps = 256      # steps per launch batch when max_steps == 0 (unbounded decode)
         self.max_decoder_steps = 0  # optional hard cap for unbounded decode (0 = none, like the reference)
         self._engines = EngineCache()
@@ -46,6 +48,7 @@ class Decoder(nn.Module):
         """The packed-weights engine for `device` (repacks if parameters changed)."""
         eng = self._engines.get(self.decoder_cell.engine_dims(), device)
         eng.ensure_packed(self.weight_tensors())
+        eng.set_precision(self.precision)
         return eng
 
     def forward(self, memory, mmask, x=None, max_steps: int = 0, p_no_forcing: float = None):

@@ -103,6 +103,15 @@ class Engine:
     def postnet_workspace_bytes(self, B: int, T: int) -> int:
         return self._lib.ttsdec_postnet_workspace_bytes(self._h, B, T)
 
+    # ---- arithmetic of the LSTM gate GEMMs ----
+    def set_precision(self, mode: str) -> None:
+        """"f32" (exact fp32 matrix instruction) or "split_f16" (hi/lo fp16 planes, 3 products)."""
+        code = {"f32": _lib.PREC_F32, "split_f16": _lib.PREC_SPLIT_F16}[mode]
+        _lib.check(self._lib.ttsdec_set_precision(self._h, code), "ttsdec_set_precision")
+
+    def precision(self) -> str:
+        return {_lib.PREC_F32: "f32", _lib.PREC_SPLIT_F16: "split_f16"}[self._lib.ttsdec_get_precision(self._h)]
+
     # ---- weights ----
     def pack(self, tensors: Sequence[Optional[Tensor]]) -> Tensor:
         """tensors: in TTSDEC_W_* order (None = not owned by the calling module)."""
