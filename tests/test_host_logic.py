@@ -194,3 +194,37 @@ def test_lengths_to_mask_and_build_tacotron_surface():
     cfg["model"]["decoder"]["type"] = "tacotron2"
     with pytest.raises(NotImplementedError):
         T.build_tacotron(cfg)
+
+
+@pytest.mark.skipif(not os.path.isdir("/root/reference/tacotron"), reason="reference checkout not present (GPU box)")
+def test_integration_recipe_drops_in_under_the_reference_tacotron_py():
+    """alias the three hot-path classes in the reference's own modules and
+    let the reference's build_tacotron assemble the model - run in a subprocess so the reference's
+    top-level module names (decoder, modules, ...) do not leak into this test session."""
+    import subprocess
+    import sys
+
+    code = r'''
+import sys, yaml
+sys.dont_write_bytecode = True
+sys.path.insert(0, %r)
+import torch_tts_amd as T
+sys.path.insert(0, "/root/reference/tacotron")
+import decoder_cell, decoder
+import modules.modules as ref_modules
+ref_keys = None
+import tacotron as ref_tacotron
+cfg = yaml.safe_load(open("/root/reference/configs/config-ljspeech.yaml"))
+ref_keys = set(ref_tacotron.build_tacotron(cfg).state_dict().keys())
+ref_tacotron.Taco2ProdDecoderCell = decoder_cell.Taco2ProdDecoderCell = T.Taco2ProdDecoderCell
+ref_tacotron.Decoder = decoder.Decoder = T.Decoder
+ref_tacotron.MelPostnet = ref_modules.MelPostnet = T.MelPostnet
+model = ref_tacotron.build_tacotron(cfg)
+assert isinstance(model.decoder, T.Decoder) and isinstance(model.decoder.decoder_cell, T.Taco2ProdDecoderCell)
+assert isinstance(model.postnet, T.MelPostnet)
+assert set(model.state_dict().keys()) == ref_keys, set(model.state_dict().keys()) ^ ref_keys
+print("OK", len(ref_keys))
+''' % ROOT
+    env = dict(os.environ, PYTHONDONTWRITEBYTECODE="1")
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, env=env, timeout=300)
+    assert r.returncode == 0 and r.stdout.startswith("OK"), r.stdout + r.stderr
