@@ -158,7 +158,7 @@ size_t ttsdec_workspace_bytes(const ttsdec_handle* h, int B, int L);
  * mel/stop projection (tacotron/decoder_cell.py:180-195).
  *
  *   memory        [B, L, d_ctx] encoder outputs (zero on padded rows)
- *   t_begin       global index of the first step of this call; 0 (re)initialises
+ *   t_begin       global index of the first step of this call (must be even); 0 (re)initialises
  *                 the recurrent state from the initial_decoder_{h,c} parameters
  *                 (decoder_cell.py:165-178) and the GO frame (decoder.py:35)
  *   n_steps       steps to run at most in this call

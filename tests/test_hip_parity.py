@@ -122,7 +122,7 @@ def test_golden_unbounded_decode_chunks(golden, H):
     """max_steps=0 decodes in chunks until the stop rule fires; chunking must not change results."""
     c, m = golden["cases"], golden["meta"]["stop"]
     dec = H.make_decoder(_small_dims(golden), golden["dec"], stop_threshold=m["threshold"])
-    dec.chunk_steps = 3  # forces several ttsdec_decode calls with state carried in the workspace
+    dec.chunk_steps = 3  # (rounded up to 4) forces several ttsdec_decode calls with state carried in the workspace
     with torch.no_grad():
         torch.manual_seed(m["seed"])
         y, s, w = dec(golden["memory"].cuda(), None, None, 0)

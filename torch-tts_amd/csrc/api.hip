@@ -32,10 +32,14 @@ struct BlobLayout {  // offsets in floats
 struct WsLayout {  // offsets in bytes
   size_t ctrl, xpre0, xpre, ctx, h_att[2], c_att, h_dec[2], c_dec, q, ynext, w[2];
   size_t xpre_h, xpre_l, ctx_h, ctx_l, h_att_h[2], h_att_l[2], h_dec_h[2], h_dec_l[2];  // split-fp16 planes
+  size_t gates_att, gates_dec;  // early partial gate sums [B, 4H]
   size_t total;
 };
 
 }  // namespace
+
+constexpr int kGraphSlots = 30;  // decode steps per captured graph (even: buffer parity is baked per slot)
+constexpr int kEventsPerSlot = 4;
 
 struct ttsdec_handle {
   ttsdec_dims d;
@@ -44,6 +48,18 @@ struct ttsdec_handle {
   BlobLayout bl;
   const float* blob;
   std::string hip_err;
+  // multi-stream step loop
+  bool overlap;     // early partial-gate GEMMs on a side stream
+  bool use_graph;   // replay a captured hipGraph instead of launching every kernel
+  hipStream_t cap_stream, side_stream;
+  hipEvent_t ev[kGraphSlots * kEventsPerSlot + 2];
+  bool streams_ready;
+  // one cached graph: valid for exactly this (workspace, blob, B, L, precision, overlap)
+  hipGraphExec_t gexec;
+  hipGraph_t graph;
+  const void* g_ws;
+  const void* g_blob;
+  int g_B, g_L, g_prec, g_overlap;
 };
 
 namespace {
@@ -123,6 +139,8 @@ WsLayout make_ws_layout(const ttsdec_dims& d, int B, int Lm) {
     W.h_att_h[i] = takeh(b * d.h_att); W.h_att_l[i] = takeh(b * d.h_att);
     W.h_dec_h[i] = takeh(b * d.h_dec); W.h_dec_l[i] = takeh(b * d.h_dec);
   }
+  W.gates_att = take(b * 4 * d.h_att);
+  W.gates_dec = take(b * 4 * d.h_dec);
   W.total = off;
   return W;
 }
@@ -170,6 +188,7 @@ struct StepBufs {
   Ctrl* ctrl;
   float *xpre0, *xpre, *ctx, *h_att[2], *c_att, *h_dec[2], *c_dec, *q, *ynext, *w[2];
   f16 *xpre_h, *xpre_l, *ctx_h, *ctx_l, *h_att_h[2], *h_att_l[2], *h_dec_h[2], *h_dec_l[2];
+  float *gates_att, *gates_dec;
 };
 
 StepBufs carve(const WsLayout& W, void* ws) {
@@ -187,57 +206,60 @@ StepBufs carve(const WsLayout& W, void* ws) {
     s.h_att_h[i] = hf(W.h_att_h[i]); s.h_att_l[i] = hf(W.h_att_l[i]);
     s.h_dec_h[i] = hf(W.h_dec_h[i]); s.h_dec_l[i] = hf(W.h_dec_l[i]);
   }
+  s.gates_att = f(W.gates_att); s.gates_dec = f(W.gates_dec);
   return s;
 }
 
+// How one step's kernels find "now": inside ttsdec_decode everything per-call lives in the
+// device control block and a kernel only gets its slot (use_ctrl); cell_step / profiling pass
+// explicit values.
 struct StepIo {
   const float* memory;
   int B, L;
-  int t, t_rel, t_stride;
-  float stop_thr;
-  int check_stop;
+  int slot;               // use_ctrl: step = ctrl->t_cur + slot; buffer parity = slot & 1 (t_cur is even)
+  int t, t_rel, t_stride;  // !use_ctrl
   int dropout_mode;
-  const uint8_t* masks;  // base of this call's [n_steps, 2, B, d_pre]
+  const uint8_t* masks;  // !use_ctrl: [2, B, d_pre] of this step
   uint64_t seed;
-  const float* teacher;
-  int teacher_T;
-  const uint8_t* teacher_flags;
   float *y, *s, *w;
   bool use_ctrl;
   int dbg;
 };
 
+// The kernels of one decode step.  A1/D1 are the early partial-gate GEMMs of the two LSTMs
+// (the K segments that do not wait for the kernel just before them), A2/D2 the finishing
+// parts; A/D are the unsplit cells.
+enum Node { N_P0, N_P1, N_A, N_A1, N_A2, N_Q, N_T, N_D, N_D1, N_D2, N_J };
+
+constexpr int kKernelsPerStep = 7;
+const char* const kKernelNames[kKernelsPerStep] = {"prenet0", "prenet1", "lstm_att", "query", "attention", "lstm_dec", "proj"};
+const Node kProfileNodes[kKernelsPerStep] = {N_P0, N_P1, N_A, N_Q, N_T, N_D, N_J};
+
 // split-fp16 needs every K segment to be whole 16-byte columns of fp16 (multiples of 8)
 bool split_ok(const ttsdec_dims& d) { return !((d.d_pre | d.d_ctx | d.h_att | d.h_dec) & 7); }
 int lstm_prec(const ttsdec_handle* h) { return (h->precision == TTSDEC_PREC_SPLIT_F16 && split_ok(h->d)) ? 1 : 0; }
 
-constexpr int kKernelsPerStep = 7;
-const char* const kKernelNames[kKernelsPerStep] = {"prenet0", "prenet1", "lstm_att", "query", "attention", "lstm_dec", "proj"};
-
-// Launches kernel `which` (0..6) of decode step io.t; which < 0 launches the whole step.
-void launch_step(const ttsdec_handle* h, const StepBufs& sb, const StepIo& io, int which, hipStream_t st) {
+void launch_node(const ttsdec_handle* h, const StepBufs& sb, const StepIo& io, Node node, hipStream_t st) {
   const ttsdec_dims& d = h->d;
   const BlobLayout& bl = h->bl;
   const float* blob = h->blob;
-  const int p = io.t & 1;
+  const int p = (io.use_ctrl ? io.slot : io.t) & 1;
   Ctrl* ctrl = io.use_ctrl ? sb.ctrl : nullptr;
   const int B = io.B, P = d.d_pre, D = d.d_ctx, Ha = d.h_att, Hd = d.h_dec;
   const float keep_scale = 1.0f / (1.0f - d.p_dropout);
   const int prec = lstm_prec(h);
-  const f16* bh = reinterpret_cast<const f16*>(blob);  // fp16 planes live at float offsets of the same blob
   auto plane = [&](size_t float_off) { return reinterpret_cast<const f16*>(blob + float_off); };
-  (void)bh;
 
-  if (which < 0 || which == 0 || which == 1) {
-    for (int layer = 0; layer < 2; ++layer) {
-      if (which >= 0 && which != layer) continue;
+  switch (node) {
+    case N_P0:
+    case N_P1: {
+      const int layer = node == N_P0 ? 0 : 1;
       GemmArgs g;
       memset(&g, 0, sizeof(g));
       if (layer == 0) {
         g.a = make_seg1(sb.ynext, d.d_mel, d.d_mel);
         g.W = blob + bl.pre0_w; g.ldw = d.d_mel; g.K = d.d_mel; g.bias = blob + bl.pre0_b;
         g.out = sb.xpre0;
-        g.teacher = io.teacher; g.teacher_T = io.teacher_T; g.teacher_flags = io.teacher_flags;
       } else {
         g.a = make_seg1(sb.xpre0, P, P);
         g.W = blob + bl.pre1_w; g.ldw = P; g.K = P; g.bias = blob + bl.pre1_b;
@@ -246,78 +268,220 @@ void launch_step(const ttsdec_handle* h, const StepBufs& sb, const StepIo& io, i
       }
       g.M = B; g.N = P; g.ldo = P;
       g.dropout_mode = io.dropout_mode;
-      g.masks = io.masks ? io.masks + ((size_t)io.t_rel * 2 + layer) * B * P : nullptr;
+      g.masks = io.masks ? io.masks + (size_t)layer * B * P : nullptr;
       g.seed = io.seed; g.layer = layer; g.keep_scale = keep_scale;
       g.r = d.r; g.d_mel = d.d_mel;
-      g.ctrl = ctrl; g.t = io.t;
+      g.ctrl = ctrl; g.slot = io.slot; g.t = io.t;
       launch_gemm(g, A_PLAIN, EPI_RELU_DROPOUT, st);
+      break;
+    }
+    case N_A:
+    case N_A1:
+    case N_A2: {
+      // attention LSTM: input cat[x_pre, ctx_prev] (decoder_cell.py:187), state h_att
+      LstmArgs a;
+      memset(&a, 0, sizeof(a));
+      a.prec = prec;
+      a.mode = node == N_A ? 0 : (node == N_A1 ? 1 : 2);
+      a.partial = sb.gates_att;
+      const int wld = P + D;
+      // segment lists: whole = [x_pre | ctx | h], early = [ctx | h], late = [x_pre]
+      const void *x0 = prec ? (const void*)sb.xpre_h : sb.xpre, *x0l = prec ? (const void*)sb.xpre_l : sb.xpre;
+      const void *x1 = prec ? (const void*)sb.ctx_h : sb.ctx, *x1l = prec ? (const void*)sb.ctx_l : sb.ctx;
+      const void *x2 = prec ? (const void*)sb.h_att_h[p] : sb.h_att[p], *x2l = prec ? (const void*)sb.h_att_l[p] : sb.h_att[p];
+      const f16 *wih_h = plane(bl.att_ih_h), *wih_l = plane(bl.att_ih_l), *whh_h = plane(bl.att_hh_h), *whh_l = plane(bl.att_hh_l);
+      const float *wih = blob + bl.att_ih, *whh = blob + bl.att_hh;
+      auto W0 = [&](bool lo) { return prec ? (const void*)(lo ? wih_l : wih_h) : (const void*)wih; };
+      auto W1 = [&](bool lo) { return prec ? (const void*)((lo ? wih_l : wih_h) + P) : (const void*)(wih + P); };
+      auto W2 = [&](bool lo) { return prec ? (const void*)(lo ? whh_l : whh_h) : (const void*)whh; };
+      if (a.mode == 0) {
+        a.a = make_seg3(x0, P, P, x1, D, D, x2, Ha, Ha); a.a_lo = make_seg3(x0l, P, P, x1l, D, D, x2l, Ha, Ha);
+        a.w = make_seg3(W0(false), wld, P, W1(false), wld, D, W2(false), Ha, Ha);
+        a.w_lo = make_seg3(W0(true), wld, P, W1(true), wld, D, W2(true), Ha, Ha);
+      } else if (a.mode == 1) {
+        a.a = make_seg2(x1, D, D, x2, Ha, Ha); a.a_lo = make_seg2(x1l, D, D, x2l, Ha, Ha);
+        a.w = make_seg2(W1(false), wld, D, W2(false), Ha, Ha); a.w_lo = make_seg2(W1(true), wld, D, W2(true), Ha, Ha);
+      } else {
+        a.a = make_seg1(x0, P, P); a.a_lo = make_seg1(x0l, P, P);
+        a.w = make_seg1(W0(false), wld, P); a.w_lo = make_seg1(W0(true), wld, P);
+      }
+      if (prec) { a.h_out_h = sb.h_att_h[1 - p]; a.h_out_l = sb.h_att_l[1 - p]; }
+      a.bsum = blob + bl.att_b; a.h_prev = sb.h_att[p]; a.c = sb.c_att; a.h_out = sb.h_att[1 - p];
+      a.M = B; a.H = Ha; a.K = P + D + Ha; a.pz = d.p_zoneout; a.ctrl = ctrl; a.slot = io.slot; a.dbg = io.dbg;
+      launch_lstm(a, st);
+      break;
+    }
+    case N_Q: {
+      GemmArgs g;
+      memset(&g, 0, sizeof(g));
+      g.a = make_seg1(sb.h_att[1 - p], Ha, Ha);
+      g.W = blob + bl.wq; g.ldw = Ha; g.K = Ha; g.M = B; g.N = D; g.out = sb.q; g.ldo = D;
+      g.ctrl = ctrl; g.slot = io.slot; g.t = io.t;
+      launch_gemm(g, A_PLAIN, EPI_PLAIN, st);
+      break;
+    }
+    case N_T: {
+      AttnArgs a;
+      memset(&a, 0, sizeof(a));
+      if (prec) { a.ctx_h = sb.ctx_h; a.ctx_l = sb.ctx_l; }
+      a.memory = io.memory; a.q = sb.q; a.w_prev = sb.w[p]; a.w_new = sb.w[1 - p]; a.w_out = io.w; a.ctx = sb.ctx;
+      a.B = B; a.L = io.L; a.D = D; a.t_rel = io.t_rel; a.t_stride = io.t_stride; a.ctrl = ctrl; a.slot = io.slot;
+      launch_attn(a, st);
+      break;
+    }
+    case N_D:
+    case N_D1:
+    case N_D2: {
+      // decoder LSTM: input cat[h_att, ctx] (decoder_cell.py:191), state h_dec
+      LstmArgs a;
+      memset(&a, 0, sizeof(a));
+      a.prec = prec;
+      a.mode = node == N_D ? 0 : (node == N_D1 ? 1 : 2);
+      a.partial = sb.gates_dec;
+      const int wld = Ha + D;
+      const void *x0 = prec ? (const void*)sb.h_att_h[1 - p] : sb.h_att[1 - p], *x0l = prec ? (const void*)sb.h_att_l[1 - p] : sb.h_att[1 - p];
+      const void *x1 = prec ? (const void*)sb.ctx_h : sb.ctx, *x1l = prec ? (const void*)sb.ctx_l : sb.ctx;
+      const void *x2 = prec ? (const void*)sb.h_dec_h[p] : sb.h_dec[p], *x2l = prec ? (const void*)sb.h_dec_l[p] : sb.h_dec[p];
+      const f16 *wih_h = plane(bl.dec_ih_h), *wih_l = plane(bl.dec_ih_l), *whh_h = plane(bl.dec_hh_h), *whh_l = plane(bl.dec_hh_l);
+      const float *wih = blob + bl.dec_ih, *whh = blob + bl.dec_hh;
+      auto W0 = [&](bool lo) { return prec ? (const void*)(lo ? wih_l : wih_h) : (const void*)wih; };
+      auto W1 = [&](bool lo) { return prec ? (const void*)((lo ? wih_l : wih_h) + Ha) : (const void*)(wih + Ha); };
+      auto W2 = [&](bool lo) { return prec ? (const void*)(lo ? whh_l : whh_h) : (const void*)whh; };
+      if (a.mode == 0) {
+        a.a = make_seg3(x0, Ha, Ha, x1, D, D, x2, Hd, Hd); a.a_lo = make_seg3(x0l, Ha, Ha, x1l, D, D, x2l, Hd, Hd);
+        a.w = make_seg3(W0(false), wld, Ha, W1(false), wld, D, W2(false), Hd, Hd);
+        a.w_lo = make_seg3(W0(true), wld, Ha, W1(true), wld, D, W2(true), Hd, Hd);
+      } else if (a.mode == 1) {  // early: [h_att | h_dec_prev]
+        a.a = make_seg2(x0, Ha, Ha, x2, Hd, Hd); a.a_lo = make_seg2(x0l, Ha, Ha, x2l, Hd, Hd);
+        a.w = make_seg2(W0(false), wld, Ha, W2(false), Hd, Hd); a.w_lo = make_seg2(W0(true), wld, Ha, W2(true), Hd, Hd);
+      } else {  // late: [ctx]
+        a.a = make_seg1(x1, D, D); a.a_lo = make_seg1(x1l, D, D);
+        a.w = make_seg1(W1(false), wld, D); a.w_lo = make_seg1(W1(true), wld, D);
+      }
+      if (prec) { a.h_out_h = sb.h_dec_h[1 - p]; a.h_out_l = sb.h_dec_l[1 - p]; }
+      a.bsum = blob + bl.dec_b; a.h_prev = sb.h_dec[p]; a.c = sb.c_dec; a.h_out = sb.h_dec[1 - p];
+      a.M = B; a.H = Hd; a.K = Ha + D + Hd; a.pz = d.p_zoneout; a.ctrl = ctrl; a.slot = io.slot; a.dbg = io.dbg;
+      launch_lstm(a, st);
+      break;
+    }
+    case N_J: {
+      GemmArgs g;
+      memset(&g, 0, sizeof(g));
+      g.a = make_seg2(sb.h_dec[1 - p], Hd, Hd, sb.ctx, D, D);
+      g.W = blob + bl.proj_w; g.ldw = Hd + D; g.K = Hd + D; g.M = B; g.N = d.r * d.d_mel + d.r;
+      g.bias = blob + bl.proj_b;
+      g.y_out = io.y; g.s_out = io.s; g.ynext = sb.ynext; g.r = d.r; g.d_mel = d.d_mel;
+      g.t_rel = io.t_rel; g.t_stride = io.t_stride; g.stop_thr = 0.f; g.check_stop = 0;
+      g.ctrl = ctrl; g.slot = io.slot; g.t = io.t;
+      launch_gemm(g, A_PLAIN, EPI_PROJ, st);
+      break;
     }
   }
-  if (which < 0 || which == 2) {
-    LstmArgs a;
-    memset(&a, 0, sizeof(a));
-    a.prec = prec;
-    if (prec) {
-      a.a = make_seg3(sb.xpre_h, P, P, sb.ctx_h, D, D, sb.h_att_h[p], Ha, Ha);
-      a.a_lo = make_seg3(sb.xpre_l, P, P, sb.ctx_l, D, D, sb.h_att_l[p], Ha, Ha);
-      a.w = make_seg3(plane(bl.att_ih_h), P + D, P, plane(bl.att_ih_h) + P, P + D, D, plane(bl.att_hh_h), Ha, Ha);
-      a.w_lo = make_seg3(plane(bl.att_ih_l), P + D, P, plane(bl.att_ih_l) + P, P + D, D, plane(bl.att_hh_l), Ha, Ha);
-      a.h_out_h = sb.h_att_h[1 - p]; a.h_out_l = sb.h_att_l[1 - p];
-    } else {
-      a.a = make_seg3(sb.xpre, P, P, sb.ctx, D, D, sb.h_att[p], Ha, Ha);
-      a.w = make_seg3(blob + bl.att_ih, P + D, P, blob + bl.att_ih + P, P + D, D, blob + bl.att_hh, Ha, Ha);
-      a.a_lo = a.a; a.w_lo = a.w;
+}
+
+// One step on a single stream, in the reference's order.
+void launch_step_serial(const ttsdec_handle* h, const StepBufs& sb, const StepIo& io, hipStream_t st) {
+  const Node order[7] = {N_P0, N_P1, N_A, N_Q, N_T, N_D, N_J};
+  for (Node n : order) launch_node(h, sb, io, n, st);
+}
+
+// n_slots steps with the early partial-gate GEMMs on the side stream:
+//   main:  P0 P1 .......... A2 Q  T ........ D2 J        (critical path)
+//   side:        A1(t) .......   D1(t) .....    A1(t+1)
+// A1(t) needs ctx and h_att of step t-1 (after T(t-1)); D1(t) needs h_att of step t (after
+// A2(t)) and h_dec of step t-1.  Every cross-stream edge is an event; under stream capture
+// the same calls become graph edges.
+int launch_steps_overlapped(ttsdec_handle* h, const StepBufs& sb, StepIo io, int slot0, int n_slots, hipStream_t mainst) {
+  hipStream_t side = h->side_stream;
+  hipEvent_t* ev = h->ev;
+  bool ok = true;
+  auto rec = [&](hipEvent_t e, hipStream_t s) { ok &= (hipEventRecord(e, s) == hipSuccess); };
+  auto wait = [&](hipStream_t s, hipEvent_t e) { ok &= (hipStreamWaitEvent(s, e, 0) == hipSuccess); };
+  hipEvent_t ev_start = ev[kGraphSlots * kEventsPerSlot];
+  rec(ev_start, mainst);
+  wait(side, ev_start);
+  for (int i = 0; i < n_slots; ++i) {
+    io.slot = slot0 + i;
+    hipEvent_t* e = ev + (i % kGraphSlots) * kEventsPerSlot;  // [0] A1 done, [1] A2 done, [2] T done, [3] D1 done
+    launch_node(h, sb, io, N_A1, side);
+    rec(e[0], side);
+    launch_node(h, sb, io, N_P0, mainst);
+    launch_node(h, sb, io, N_P1, mainst);
+    wait(mainst, e[0]);
+    launch_node(h, sb, io, N_A2, mainst);
+    rec(e[1], mainst);
+    wait(side, e[1]);
+    launch_node(h, sb, io, N_D1, side);
+    rec(e[3], side);
+    launch_node(h, sb, io, N_Q, mainst);
+    launch_node(h, sb, io, N_T, mainst);
+    rec(e[2], mainst);
+    wait(side, e[2]);  // the next A1 reads this step's ctx
+    wait(mainst, e[3]);
+    launch_node(h, sb, io, N_D2, mainst);
+    launch_node(h, sb, io, N_J, mainst);
+  }
+  // join the side stream's trailing wait so a capture ends with a single leaf
+  hipEvent_t ev_end = ev[kGraphSlots * kEventsPerSlot + 1];
+  rec(ev_end, side);
+  wait(mainst, ev_end);
+  return (ok && hipGetLastError() == hipSuccess) ? TTSDEC_OK : TTSDEC_ERR_HIP;
+}
+
+int ensure_streams(ttsdec_handle* h) {
+  if (h->streams_ready) return TTSDEC_OK;
+  if (hipStreamCreateWithFlags(&h->cap_stream, hipStreamNonBlocking) != hipSuccess) return TTSDEC_ERR_HIP;
+  if (hipStreamCreateWithFlags(&h->side_stream, hipStreamNonBlocking) != hipSuccess) return TTSDEC_ERR_HIP;
+  for (auto& e : h->ev)
+    if (hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) return TTSDEC_ERR_HIP;
+  h->streams_ready = true;
+  return TTSDEC_OK;
+}
+
+void drop_graph(ttsdec_handle* h) {
+  if (h->gexec) { (void)hipGraphExecDestroy(h->gexec); h->gexec = nullptr; }
+  if (h->graph) { (void)hipGraphDestroy(h->graph); h->graph = nullptr; }
+}
+
+// Captures kGraphSlots steps (+ the t_cur advance) once per (workspace, blob, B, L, mode).
+int ensure_graph(ttsdec_handle* h, const StepBufs& sb, const void* ws, int B, int L) {
+  const int prec = lstm_prec(h);
+  if (h->gexec && h->g_ws == ws && h->g_blob == h->blob && h->g_B == B && h->g_L == L && h->g_prec == prec &&
+      h->g_overlap == (int)h->overlap)
+    return TTSDEC_OK;
+  drop_graph(h);
+  StepIo io;
+  memset(&io, 0, sizeof(io));
+  io.B = B; io.L = L; io.use_ctrl = true;
+  if (hipStreamBeginCapture(h->cap_stream, hipStreamCaptureModeRelaxed) != hipSuccess) return TTSDEC_ERR_HIP;
+  int rc = TTSDEC_OK;
+  if (h->overlap) {
+    rc = launch_steps_overlapped(h, sb, io, 0, kGraphSlots, h->cap_stream);
+  } else {
+    for (int i = 0; i < kGraphSlots; ++i) {
+      io.slot = i;
+      launch_step_serial(h, sb, io, h->cap_stream);
     }
-    a.bsum = blob + bl.att_b; a.h_prev = sb.h_att[p]; a.c = sb.c_att; a.h_out = sb.h_att[1 - p];
-    a.M = B; a.H = Ha; a.K = P + D + Ha; a.pz = d.p_zoneout; a.ctrl = ctrl; a.t = io.t; a.dbg = io.dbg;
-    launch_lstm(a, st);
   }
-  if (which < 0 || which == 3) {
-    GemmArgs g;
-    memset(&g, 0, sizeof(g));
-    g.a = make_seg1(sb.h_att[1 - p], Ha, Ha);
-    g.W = blob + bl.wq; g.ldw = Ha; g.K = Ha; g.M = B; g.N = D; g.out = sb.q; g.ldo = D;
-    g.ctrl = ctrl; g.t = io.t;
-    launch_gemm(g, A_PLAIN, EPI_PLAIN, st);
+  launch_advance(sb.ctrl, kGraphSlots, h->cap_stream);
+  hipGraph_t graph = nullptr;
+  hipError_t e = hipStreamEndCapture(h->cap_stream, &graph);
+  if (e != hipSuccess || rc != TTSDEC_OK || graph == nullptr) {
+    if (graph) (void)hipGraphDestroy(graph);
+    h->hip_err = std::string("graph capture: ") + hipGetErrorString(e);
+    (void)hipGetLastError();
+    return TTSDEC_ERR_HIP;
   }
-  if (which < 0 || which == 4) {
-    AttnArgs a;
-    memset(&a, 0, sizeof(a));
-    if (prec) { a.ctx_h = sb.ctx_h; a.ctx_l = sb.ctx_l; }
-    a.memory = io.memory; a.q = sb.q; a.w_prev = sb.w[p]; a.w_new = sb.w[1 - p]; a.w_out = io.w; a.ctx = sb.ctx;
-    a.B = B; a.L = io.L; a.D = D; a.t_rel = io.t_rel; a.t_stride = io.t_stride; a.ctrl = ctrl; a.t = io.t;
-    launch_attn(a, st);
+  hipGraphExec_t exec = nullptr;
+  e = hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0);
+  if (e != hipSuccess) {
+    (void)hipGraphDestroy(graph);
+    h->hip_err = std::string("hipGraphInstantiate: ") + hipGetErrorString(e);
+    return TTSDEC_ERR_HIP;
   }
-  if (which < 0 || which == 5) {
-    LstmArgs a;
-    memset(&a, 0, sizeof(a));
-    a.prec = prec;
-    if (prec) {
-      a.a = make_seg3(sb.h_att_h[1 - p], Ha, Ha, sb.ctx_h, D, D, sb.h_dec_h[p], Hd, Hd);
-      a.a_lo = make_seg3(sb.h_att_l[1 - p], Ha, Ha, sb.ctx_l, D, D, sb.h_dec_l[p], Hd, Hd);
-      a.w = make_seg3(plane(bl.dec_ih_h), Ha + D, Ha, plane(bl.dec_ih_h) + Ha, Ha + D, D, plane(bl.dec_hh_h), Hd, Hd);
-      a.w_lo = make_seg3(plane(bl.dec_ih_l), Ha + D, Ha, plane(bl.dec_ih_l) + Ha, Ha + D, D, plane(bl.dec_hh_l), Hd, Hd);
-      a.h_out_h = sb.h_dec_h[1 - p]; a.h_out_l = sb.h_dec_l[1 - p];
-    } else {
-      a.a = make_seg3(sb.h_att[1 - p], Ha, Ha, sb.ctx, D, D, sb.h_dec[p], Hd, Hd);
-      a.w = make_seg3(blob + bl.dec_ih, Ha + D, Ha, blob + bl.dec_ih + Ha, Ha + D, D, blob + bl.dec_hh, Hd, Hd);
-      a.a_lo = a.a; a.w_lo = a.w;
-    }
-    a.bsum = blob + bl.dec_b; a.h_prev = sb.h_dec[p]; a.c = sb.c_dec; a.h_out = sb.h_dec[1 - p];
-    a.M = B; a.H = Hd; a.K = Ha + D + Hd; a.pz = d.p_zoneout; a.ctrl = ctrl; a.t = io.t; a.dbg = io.dbg;
-    launch_lstm(a, st);
-  }
-  if (which < 0 || which == 6) {
-    GemmArgs g;
-    memset(&g, 0, sizeof(g));
-    g.a = make_seg2(sb.h_dec[1 - p], Hd, Hd, sb.ctx, D, D);
-    g.W = blob + bl.proj_w; g.ldw = Hd + D; g.K = Hd + D; g.M = B; g.N = d.r * d.d_mel + d.r;
-    g.bias = blob + bl.proj_b;
-    g.y_out = io.y; g.s_out = io.s; g.ynext = sb.ynext; g.r = d.r; g.d_mel = d.d_mel;
-    g.t_rel = io.t_rel; g.t_stride = io.t_stride; g.stop_thr = io.stop_thr; g.check_stop = io.check_stop && io.use_ctrl;
-    g.ctrl = ctrl; g.t = io.t;
-    launch_gemm(g, A_PLAIN, EPI_PROJ, st);
-  }
+  h->graph = graph; h->gexec = exec;
+  h->g_ws = ws; h->g_blob = h->blob; h->g_B = B; h->g_L = L; h->g_prec = prec; h->g_overlap = (int)h->overlap;
+  return TTSDEC_OK;
 }
 
 }  // namespace
@@ -352,6 +516,18 @@ int ttsdec_create(const ttsdec_dims* dims, ttsdec_handle** out) {
   h->precision = TTSDEC_PREC_F32;
   h->bl = make_blob_layout(*dims);
   h->blob = nullptr;
+  h->streams_ready = false;
+  h->gexec = nullptr;
+  h->graph = nullptr;
+  h->g_ws = h->g_blob = nullptr;
+  // Measurement switches.  The two-stream schedule (early partial-gate GEMMs beside the small
+  // critical-path kernels) measured SLOWER on MI355X (126 vs 96 us per step at B=256: the early
+  // GEMM's 256 workgroups hold every CU's LDS, so the small kernels queue behind them), so it
+  // is opt-in; graph replay is on.
+  const char* e1 = getenv("TTSDEC_OVERLAP");
+  const char* e2 = getenv("TTSDEC_NO_GRAPH");
+  h->overlap = (e1 && atoi(e1));
+  h->use_graph = !(e2 && atoi(e2));
   int ndev = 0, dev = -1;
   if (hipGetDeviceCount(&ndev) == hipSuccess && ndev > 0 && hipGetDevice(&dev) == hipSuccess) {
     h->device = dev;
@@ -364,6 +540,13 @@ int ttsdec_create(const ttsdec_dims* dims, ttsdec_handle** out) {
 }
 
 int ttsdec_destroy(ttsdec_handle* h) {
+  if (!h) return TTSDEC_OK;
+  drop_graph(h);
+  if (h->streams_ready) {
+    for (auto& e : h->ev) (void)hipEventDestroy(e);
+    (void)hipStreamDestroy(h->cap_stream);
+    (void)hipStreamDestroy(h->side_stream);
+  }
   delete h;
   return TTSDEC_OK;
 }
@@ -474,6 +657,10 @@ int ttsdec_decode(ttsdec_handle* h, const float* memory, int B, int L, int t_beg
   const StepBufs sb = carve(W, workspace);
   const ttsdec_dims& d = h->d;
 
+  if (t_begin & 1) return TTSDEC_ERR_INVALID_ARG;  // buffer parity is tied to the step index
+  rc = ensure_streams(h);
+  if (rc != TTSDEC_OK) return rc;
+
   if (t_begin == 0) {
     InitArgs ia;
     ia.ctrl = sb.ctrl;
@@ -486,18 +673,30 @@ int ttsdec_decode(ttsdec_handle* h, const float* memory, int B, int L, int t_beg
     ia.B = B; ia.L = L; ia.D = d.d_ctx; ia.Ha = d.h_att; ia.Hd = d.h_dec; ia.d_mel = d.d_mel;
     launch_init(ia, st);
   }
+  CallArgs ca;
+  ca.t_begin = t_begin; ca.n_steps = n_steps; ca.t_stride = t_stride; ca.check_stop = check_stop;
+  ca.dropout_mode = dropout_mode; ca.teacher_T = teacher_T; ca.stop_thr = stop_threshold; ca.seed = seed;
+  ca.memory = memory; ca.masks = masks; ca.teacher = teacher; ca.teacher_flags = teacher_flags;
+  ca.y = y; ca.s = s; ca.w = w;
+  launch_set_call(sb.ctrl, ca, st);
+
   StepIo io;
-  io.memory = memory; io.B = B; io.L = L; io.t_stride = t_stride;
-  io.stop_thr = stop_threshold; io.check_stop = check_stop;
-  io.dropout_mode = dropout_mode; io.masks = masks; io.seed = seed;
-  io.teacher = teacher; io.teacher_T = teacher_T; io.teacher_flags = teacher_flags;
-  io.y = y; io.s = s; io.w = w; io.use_ctrl = true; io.dbg = 0;
-  for (int i = 0; i < n_steps; ++i) {
-    io.t = t_begin + i;
-    io.t_rel = i;
-    launch_step(h, sb, io, -1, st);
+  memset(&io, 0, sizeof(io));
+  io.B = B; io.L = L; io.use_ctrl = true;
+  if (h->use_graph && n_steps >= kGraphSlots / 2) {
+    rc = ensure_graph(h, sb, workspace, B, L);
+    if (rc != TTSDEC_OK) return rc;
+    for (int done = 0; done < n_steps; done += kGraphSlots) HIP_TRY(h, hipGraphLaunch(h->gexec, st));
+  } else if (h->overlap) {
+    rc = launch_steps_overlapped(h, sb, io, 0, n_steps, st);
+    if (rc != TTSDEC_OK) return hip_fail(h, hipGetLastError(), "decode (overlapped)");
+  } else {
+    for (int i = 0; i < n_steps; ++i) {
+      io.slot = i;
+      launch_step_serial(h, sb, io, st);
+    }
   }
-  launch_finish(sb.ctrl, t_begin + n_steps, T_out, st);
+  launch_finish(sb.ctrl, T_out, st);
   return check_launch(h, "decode");
 }
 
@@ -578,9 +777,10 @@ int ttsdec_cell_step(ttsdec_handle* h, const float* x, const float* memory, int 
   memset(&io, 0, sizeof(io));
   io.memory = memory; io.B = B; io.L = L; io.t = step; io.t_rel = 0; io.t_stride = 1;
   io.dropout_mode = dropout_mode; io.masks = masks; io.seed = seed;
-  // y/s of the projection are not part of the cell: park them in x_dec's tail? no - run steps 0..5 only
   io.use_ctrl = false;
-  for (int k = 0; k < 6; ++k) launch_step(h, sb, io, k, st);
+  // the projection (fc_mel / fc_stop) belongs to Decoder, not to the cell
+  const Node cell_nodes[6] = {N_P0, N_P1, N_A, N_Q, N_T, N_D};
+  for (Node n : cell_nodes) launch_node(h, sb, io, n, st);
   launch_copy(sb.ctx, ctx, b * d.d_ctx, st);
   launch_copy(sb.w[1 - p], w, b * L, st);
   launch_copy(sb.h_att[1 - p], h_att, b * d.h_att, st);
@@ -620,9 +820,9 @@ int ttsdec_profile_step(ttsdec_handle* h, const float* memory, int B, int L, int
   HIP_TRY(h, hipEventCreate(&e0));
   HIP_TRY(h, hipEventCreate(&e1));
   for (int k = 0; k < kKernelsPerStep; ++k) {
-    for (int i = 0; i < 3; ++i) launch_step(h, sb, io, k, st);  // warm
+    for (int i = 0; i < 3; ++i) launch_node(h, sb, io, kProfileNodes[k], st);  // warm
     HIP_TRY(h, hipEventRecord(e0, st));
-    for (int i = 0; i < iters; ++i) launch_step(h, sb, io, k, st);
+    for (int i = 0; i < iters; ++i) launch_node(h, sb, io, kProfileNodes[k], st);
     HIP_TRY(h, hipEventRecord(e1, st));
     HIP_TRY(h, hipEventSynchronize(e1));
     float ms = 0.f;

@@ -16,13 +16,41 @@ constexpr int kGemmThreads = 512;  // 4 MFMA waves + 4 loader waves
 constexpr int kAttnThreads = 512;
 constexpr int kStopNever = 0x7fffffff;
 
-// Control words living at the head of the decoder workspace.  Written by kernels
-// only (initialised by init_state_kernel), read by every step kernel.
+// Control block at the head of the decoder workspace.  Everything that changes from one
+// ttsdec_decode call (or one graph replay) to the next lives here, so the step kernels of
+// a captured hipGraph take only a baked slot index: step t = t_cur + slot.
 struct Ctrl {
   int stop_t;      // first step at which the batch-global stop rule fired, else kStopNever
   int steps_done;  // total steps produced so far (maintained by finish_kernel)
-  int pad[62];
+  int t_cur;       // global step index of slot 0 of the current launch batch / graph replay
+  int t_call;      // t_begin of the current ttsdec_decode call (outputs are indexed t - t_call)
+  int t_end;       // t_begin + n_steps of the call: slots at or past it do nothing
+  int t_stride;    // capacity (steps) of this call's y / s / w
+  int check_stop;
+  int dropout_mode;
+  float stop_thr;
+  int teacher_T;
+  unsigned long long seed;
+  const float* memory;
+  const uint8_t* masks;  // this call's [n_steps, 2, B, d_pre]
+  const float* teacher;
+  const uint8_t* teacher_flags;
+  float *y, *s, *w;
+  int pad[32];
 };
+
+// what a step kernel needs to know about "now"
+struct StepNow {
+  int t, t_rel;
+  bool live;
+};
+__device__ __forceinline__ StepNow step_now(const Ctrl* c, int slot) {
+  StepNow n;
+  n.t = c->t_cur + slot;
+  n.t_rel = n.t - c->t_call;
+  n.live = n.t < c->t_end && n.t <= c->stop_t;
+  return n;
+}
 
 // ---------------------------------------------------------------------------
 // Elementwise math that mirrors the reference's separate ATen ops: every

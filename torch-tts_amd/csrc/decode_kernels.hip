@@ -68,7 +68,30 @@ struct LoaderW {
 
 template <class Cfg, int AK, int EK>
 __global__ __launch_bounds__(kGemmThreads) void gemm_rows_kernel(GemmArgs g) {
-  if (g.ctrl != nullptr && g.t > g.ctrl->stop_t) return;
+  if (g.ctrl != nullptr) {  // step kernel inside a decode call: "now" and the call's buffers come from *ctrl
+    const Ctrl* c = g.ctrl;
+    const StepNow now = step_now(c, g.slot);
+    if (!now.live) return;
+    g.t = now.t;
+    g.t_rel = now.t_rel;
+    g.t_stride = c->t_stride;
+    if (EK == EPI_RELU_DROPOUT) {
+      g.dropout_mode = c->dropout_mode;
+      g.seed = c->seed;
+      g.masks = c->masks ? c->masks + ((size_t)now.t_rel * 2 + g.layer) * g.M * g.N : nullptr;
+      if (g.layer == 0) {
+        g.teacher = c->teacher;
+        g.teacher_T = c->teacher_T;
+        g.teacher_flags = c->teacher_flags;
+      }
+    }
+    if (EK == EPI_PROJ) {
+      g.y_out = c->y;
+      g.s_out = c->s;
+      g.stop_thr = c->stop_thr;
+      g.check_stop = c->check_stop;
+    }
+  }
   __shared__ __attribute__((aligned(16))) float smem[Cfg::kLdsFloats];
   constexpr int BM = Cfg::BM, BN = Cfg::BN, LDO = Cfg::LDO;
   const int m0 = blockIdx.y * BM;
@@ -184,7 +207,7 @@ struct LoaderWLstm {
 
 template <class Cfg>
 __global__ __launch_bounds__(kGemmThreads) void lstm_kernel(LstmArgs g) {
-  if (g.ctrl != nullptr && g.t > g.ctrl->stop_t) return;
+  if (g.ctrl != nullptr && !step_now(g.ctrl, g.slot).live) return;
   __shared__ __attribute__((aligned(16))) float smem[Cfg::kLdsFloats];
   constexpr int BM = Cfg::BM, BN = Cfg::BN, LDO = Cfg::LDO, BU = BN / 4, EB = Cfg::EB;
   const int m0 = blockIdx.y * BM;
@@ -199,10 +222,25 @@ __global__ __launch_bounds__(kGemmThreads) void lstm_kernel(LstmArgs g) {
     const int m = m0 + row, unit = u0 + u;
     if (m >= g.M || unit >= H) continue;
     const float* tr = smem + row * LDO;
-    const float gi = add_rn(tr[0 * BU + u], g.bsum[0 * H + unit]);
-    const float gf = add_rn(tr[1 * BU + u], g.bsum[1 * H + unit]);
-    const float gg = add_rn(tr[2 * BU + u], g.bsum[2 * H + unit]);
-    const float go = add_rn(tr[3 * BU + u], g.bsum[3 * H + unit]);
+    float si = tr[0 * BU + u], sf = tr[1 * BU + u], sg = tr[2 * BU + u], so = tr[3 * BU + u];
+    const size_t pidx = (size_t)m * 4 * H + unit;
+    if (g.mode == 1) {  // early part: park the raw gate sums
+      g.partial[pidx] = si;
+      g.partial[pidx + H] = sf;
+      g.partial[pidx + 2 * H] = sg;
+      g.partial[pidx + 3 * H] = so;
+      continue;
+    }
+    if (g.mode == 2) {  // finishing part: early sums + the late segments (fixed order: deterministic)
+      si = add_rn(g.partial[pidx], si);
+      sf = add_rn(g.partial[pidx + H], sf);
+      sg = add_rn(g.partial[pidx + 2 * H], sg);
+      so = add_rn(g.partial[pidx + 3 * H], so);
+    }
+    const float gi = add_rn(si, g.bsum[0 * H + unit]);
+    const float gf = add_rn(sf, g.bsum[1 * H + unit]);
+    const float gg = add_rn(sg, g.bsum[2 * H + unit]);
+    const float go = add_rn(so, g.bsum[3 * H + unit]);
     const size_t idx = (size_t)m * H + unit;
     const float c_prev = g.c[idx];
     const float h_prev = g.h_prev[idx];
@@ -264,7 +302,15 @@ __device__ __forceinline__ float wave_sum(float v) {
 
 template <int NJ>
 __global__ __launch_bounds__(kAttnThreads) void attn_kernel(AttnArgs g) {
-  if (g.ctrl != nullptr && g.t > g.ctrl->stop_t) return;
+  if (g.ctrl != nullptr) {
+    const Ctrl* c = g.ctrl;
+    const StepNow now = step_now(c, g.slot);
+    if (!now.live) return;
+    g.memory = c->memory;
+    g.w_out = c->w;
+    g.t_rel = now.t_rel;
+    g.t_stride = c->t_stride;
+  }
   constexpr int NW = kAttnThreads / 64;
   __shared__ __attribute__((aligned(16))) float part[NW * NJ * 256];
   const int b = blockIdx.x;
@@ -414,8 +460,9 @@ void launch_init(const InitArgs& a, hipStream_t st) {
   hipLaunchKernelGGL(init_state_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, a);
 }
 
-__global__ void finish_kernel(Ctrl* ctrl, int t_end, int32_t* T_out) {
+__global__ void finish_kernel(Ctrl* ctrl, int32_t* T_out) {
   const int stop = ctrl->stop_t;
+  const int t_end = ctrl->t_end;
   const int fired = (stop != kStopNever && stop < t_end) ? 1 : 0;
   const int done = fired ? stop + 1 : t_end;
   ctrl->steps_done = done;
@@ -425,8 +472,35 @@ __global__ void finish_kernel(Ctrl* ctrl, int t_end, int32_t* T_out) {
   }
 }
 
-void launch_finish(Ctrl* ctrl, int t_end, int32_t* T_out, hipStream_t st) {
-  hipLaunchKernelGGL(finish_kernel, dim3(1), dim3(1), 0, st, ctrl, t_end, T_out);
+void launch_finish(Ctrl* ctrl, int32_t* T_out, hipStream_t st) {
+  hipLaunchKernelGGL(finish_kernel, dim3(1), dim3(1), 0, st, ctrl, T_out);
+}
+
+__global__ void set_call_kernel(Ctrl* c, CallArgs a) {
+  c->t_cur = a.t_begin;
+  c->t_call = a.t_begin;
+  c->t_end = a.t_begin + a.n_steps;
+  c->t_stride = a.t_stride;
+  c->check_stop = a.check_stop;
+  c->dropout_mode = a.dropout_mode;
+  c->stop_thr = a.stop_thr;
+  c->teacher_T = a.teacher_T;
+  c->seed = a.seed;
+  c->memory = a.memory;
+  c->masks = a.masks;
+  c->teacher = a.teacher;
+  c->teacher_flags = a.teacher_flags;
+  c->y = a.y;
+  c->s = a.s;
+  c->w = a.w;
+}
+void launch_set_call(Ctrl* ctrl, const CallArgs& a, hipStream_t st) {
+  hipLaunchKernelGGL(set_call_kernel, dim3(1), dim3(1), 0, st, ctrl, a);
+}
+
+__global__ void advance_kernel(Ctrl* c, int n_slots) { c->t_cur += n_slots; }
+void launch_advance(Ctrl* ctrl, int n_slots, hipStream_t st) {
+  hipLaunchKernelGGL(advance_kernel, dim3(1), dim3(1), 0, st, ctrl, n_slots);
 }
 
 // ===========================================================================

@@ -44,9 +44,12 @@ struct GemmArgs {
   const float* teacher;  // [B, teacher_T, d_mel] or nullptr
   int teacher_T;
   const uint8_t* teacher_flags;
-  // step control
-  Ctrl* ctrl;  // nullptr: no stop check (postnet)
-  int t;       // absolute step index
+  // step control.  ctrl != nullptr: the step index is ctrl->t_cur + slot and the per-call
+  // pointers (masks, teacher, y, s, ...) come from *ctrl; the fields above are ignored for them.
+  // ctrl == nullptr (postnet, cell_step, profiling): everything comes from this struct.
+  Ctrl* ctrl;
+  int slot;
+  int t;  // absolute step index when ctrl == nullptr
 };
 
 void launch_gemm(const GemmArgs& a, AKind ak, EpiKind ek, hipStream_t st);
@@ -64,8 +67,13 @@ struct LstmArgs {
   float* h_out;         // [M, H]
   int M, H, K;
   float pz;  // zoneout probability (eval-mode blend)
+  // mode 0: whole cell.  mode 1: gates GEMM over the given segments only, raw sums stored to
+  // partial [M, 4H] (PyTorch gate order) - the part of the cell that does not wait for the kernel
+  // just before it.  mode 2: the remaining segments, + partial, then the cell update.
+  int mode;
+  float* partial;
   Ctrl* ctrl;
-  int t;
+  int slot;
   int dbg;  // measurement ablations (ttsdec_profile_step only): 1 = every load reads the zero block
 };
 void launch_lstm(const LstmArgs& a, hipStream_t st);
@@ -80,8 +88,8 @@ struct AttnArgs {
   float* ctx;           // [B, D]
   f16 *ctx_h, *ctx_l;   // optional split-fp16 planes of ctx
   int B, L, D, t_rel, t_stride;
-  Ctrl* ctrl;
-  int t;
+  Ctrl* ctrl;  // != nullptr: memory, w_out, t_rel, t_stride come from *ctrl
+  int slot;
 };
 void launch_attn(const AttnArgs& a, hipStream_t st);
 
@@ -97,7 +105,19 @@ struct InitArgs {
   int B, L, D, Ha, Hd, d_mel;
 };
 void launch_init(const InitArgs& a, hipStream_t st);
-void launch_finish(Ctrl* ctrl, int t_end, int32_t* T_out, hipStream_t st);
+void launch_finish(Ctrl* ctrl, int32_t* T_out, hipStream_t st);
+struct CallArgs {  // copied into *ctrl by launch_set_call at the start of every ttsdec_decode
+  int t_begin, n_steps, t_stride, check_stop, dropout_mode, teacher_T;
+  float stop_thr;
+  unsigned long long seed;
+  const float* memory;
+  const uint8_t* masks;
+  const float* teacher;
+  const uint8_t* teacher_flags;
+  float *y, *s, *w;
+};
+void launch_set_call(Ctrl* ctrl, const CallArgs& a, hipStream_t st);
+void launch_advance(Ctrl* ctrl, int n_slots, hipStream_t st);
 
 // ---- weight packing ----
 void launch_add_vec(const float* a, const float* b, float* out, int n, hipStream_t st);

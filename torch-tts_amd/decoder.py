@@ -102,8 +102,9 @@ class Decoder(nn.Module):
         t_out = torch.zeros(2, dtype=torch.int32, device=device)
         t = 0
         produced = 0
+        chunk = max(2, int(self.chunk_steps) + (int(self.chunk_steps) & 1))  # even: ttsdec_decode ties buffer parity to t_begin
         while True:
-            n = self.chunk_steps if cap is None else min(cap - t, self.chunk_steps if total_steps is None else cap - t)
+            n = chunk if cap is None else min(cap - t, chunk if total_steps is None else cap - t)
             if n <= 0:
                 break
             masks_dev = None
