@@ -68,10 +68,11 @@ struct LoaderW {
 
 template <class Cfg, int AK, int EK>
 __global__ __launch_bounds__(kGemmThreads) void gemm_rows_kernel(GemmArgs g) {
+  bool live = true;
   if (g.ctrl != nullptr) {  // step kernel inside a decode call: "now" and the call's buffers come from *ctrl
     const Ctrl* c = g.ctrl;
     const StepNow now = step_now(c, g.slot);
-    if (!now.live) return;
+    live = now.live;
     g.t = now.t;
     g.t_rel = now.t_rel;
     g.t_stride = c->t_stride;
@@ -94,13 +95,34 @@ __global__ __launch_bounds__(kGemmThreads) void gemm_rows_kernel(GemmArgs g) {
   }
   __shared__ __attribute__((aligned(16))) float smem[Cfg::kLdsFloats];
   constexpr int BM = Cfg::BM, BN = Cfg::BN, LDO = Cfg::LDO;
+  constexpr int EPT = BM * BN / kGemmThreads;  // output elements per thread
   const int m0 = blockIdx.y * BM;
   const int n0 = blockIdx.x * BN;
+
+  // Epilogue operands are requested BEFORE the K loop (their latency hides under it).
+  float pre_bias[EPT], pre_res[EPT];
+  uint8_t pre_mask[EPT];
+#pragma unroll
+  for (int j = 0; j < EPT; ++j) {
+    const int e = threadIdx.x + j * kGemmThreads;
+    const int m = m0 + e / BN, n = n0 + e % BN;
+    const bool ok = live && m < g.M && n < g.N;
+    pre_bias[j] = (ok && g.bias != nullptr) ? g.bias[n] : 0.f;
+    pre_mask[j] = 1;
+    pre_res[j] = 0.f;
+    if (EK == EPI_RELU_DROPOUT && ok && g.dropout_mode == TTSDEC_DROPOUT_MASKS) pre_mask[j] = g.masks[(size_t)m * g.N + n];
+    if (EK == EPI_BN_ISRU && ok) {
+      pre_bias[j] = g.alpha[n];
+      pre_res[j] = g.beta[n];
+    }
+    if (EK == EPI_RESIDUAL && ok) pre_res[j] = g.resid[(size_t)m * g.ldo + n];
+  }
+
   if (AK == A_CONV) {
     const LoaderConv la{static_cast<const float*>(g.a.p0), m0, g.M, g.T, g.Cin, g.taps, g.K};
     const Seg3 ws = make_seg1(g.W, g.ldw, g.K);
     const LoaderW<4> lb{ws, ws, n0, g.N};
-    gemm_tile<Cfg>(la, lb, smem);
+    gemm_tile<Cfg>(la, lb, smem, live);
   } else {
     Seg3 s = g.a;
     if (g.teacher != nullptr && g.t > 0 && g.teacher_flags[g.t - 1] != 0) {
@@ -112,22 +134,26 @@ __global__ __launch_bounds__(kGemmThreads) void gemm_rows_kernel(GemmArgs g) {
     const Seg3 ws = make_seg3(g.W, g.ldw, k0, g.W + k0, g.ldw, k1, g.W + k0 + k1, g.ldw, k2);
     const LoaderW<4> lb{ws, ws, n0, g.N};
     const LoaderPlain<4> la{s, s, m0, g.M};
-    gemm_tile<Cfg>(la, lb, smem);
+    gemm_tile<Cfg>(la, lb, smem, live);
   }
+  if (!live) return;
 
-  for (int e = threadIdx.x; e < BM * BN; e += kGemmThreads) {
+#pragma unroll
+  for (int j = 0; j < EPT; ++j) {
+    const int e = threadIdx.x + j * kGemmThreads;
     const int row = e / BN, col = e % BN;
     const int m = m0 + row, n = n0 + col;
     if (m >= g.M || n >= g.N) continue;
     float v = smem[row * LDO + col];
-    if (g.bias != nullptr) v = add_rn(v, g.bias[n]);
+    if (EK != EPI_BN_ISRU && g.bias != nullptr) v = add_rn(v, pre_bias[j]);
     if (EK == EPI_PLAIN) {
       g.out[(size_t)m * g.ldo + n] = v;
+      if (g.out_h != nullptr) split_f16(v, g.out_h[(size_t)m * g.ldo + n], g.out_l[(size_t)m * g.ldo + n]);
     } else if (EK == EPI_RELU_DROPOUT) {
       // modules.py:39-40: relu then dropout(p, always): kept units scaled by 1/(1-p)
       v = v > 0.f ? v : 0.f;
       if (g.dropout_mode == TTSDEC_DROPOUT_MASKS) {
-        v = g.masks[(size_t)m * g.N + n] ? mul_rn(v, g.keep_scale) : 0.f;
+        v = pre_mask[j] ? mul_rn(v, g.keep_scale) : 0.f;
       } else if (g.dropout_mode == TTSDEC_DROPOUT_PHILOX) {
         v = philox_keep(g.seed, (uint32_t)g.t, (uint32_t)g.layer, (uint32_t)m, (uint32_t)n) ? mul_rn(v, g.keep_scale) : 0.f;
       }
@@ -138,22 +164,22 @@ __global__ __launch_bounds__(kGemmThreads) void gemm_rows_kernel(GemmArgs g) {
       if (n < nm) {
         // decoder.py:53-54: leaky_relu(fc_mel(d_t), 0.01) viewed as [B, r, d_mel]
         v = v > 0.f ? v : mul_rn(v, 0.01f);
-        const int j = n / g.d_mel, c = n - j * g.d_mel;
-        g.y_out[((size_t)m * g.t_stride * g.r + (size_t)g.t_rel * g.r + j) * g.d_mel + c] = v;
-        if (j == g.r - 1) g.ynext[(size_t)m * g.d_mel + c] = v;  // decoder.py:48 y_t[:, -1, :]
+        const int jf = n / g.d_mel, c = n - jf * g.d_mel;
+        g.y_out[((size_t)m * g.t_stride * g.r + (size_t)g.t_rel * g.r + jf) * g.d_mel + c] = v;
+        if (jf == g.r - 1) g.ynext[(size_t)m * g.d_mel + c] = v;  // decoder.py:48 y_t[:, -1, :]
       } else {
         // decoder.py:52 stop logit; decoder.py:68 batch-global rule
-        const int j = n - nm;
-        g.s_out[(size_t)m * g.t_stride * g.r + (size_t)g.t_rel * g.r + j] = v;
+        const int jf = n - nm;
+        g.s_out[(size_t)m * g.t_stride * g.r + (size_t)g.t_rel * g.r + jf] = v;
         if (g.check_stop && v < g.stop_thr) atomicMin(&g.ctrl->stop_t, g.t);
       }
     } else if (EK == EPI_BN_ISRU) {
       // modules.py:181 isru(BatchNorm1d(conv(x))) with eval-mode BN as x*alpha + beta
-      v = isru(add_rn(mul_rn(v, g.alpha[n]), g.beta[n]));
+      v = isru(add_rn(mul_rn(v, pre_bias[j]), pre_res[j]));
       g.out[(size_t)m * g.ldo + n] = v;
     } else if (EK == EPI_RESIDUAL) {
       // modules.py:184 x + fc_out(...)
-      g.out[(size_t)m * g.ldo + n] = add_rn(g.resid[(size_t)m * g.ldo + n], v);
+      g.out[(size_t)m * g.ldo + n] = add_rn(pre_res[j], v);
     }
   }
 }
@@ -207,20 +233,43 @@ struct LoaderWLstm {
 
 template <class Cfg>
 __global__ __launch_bounds__(kGemmThreads) void lstm_kernel(LstmArgs g) {
-  if (g.ctrl != nullptr && !step_now(g.ctrl, g.slot).live) return;
+  const bool live = g.ctrl == nullptr || step_now(g.ctrl, g.slot).live;
   __shared__ __attribute__((aligned(16))) float smem[Cfg::kLdsFloats];
   constexpr int BM = Cfg::BM, BN = Cfg::BN, LDO = Cfg::LDO, BU = BN / 4, EB = Cfg::EB;
+  constexpr int EPT = (BM * BU + kGemmThreads - 1) / kGemmThreads;  // (row, unit) pairs per thread
   const int m0 = blockIdx.y * BM;
   const int u0 = blockIdx.x * BU;
+  const int H = g.H;
+
+  // cell-update operands are requested BEFORE the K loop (their latency hides under it)
+  float pb[EPT][4], pc[EPT], ph[EPT], pp[EPT][4];
+#pragma unroll
+  for (int j = 0; j < EPT; ++j) {
+    const int e = threadIdx.x + j * kGemmThreads;
+    const int m = m0 + e / BU, unit = u0 + e % BU;
+    const bool ok = live && e < BM * BU && m < g.M && unit < H && g.mode != 1;
+    const size_t idx = (size_t)m * H + unit;
+    const size_t pidx = (size_t)m * 4 * H + unit;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      pb[j][k] = ok ? g.bsum[k * H + unit] : 0.f;
+      pp[j][k] = (ok && g.mode == 2) ? g.partial[pidx + (size_t)k * H] : 0.f;
+    }
+    pc[j] = ok ? g.c[idx] : 0.f;
+    ph[j] = ok ? g.h_prev[idx] : 0.f;
+  }
+
   const LoaderPlain<EB> la{g.a, g.a_lo, m0, g.M};
   const LoaderWLstm<BU, EB> lb{g.w, g.w_lo, u0, g.H};
-  gemm_tile<Cfg>(la, lb, smem, g.dbg);
+  gemm_tile<Cfg>(la, lb, smem, live, g.dbg);
+  if (!live) return;
 
-  const int H = g.H;
-  for (int e = threadIdx.x; e < BM * BU; e += kGemmThreads) {
+#pragma unroll
+  for (int j = 0; j < EPT; ++j) {
+    const int e = threadIdx.x + j * kGemmThreads;
     const int row = e / BU, u = e % BU;
     const int m = m0 + row, unit = u0 + u;
-    if (m >= g.M || unit >= H) continue;
+    if (e >= BM * BU || m >= g.M || unit >= H) continue;
     const float* tr = smem + row * LDO;
     float si = tr[0 * BU + u], sf = tr[1 * BU + u], sg = tr[2 * BU + u], so = tr[3 * BU + u];
     const size_t pidx = (size_t)m * 4 * H + unit;
@@ -232,18 +281,18 @@ __global__ __launch_bounds__(kGemmThreads) void lstm_kernel(LstmArgs g) {
       continue;
     }
     if (g.mode == 2) {  // finishing part: early sums + the late segments (fixed order: deterministic)
-      si = add_rn(g.partial[pidx], si);
-      sf = add_rn(g.partial[pidx + H], sf);
-      sg = add_rn(g.partial[pidx + 2 * H], sg);
-      so = add_rn(g.partial[pidx + 3 * H], so);
+      si = add_rn(pp[j][0], si);
+      sf = add_rn(pp[j][1], sf);
+      sg = add_rn(pp[j][2], sg);
+      so = add_rn(pp[j][3], so);
     }
-    const float gi = add_rn(si, g.bsum[0 * H + unit]);
-    const float gf = add_rn(sf, g.bsum[1 * H + unit]);
-    const float gg = add_rn(sg, g.bsum[2 * H + unit]);
-    const float go = add_rn(so, g.bsum[3 * H + unit]);
+    const float gi = add_rn(si, pb[j][0]);
+    const float gf = add_rn(sf, pb[j][1]);
+    const float gg = add_rn(sg, pb[j][2]);
+    const float go = add_rn(so, pb[j][3]);
     const size_t idx = (size_t)m * H + unit;
-    const float c_prev = g.c[idx];
-    const float h_prev = g.h_prev[idx];
+    const float c_prev = pc[j];
+    const float h_prev = ph[j];
     // nn.LSTMCell: c' = sigmoid(f)*c + sigmoid(i)*tanh(g); h' = sigmoid(o)*tanh(c')
     const float c_new = add_rn(mul_rn(sigmoid_f(gf), c_prev), mul_rn(sigmoid_f(gi), tanhf(gg)));
     const float h_new = mul_rn(sigmoid_f(go), tanhf(c_new));
@@ -260,7 +309,7 @@ void launch_lstm(const LstmArgs& a, hipStream_t st) {
   if (a.M <= 0) return;
   if (a.prec == 1) {
     if (a.M >= 192) {
-      using Cfg = TileCfg<2, 2, 1, 4, PREC_F16S>;  // 64 rows x 16 units, 32 KiB stages (64 k each)
+      using Cfg = TileCfg<2, 2, 1, 4, PREC_F16S>;  // 64 rows x 16 units, 32 KiB stages (64 k each); S=5 and nt weight loads measured slower
       dim3 grid((a.H + 15) / 16, (a.M + 63) / 64);
       hipLaunchKernelGGL((lstm_kernel<Cfg>), grid, dim3(kGemmThreads), 0, st, a);
     } else {

@@ -42,8 +42,9 @@ namespace ttsdec {
 
 enum Prec { PREC_F32 = 0, PREC_F16S = 1 };
 
-template <int WM, int WN, int WK, int S, int PREC = PREC_F32>
+template <int WM, int WN, int WK, int S, int PREC = PREC_F32, int AUXB = 0>
 struct TileCfg {
+  static constexpr int kAuxB = AUXB;  // cache-policy bits of the B (weight) operand's LDS-DMA: 2 = nt (streamed once)
   static_assert(WM * WN * WK == 4, "4 MFMA waves per workgroup");
   static_assert(S >= 3, "ring needs at least 3 stages (fragment reads run one tile ahead of the MFMAs)");
   static constexpr int kPrec = PREC;
@@ -105,7 +106,11 @@ __device__ __forceinline__ void wait_vmcnt() {
 // After the call `smem` holds the BM x BN result, row-major with leading dimension
 // Cfg::LDO, summed over the WK slices, visible to all threads.
 template <class Cfg, class LoaderA, class LoaderB>
-__device__ __forceinline__ void gemm_tile(const LoaderA& la, const LoaderB& lb, float* smem, int dbg = 0) {
+__device__ __forceinline__ void gemm_tile(const LoaderA& la, const LoaderB& lb, float* smem, bool live = true,
+                                          int dbg = 0) {
+  // `live` (does this launch have anything to do?) typically comes from a control-block load
+  // that is still in flight: it is first looked at AFTER the loader waves have issued their
+  // prologue DMAs, so its latency hides under theirs.  A dead launch drains and falls through.
   constexpr int BM = Cfg::BM, BN = Cfg::BN, KT = Cfg::KT, C16 = Cfg::C16, RPI = Cfg::ROWS_PER_INST;
   constexpr int NA = Cfg::NA, NB = Cfg::NB, NP = Cfg::NP, EB = Cfg::EB, ROWB = Cfg::ROWB;
   constexpr int LDO = Cfg::LDO, S = Cfg::STAGES;
@@ -202,9 +207,10 @@ __device__ __forceinline__ void gemm_tile(const LoaderA& la, const LoaderB& lb, 
 #pragma unroll
         for (int i = 0; i < NB; ++i) {
           gbyte* ptr = (partial && kpos + cb[i] >= seg_len) ? zero_addr() : curb[p][i];
-          __builtin_amdgcn_global_load_lds(
-              (global_void*)ptr,
-              (lds_void*)(st + NP * Cfg::kPlaneABytes + p * Cfg::kPlaneBBytes + (wave * NB + i) * 1024), 16, 0, 0);
+          lds_void* dst = (lds_void*)(st + NP * Cfg::kPlaneABytes + p * Cfg::kPlaneBBytes + (wave * NB + i) * 1024);
+          // (size and cache-policy arguments of the builtin must be literals)
+          if constexpr (Cfg::kAuxB == 2) __builtin_amdgcn_global_load_lds((global_void*)ptr, dst, 16, 0, 2);
+          else __builtin_amdgcn_global_load_lds((global_void*)ptr, dst, 16, 0, 0);
           curb[p][i] += incb[i];
         }
       }
@@ -240,9 +246,12 @@ __device__ __forceinline__ void gemm_tile(const LoaderA& la, const LoaderB& lb, 
     // tiles 0 .. S-2 in flight
 #pragma unroll
     for (int t = 0; t < S - 1; ++t) issue_tile();
-    wait_vmcnt<(S - 2) * Cfg::NLOADS>();  // tile 0 landed
-    __builtin_amdgcn_s_barrier();         // B0
-    for (int t = 0; t < nk; ++t) {
+    const int nk_run = live ? nk : 0;
+    if (live) {
+      wait_vmcnt<(S - 2) * Cfg::NLOADS>();  // tile 0 landed
+      __builtin_amdgcn_s_barrier();         // B0
+    }
+    for (int t = 0; t < nk_run; ++t) {
       wait_vmcnt<Cfg::kWaitCnt>();        // this wave's part of tile t+1 has landed
       __builtin_amdgcn_s_barrier();       // B(t+1): the MFMA waves have issued tile t-1's MFMAs, its stage is free
       if (dbg != 3) issue_tile();         // tile t+S-1 into that stage (dbg 3: measurement ablation)
@@ -290,11 +299,14 @@ __device__ __forceinline__ void gemm_tile(const LoaderA& la, const LoaderB& lb, 
           }
         }
       };
-      __builtin_amdgcn_s_barrier();  // B0: tile 0 is in LDS
-      read_frags(std::integral_constant<int, 0>{});
-      for (int t = 0; t < nk; t += 2) {
+      const int nk_run = live ? nk : 0;
+      if (live) {
+        __builtin_amdgcn_s_barrier();  // B0: tile 0 is in LDS
+        read_frags(std::integral_constant<int, 0>{});
+      }
+      for (int t = 0; t < nk_run; t += 2) {
         tile_step(std::integral_constant<int, 0>{});
-        if (t + 1 < nk) tile_step(std::integral_constant<int, 1>{});
+        if (t + 1 < nk_run) tile_step(std::integral_constant<int, 1>{});
       }
     } else {
       // split-fp16: per k16-step s one 16-byte fragment of each of A_hi, A_lo, B_hi, B_lo
@@ -333,11 +345,14 @@ __device__ __forceinline__ void gemm_tile(const LoaderA& la, const LoaderB& lb, 
           }
         }
       };
-      __builtin_amdgcn_s_barrier();
-      read_frags(std::integral_constant<int, 0>{});
-      for (int t = 0; t < nk; t += 2) {
+      const int nk_run = live ? nk : 0;
+      if (live) {
+        __builtin_amdgcn_s_barrier();
+        read_frags(std::integral_constant<int, 0>{});
+      }
+      for (int t = 0; t < nk_run; t += 2) {
         tile_step(std::integral_constant<int, 0>{});
-        if (t + 1 < nk) tile_step(std::integral_constant<int, 1>{});
+        if (t + 1 < nk_run) tile_step(std::integral_constant<int, 1>{});
       }
 #pragma unroll
       for (int i = 0; i < 16; ++i) acc[i] = fmaf(acc2[i], 1.0f / kSplitScale, acc[i]);
