@@ -67,7 +67,7 @@ def main():
     ap.add_argument("--batch", type=int, default=256, help="utterances per GPU")
     ap.add_argument("--mem-len", type=int, default=120)
     ap.add_argument("--frames", type=int, default=600)
-    ap.add_argument("--postnet", choices=["f32", "bf16"], default="f32")
+    ap.add_argument("--postnet", choices=["f32", "bf16", "split_f16"], default="split_f16")
     ap.add_argument("--precision", choices=["f32", "split_f16"], default="split_f16",
                     help="arithmetic of the LSTM gate GEMMs (include/ttsdec.h TTSDEC_PREC_*)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -129,7 +129,7 @@ def main():
     s = torch.empty(B, NF, device=dev)
     w = torch.empty(B, NF, L, device=dev)
     t_out = torch.zeros(2, dtype=torch.int32, device=dev)
-    prec = {"f32": _lib.POSTNET_F32, "bf16": _lib.POSTNET_BF16}[args.postnet]
+    prec = {"f32": _lib.POSTNET_F32, "bf16": _lib.POSTNET_BF16, "split_f16": _lib.POSTNET_SPLIT_F16}[args.postnet]
 
     def one_step():
         eng.decode(mem, t_begin=0, n_steps=NF, stop_threshold=-2.0, check_stop=True, dropout_mode=_lib.DROPOUT_PHILOX,

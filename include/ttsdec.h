@@ -112,9 +112,11 @@ enum {
 
 /* Postnet arithmetic. */
 enum {
-  TTSDEC_POSTNET_F32 = 0,   /* exact fp32 (fp32-input MFMA)                                   */
-  TTSDEC_POSTNET_BF16 = 1   /* bf16 MFMA, fp32 accumulate (BASELINE.json configs[2])          */
-};
+  TTSDEC_POSTNET_F32 = 0,       /* exact fp32 (fp32-input MFMA)                                              */
+  TTSDEC_POSTNET_BF16 = 1,      /* bf16 operands on the bf16 MFMA, fp32 accumulate (BASELINE.json configs[2]):
+                                 * ~3 significant digits; the tolerance is reported by the tests/bench       */
+  TTSDEC_POSTNET_SPLIT_F16 = 2  /* split-fp16 operands (see TTSDEC_PREC_SPLIT_F16): fp32-grade               */
+};                              /* 16-bit modes need d_mel and postnet_hidden to be multiples of 8, else F32 is used */
 
 int ttsdec_version(void);
 const char* ttsdec_strerror(int code);

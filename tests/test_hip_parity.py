@@ -246,6 +246,25 @@ def test_postnet_ljspeech_dims_vs_oracle(H):
     H.assert_close(out, ref, RTOL, ATOL, "postnet")
 
 
+@pytest.mark.parametrize("mode,rtol,atol", [("split_f16", RTOL, ATOL), ("bf16", 3e-2, 3e-2)])
+def test_postnet_low_precision_modes_vs_oracle(H, mode, rtol, atol):
+    """Postnet on 16-bit MFMA operands.  split_f16 must meet the exact path's bar; bf16
+    (BASELINE.json configs[2]: 'Postnet conv1d on MFMA bf16, mel tolerance vs CPU reported')
+    carries 8 significand bits per operand - its measured error is printed and bounded."""
+    pw = O.random_postnet_weights(80, 512, 3, seed=9)
+    g = torch.Generator().manual_seed(2)
+    y = torch.randn(5, 131, 80, generator=g)
+    ref = O.mel_postnet(y, pw, 3)
+    pn = H.make_postnet(80, 512, 3, pw)
+    pn.precision = mode
+    with torch.no_grad():
+        out = pn(y.cuda()).cpu()
+    err = (out - ref).abs()
+    print(f"postnet {mode}: max abs err {float(err.max()):.3e}, rel-to-max {float(err.max() / ref.abs().max()):.3e}, "
+          f"mean abs err {float(err.mean()):.3e}")
+    H.assert_close(out, ref, rtol, atol, f"postnet {mode}")
+
+
 def test_philox_mode_matches_oracle_masks(H):
     """On-device dropout: the same Philox function restated in the oracle gives the masks;
     the decode must match the oracle run with those masks injected."""

@@ -37,10 +37,12 @@ def test_host_only_queries_and_layout_sizes():
     # + the split-fp16 planes (hi, lo) of the four LSTM weight matrices: another 4 bytes per LSTM weight
     n_lstm_w = 4096 * (768 + 1024) + 4096 * (1536 + 1024)
     assert e.packed_bytes() >= 4 * (n_dec + n_lstm_w) and e.packed_bytes() % 256 == 0
-    assert e.packed_bytes() < 4 * (n_dec + n_lstm_w + 2870272) * 1.01 + 64 * 256
+    # + postnet fp32 (2 870 272 params incl. BN folded to alpha/beta) and its bf16 / fp16-hi / fp16-lo planes
+    n_post_w = 512 * 80 * 5 + 2 * 512 * 512 * 5 + 80 * 512
+    assert e.packed_bytes() < 4 * (n_dec + n_lstm_w + 2870272) * 1.01 + 6 * n_post_w + 128 * 256
     w1, w2 = e.workspace_bytes(64, 120), e.workspace_bytes(256, 120)
     assert 0 < w1 < w2 and w2 % 256 == 0
-    assert e.postnet_workspace_bytes(256, 600) == 2 * 256 * 600 * 512 * 4
+    assert e.postnet_workspace_bytes(256, 600) == 2 * 256 * 600 * 512 * 4 + 256 * 600 * 80 * 4
     assert T.Engine(T.EngineDims(), None).num_weight_tensors() == 21
     # precision switch: split-fp16 needs 8-aligned feature dims, otherwise the handle stays on fp32
     assert e.precision() == "f32"

@@ -13,7 +13,7 @@ LIB_PATH = os.path.join(HERE, "lib", "libttsdec.so")
 OK = 0
 ERR_INVALID_ARG, ERR_DIMS, ERR_HIP, ERR_NOT_BOUND, ERR_WORKSPACE, ERR_DEVICE = -1, -2, -3, -4, -5, -6
 DROPOUT_OFF, DROPOUT_MASKS, DROPOUT_PHILOX = 0, 1, 2
-POSTNET_F32, POSTNET_BF16 = 0, 1
+POSTNET_F32, POSTNET_BF16, POSTNET_SPLIT_F16 = 0, 1, 2
 PREC_F32, PREC_SPLIT_F16 = 0, 1
 W_DECODER_COUNT = 21
 W_POSTNET_PER_LAYER = 5

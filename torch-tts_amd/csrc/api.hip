@@ -25,7 +25,8 @@ struct BlobLayout {  // offsets in floats
   size_t h0a, c0a, h0d, c0d;
   size_t proj_w, proj_b;
   size_t conv_w[kMaxPostnetLayers], conv_alpha[kMaxPostnetLayers], conv_beta[kMaxPostnetLayers];
-  size_t fc_w;
+  size_t conv_wb[kMaxPostnetLayers], conv_wh[kMaxPostnetLayers], conv_wl[kMaxPostnetLayers];  // bf16 / split-fp16 planes
+  size_t fc_w, fc_wb, fc_wh, fc_wl;
   size_t total;
 };
 
@@ -101,9 +102,15 @@ BlobLayout make_blob_layout(const ttsdec_dims& d) {
     L.conv_w[i] = take((size_t)d.postnet_hidden * d.postnet_kernel * cin);
     L.conv_alpha[i] = take(d.postnet_hidden);
     L.conv_beta[i] = take(d.postnet_hidden);
+    const size_t nh = ((size_t)d.postnet_hidden * d.postnet_kernel * cin + 1) / 2;  // 16-bit plane, in floats
+    L.conv_wb[i] = take(nh); L.conv_wh[i] = take(nh); L.conv_wl[i] = take(nh);
     cin = d.postnet_hidden;
   }
-  if (d.postnet_layers > 0) L.fc_w = take(Mel * (size_t)d.postnet_hidden);
+  if (d.postnet_layers > 0) {
+    L.fc_w = take(Mel * (size_t)d.postnet_hidden);
+    const size_t nh = (Mel * (size_t)d.postnet_hidden + 1) / 2;
+    L.fc_wb = take(nh); L.fc_wh = take(nh); L.fc_wl = take(nh);
+  }
   L.total = off;
   return L;
 }
@@ -264,7 +271,7 @@ void launch_node(const ttsdec_handle* h, const StepBufs& sb, const StepIo& io, N
         g.a = make_seg1(sb.xpre0, P, P);
         g.W = blob + bl.pre1_w; g.ldw = P; g.K = P; g.bias = blob + bl.pre1_b;
         g.out = sb.xpre;
-        if (prec) { g.out_h = sb.xpre_h; g.out_l = sb.xpre_l; }
+        if (prec) { g.out_h = sb.xpre_h; g.out_l = sb.xpre_l; g.out_kind = 1; }
       }
       g.M = B; g.N = P; g.ldo = P;
       g.dropout_mode = io.dropout_mode;
@@ -615,12 +622,21 @@ int ttsdec_pack_weights(ttsdec_handle* h, const float* const* src, int n_src, vo
     const float* const* ps = src + TTSDEC_W_DECODER_COUNT + TTSDEC_W_POSTNET_PER_LAYER * i;
     if (!ps[0] || !ps[1] || !ps[2] || !ps[3] || !ps[4]) return TTSDEC_ERR_INVALID_ARG;
     launch_conv_transpose(ps[0], b + L.conv_w[i], d.postnet_hidden, cin, d.postnet_kernel, st);
+    {
+      const size_t n = (size_t)d.postnet_hidden * d.postnet_kernel * cin;
+      launch_split(b + L.conv_w[i], hp(L.conv_wh[i]), hp(L.conv_wl[i]), n, st);
+      launch_to_bf16(b + L.conv_w[i], b + L.conv_wb[i], n, st);
+    }
     launch_bn_fold(ps[1], ps[2], ps[3], ps[4], d.bn_eps, b + L.conv_alpha[i], b + L.conv_beta[i], d.postnet_hidden, st);
     cin = d.postnet_hidden;
   }
-  if (d.postnet_layers > 0)
-    launch_copy(src[TTSDEC_W_DECODER_COUNT + TTSDEC_W_POSTNET_PER_LAYER * d.postnet_layers], b + L.fc_w,
-                Mel * (size_t)d.postnet_hidden, st);
+  if (d.postnet_layers > 0) {
+    const float* fc = src[TTSDEC_W_DECODER_COUNT + TTSDEC_W_POSTNET_PER_LAYER * d.postnet_layers];
+    const size_t n = Mel * (size_t)d.postnet_hidden;
+    launch_copy(fc, b + L.fc_w, n, st);
+    launch_split(fc, hp(L.fc_wh), hp(L.fc_wl), n, st);
+    launch_to_bf16(fc, b + L.fc_wb, n, st);
+  }
   rc = check_launch(h, "pack_weights");
   if (rc != TTSDEC_OK) return rc;
   h->blob = b;
@@ -702,14 +718,17 @@ int ttsdec_decode(ttsdec_handle* h, const float* memory, int B, int L, int t_beg
 
 size_t ttsdec_postnet_workspace_bytes(const ttsdec_handle* h, int B, int T) {
   if (!h || B <= 0 || T <= 0 || h->d.postnet_layers <= 0) return 0;
-  return 2 * align_up((size_t)B * T * h->d.postnet_hidden * sizeof(float), 256);
+  // two activation buffers (fp32, or hi+lo fp16 planes, or one bf16 plane) + 16-bit planes of the input
+  return 2 * align_up((size_t)B * T * h->d.postnet_hidden * sizeof(float), 256) +
+         align_up((size_t)B * T * h->d.d_mel * sizeof(float), 256);
 }
 
 int ttsdec_postnet(ttsdec_handle* h, const float* y, int B, int T, int precision, float* y_post, void* workspace,
                    size_t workspace_bytes, void* stream) {
   if (!h || !y || !y_post || !workspace || B <= 0 || T <= 0) return TTSDEC_ERR_INVALID_ARG;
   if (h->d.postnet_layers <= 0) return TTSDEC_ERR_DIMS;
-  if (precision != TTSDEC_POSTNET_F32) return TTSDEC_ERR_INVALID_ARG;  // bf16 path: not built yet
+  if (precision != TTSDEC_POSTNET_F32 && precision != TTSDEC_POSTNET_BF16 && precision != TTSDEC_POSTNET_SPLIT_F16)
+    return TTSDEC_ERR_INVALID_ARG;
   if (!h->blob) return TTSDEC_ERR_NOT_BOUND;
   int rc = check_device(h);
   if (rc != TTSDEC_OK) return rc;
@@ -717,27 +736,72 @@ int ttsdec_postnet(ttsdec_handle* h, const float* y, int B, int T, int precision
     return TTSDEC_ERR_WORKSPACE;
   hipStream_t st = static_cast<hipStream_t>(stream);
   const ttsdec_dims& d = h->d;
-  const size_t half = align_up((size_t)B * T * d.postnet_hidden * sizeof(float), 256);
-  float* act[2] = {static_cast<float*>(workspace), reinterpret_cast<float*>(static_cast<char*>(workspace) + half)};
-  const float* in = y;
+  const BlobLayout& L = h->bl;
+  // 16-bit modes need whole 16-byte columns of 16-bit elements in every K segment
+  int prec = PREC_F32;
+  if (!((d.d_mel | d.postnet_hidden) & 7)) {
+    if (precision == TTSDEC_POSTNET_BF16) prec = PREC_BF16;
+    if (precision == TTSDEC_POSTNET_SPLIT_F16) prec = PREC_F16S;
+  }
+  const size_t M = (size_t)B * T;
+  const size_t act_bytes = align_up(M * d.postnet_hidden * sizeof(float), 256);
+  char* wsb = static_cast<char*>(workspace);
+  char* act[2] = {wsb, wsb + act_bytes};
+  char* yin = wsb + 2 * act_bytes;
+  auto plane = [&](size_t float_off) { return reinterpret_cast<const void*>(h->blob + float_off); };
+
+  // current layer input as (plane 0, plane 1)
+  const void *in0 = y, *in1 = y;
+  if (prec == PREC_F16S) {
+    f16* yh = reinterpret_cast<f16*>(yin);
+    f16* yl = yh + M * d.d_mel;
+    launch_split(y, yh, yl, M * d.d_mel, st);
+    in0 = yh; in1 = yl;
+  } else if (prec == PREC_BF16) {
+    launch_to_bf16(y, yin, M * d.d_mel, st);
+    in0 = in1 = yin;
+  }
   int cin = d.d_mel;
   for (int i = 0; i < d.postnet_layers; ++i) {
     GemmArgs g;
     memset(&g, 0, sizeof(g));
-    g.a = make_seg1(in, cin, cin);
+    g.prec = prec;
+    g.a = make_seg1(in0, cin, cin);
+    g.a_lo = make_seg1(in1, cin, cin);
     g.T = T; g.Cin = cin; g.taps = d.postnet_kernel;
-    g.W = h->blob + h->bl.conv_w[i]; g.ldw = d.postnet_kernel * cin; g.K = d.postnet_kernel * cin;
-    g.M = B * T; g.N = d.postnet_hidden;
-    g.alpha = h->blob + h->bl.conv_alpha[i]; g.beta = h->blob + h->bl.conv_beta[i];
-    g.out = act[i & 1]; g.ldo = d.postnet_hidden;
+    g.ldw = d.postnet_kernel * cin; g.K = d.postnet_kernel * cin;
+    g.M = (int)M; g.N = d.postnet_hidden;
+    g.alpha = h->blob + L.conv_alpha[i]; g.beta = h->blob + L.conv_beta[i];
+    g.ldo = d.postnet_hidden;
+    char* o = act[i & 1];
+    if (prec == PREC_F32) {
+      g.W = g.W_lo = h->blob + L.conv_w[i];
+      g.out = reinterpret_cast<float*>(o);
+      in0 = in1 = o;
+    } else if (prec == PREC_F16S) {
+      g.W = plane(L.conv_wh[i]); g.W_lo = plane(L.conv_wl[i]);
+      g.out_kind = 1;
+      g.out_h = reinterpret_cast<f16*>(o);
+      g.out_l = g.out_h + M * d.postnet_hidden;
+      in0 = g.out_h; in1 = g.out_l;
+    } else {
+      g.W = g.W_lo = plane(L.conv_wb[i]);
+      g.out_kind = 2;
+      g.out_h = reinterpret_cast<f16*>(o);
+      in0 = in1 = o;
+    }
     launch_gemm(g, A_CONV, EPI_BN_ISRU, st);
-    in = act[i & 1];
     cin = d.postnet_hidden;
   }
   GemmArgs g;
   memset(&g, 0, sizeof(g));
-  g.a = make_seg1(in, cin, cin);
-  g.W = h->blob + h->bl.fc_w; g.ldw = cin; g.K = cin; g.M = B * T; g.N = d.d_mel;
+  g.prec = prec;
+  g.a = make_seg1(in0, cin, cin);
+  g.a_lo = make_seg1(in1, cin, cin);
+  if (prec == PREC_F32) g.W = g.W_lo = h->blob + L.fc_w;
+  else if (prec == PREC_F16S) { g.W = plane(L.fc_wh); g.W_lo = plane(L.fc_wl); }
+  else g.W = g.W_lo = plane(L.fc_wb);
+  g.ldw = cin; g.K = cin; g.M = (int)M; g.N = d.d_mel;
   g.resid = y; g.out = y_post; g.ldo = d.d_mel;
   launch_gemm(g, A_PLAIN, EPI_RESIDUAL, st);
   return check_launch(h, "postnet");

@@ -16,6 +16,9 @@ constexpr int kGemmThreads = 512;  // 4 MFMA waves + 4 loader waves
 constexpr int kAttnThreads = 512;
 constexpr int kStopNever = 0x7fffffff;
 
+// arithmetic modes of the GEMM core (gemm_tile.h)
+enum Prec { PREC_F32 = 0, PREC_F16S = 1, PREC_BF16 = 2 };
+
 // Control block at the head of the decoder workspace.  Everything that changes from one
 // ttsdec_decode call (or one graph replay) to the next lives here, so the step kernels of
 // a captured hipGraph take only a baked slot index: step t = t_cur + slot.
@@ -150,6 +153,8 @@ __device__ __forceinline__ int seg_count(const Seg3& s) { return s.e2 > s.e1 ? 3
 // ---------------------------------------------------------------------------
 typedef _Float16 f16;
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16;
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 constexpr float kSplitScale = 2048.0f;
 __device__ __forceinline__ void split_f16(float x, f16& hi, f16& lo) {
   f16 h = (f16)x;

@@ -31,15 +31,16 @@ struct LoaderPlain {
 // implicit im2col for Conv1d(k, padding=(k-1)/2) on channel-last activations x [B*T, Cin]:
 // with k = tap*Cin + c the im2col row of frame m is the contiguous window
 // x[(m - taps/2)*Cin + k], valid while the tapped frame stays inside the utterance.
+template <int EB>
 struct LoaderConv {
-  const float* x;
+  const void *x, *x_lo;
   int m0, M, T, Cin, taps, K;
   static constexpr bool kRange = true;
   __device__ __forceinline__ int nseg() const { return 1; }
   __device__ __forceinline__ int seglen(int i) const { return i == 0 ? K : 0; }
   __device__ __forceinline__ bool row_ok(int r) const { return m0 + r < M; }
-  __device__ __forceinline__ gbyte* row_ptr(int r, int, int) const {
-    return as_global(x) + (((long)(m0 + r) - (taps >> 1)) * Cin) * 4;
+  __device__ __forceinline__ gbyte* row_ptr(int r, int, int plane) const {
+    return as_global(plane == 0 ? x : x_lo) + (((long)(m0 + r) - (taps >> 1)) * Cin) * EB;
   }
   __device__ __forceinline__ int k_lo(int r) const {
     const int t = (m0 + r) % T, half = taps >> 1;
@@ -118,22 +119,25 @@ __global__ __launch_bounds__(kGemmThreads) void gemm_rows_kernel(GemmArgs g) {
     if (EK == EPI_RESIDUAL && ok) pre_res[j] = g.resid[(size_t)m * g.ldo + n];
   }
 
+  constexpr int EB = Cfg::EB;
   if (AK == A_CONV) {
-    const LoaderConv la{static_cast<const float*>(g.a.p0), m0, g.M, g.T, g.Cin, g.taps, g.K};
-    const Seg3 ws = make_seg1(g.W, g.ldw, g.K);
-    const LoaderW<4> lb{ws, ws, n0, g.N};
+    const LoaderConv<EB> la{g.a.p0, g.a_lo.p0, m0, g.M, g.T, g.Cin, g.taps, g.K};
+    const LoaderW<EB> lb{make_seg1(g.W, g.ldw, g.K), make_seg1(g.W_lo, g.ldw, g.K), n0, g.N};
     gemm_tile<Cfg>(la, lb, smem, live);
   } else {
-    Seg3 s = g.a;
+    Seg3 s = g.a, s_lo = g.a_lo;
     if (g.teacher != nullptr && g.t > 0 && g.teacher_flags[g.t - 1] != 0) {
-      // decoder.py:65-66: next input = last frame of teacher group t-1 = teacher frame t*r - 1
+      // decoder.py:65-66: next input = last frame of teacher group t-1 = teacher frame t*r - 1 (fp32 path only)
       s = make_seg1(g.teacher + (size_t)(g.t * g.r - 1) * g.d_mel, g.teacher_T * g.d_mel, g.d_mel);
+      s_lo = s;
     }
     // W is one [N, K] matrix: cut it at A's segment boundaries
     const int k0 = s.e0, k1 = s.e1 - s.e0, k2 = s.e2 - s.e1;
-    const Seg3 ws = make_seg3(g.W, g.ldw, k0, g.W + k0, g.ldw, k1, g.W + k0 + k1, g.ldw, k2);
-    const LoaderW<4> lb{ws, ws, n0, g.N};
-    const LoaderPlain<4> la{s, s, m0, g.M};
+    const char *w = static_cast<const char*>(g.W), *wl = static_cast<const char*>(g.W_lo);
+    const Seg3 ws = make_seg3(w, g.ldw, k0, w + (size_t)k0 * EB, g.ldw, k1, w + (size_t)(k0 + k1) * EB, g.ldw, k2);
+    const Seg3 wsl = make_seg3(wl, g.ldw, k0, wl + (size_t)k0 * EB, g.ldw, k1, wl + (size_t)(k0 + k1) * EB, g.ldw, k2);
+    const LoaderW<EB> lb{ws, wsl, n0, g.N};
+    const LoaderPlain<EB> la{s, s_lo, m0, g.M};
     gemm_tile<Cfg>(la, lb, smem, live);
   }
   if (!live) return;
@@ -146,9 +150,14 @@ __global__ __launch_bounds__(kGemmThreads) void gemm_rows_kernel(GemmArgs g) {
     if (m >= g.M || n >= g.N) continue;
     float v = smem[row * LDO + col];
     if (EK != EPI_BN_ISRU && g.bias != nullptr) v = add_rn(v, pre_bias[j]);
+    auto store16 = [&](float val) {  // 16-bit copies for a following 16-bit GEMM
+      const size_t o = (size_t)m * g.ldo + n;
+      if (g.out_kind == 1) split_f16(val, g.out_h[o], g.out_l[o]);
+      else if (g.out_kind == 2) reinterpret_cast<bf16*>(g.out_h)[o] = (bf16)val;
+    };
     if (EK == EPI_PLAIN) {
       g.out[(size_t)m * g.ldo + n] = v;
-      if (g.out_h != nullptr) split_f16(v, g.out_h[(size_t)m * g.ldo + n], g.out_l[(size_t)m * g.ldo + n]);
+      store16(v);
     } else if (EK == EPI_RELU_DROPOUT) {
       // modules.py:39-40: relu then dropout(p, always): kept units scaled by 1/(1-p)
       v = v > 0.f ? v : 0.f;
@@ -158,7 +167,7 @@ __global__ __launch_bounds__(kGemmThreads) void gemm_rows_kernel(GemmArgs g) {
         v = philox_keep(g.seed, (uint32_t)g.t, (uint32_t)g.layer, (uint32_t)m, (uint32_t)n) ? mul_rn(v, g.keep_scale) : 0.f;
       }
       g.out[(size_t)m * g.ldo + n] = v;
-      if (g.out_h != nullptr) split_f16(v, g.out_h[(size_t)m * g.ldo + n], g.out_l[(size_t)m * g.ldo + n]);
+      store16(v);
     } else if (EK == EPI_PROJ) {
       const int nm = g.r * g.d_mel;
       if (n < nm) {
@@ -176,7 +185,8 @@ __global__ __launch_bounds__(kGemmThreads) void gemm_rows_kernel(GemmArgs g) {
     } else if (EK == EPI_BN_ISRU) {
       // modules.py:181 isru(BatchNorm1d(conv(x))) with eval-mode BN as x*alpha + beta
       v = isru(add_rn(mul_rn(v, pre_bias[j]), pre_res[j]));
-      g.out[(size_t)m * g.ldo + n] = v;
+      if (g.out != nullptr) g.out[(size_t)m * g.ldo + n] = v;
+      store16(v);
     } else if (EK == EPI_RESIDUAL) {
       // modules.py:184 x + fc_out(...)
       g.out[(size_t)m * g.ldo + n] = add_rn(pre_res[j], v);
@@ -184,13 +194,14 @@ __global__ __launch_bounds__(kGemmThreads) void gemm_rows_kernel(GemmArgs g) {
   }
 }
 
-template <int AK, int EK>
+template <int AK, int EK, int PREC>
 static void launch_gemm_cfg(const GemmArgs& a, hipStream_t st) {
   // Pick the tile so the grid covers the 256 CUs when it can; small M uses 32x32 tiles
-  // with the four waves splitting K.
+  // with the four MFMA waves splitting K.
   const long tiles_big = (long)((a.M + 63) / 64) * ((a.N + 63) / 64);
-  if (a.M >= 64 && tiles_big >= 512) {
-    using Cfg = TileCfg<2, 2, 1, 4>;  // 64 KiB ring: two workgroups per CU on the big (postnet) grids
+  if (PREC != PREC_F32 || (a.M >= 64 && tiles_big >= 512)) {
+    // 64x64 tiles; ring: fp32 4 x 16 KiB, bf16 5 x 16 KiB, split-fp16 4 x 32 KiB
+    using Cfg = TileCfg<2, 2, 1, (PREC == PREC_BF16 ? 5 : 4), PREC>;
     dim3 grid((a.N + Cfg::BN - 1) / Cfg::BN, (a.M + Cfg::BM - 1) / Cfg::BM);
     hipLaunchKernelGGL((gemm_rows_kernel<Cfg, AK, EK>), grid, dim3(kGemmThreads), 0, st, a);
   } else {
@@ -200,14 +211,21 @@ static void launch_gemm_cfg(const GemmArgs& a, hipStream_t st) {
   }
 }
 
+template <int AK, int EK>
+static void launch_gemm_prec(const GemmArgs& a, hipStream_t st) {
+  if (a.prec == PREC_F16S) return launch_gemm_cfg<AK, EK, PREC_F16S>(a, st);
+  if (a.prec == PREC_BF16) return launch_gemm_cfg<AK, EK, PREC_BF16>(a, st);
+  return launch_gemm_cfg<AK, EK, PREC_F32>(a, st);
+}
+
 void launch_gemm(const GemmArgs& a, AKind ak, EpiKind ek, hipStream_t st) {
   if (a.M <= 0 || a.N <= 0) return;
-  if (ak == A_CONV && ek == EPI_BN_ISRU) return launch_gemm_cfg<A_CONV, EPI_BN_ISRU>(a, st);
+  if (ak == A_CONV && ek == EPI_BN_ISRU) return launch_gemm_prec<A_CONV, EPI_BN_ISRU>(a, st);
   switch (ek) {
-    case EPI_PLAIN: return launch_gemm_cfg<A_PLAIN, EPI_PLAIN>(a, st);
-    case EPI_RELU_DROPOUT: return launch_gemm_cfg<A_PLAIN, EPI_RELU_DROPOUT>(a, st);
-    case EPI_PROJ: return launch_gemm_cfg<A_PLAIN, EPI_PROJ>(a, st);
-    case EPI_RESIDUAL: return launch_gemm_cfg<A_PLAIN, EPI_RESIDUAL>(a, st);
+    case EPI_PLAIN: return launch_gemm_cfg<A_PLAIN, EPI_PLAIN, PREC_F32>(a, st);
+    case EPI_RELU_DROPOUT: return launch_gemm_cfg<A_PLAIN, EPI_RELU_DROPOUT, PREC_F32>(a, st);
+    case EPI_PROJ: return launch_gemm_cfg<A_PLAIN, EPI_PROJ, PREC_F32>(a, st);
+    case EPI_RESIDUAL: return launch_gemm_prec<A_PLAIN, EPI_RESIDUAL>(a, st);
     default: return;
   }
 }
@@ -579,6 +597,15 @@ __global__ void split_kernel(const float* src, f16* hi, f16* lo, size_t n) {
 void launch_split(const float* src, f16* hi, f16* lo, size_t n, hipStream_t st) {
   if (n == 0 || src == nullptr) return;
   hipLaunchKernelGGL(split_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, src, hi, lo, n);
+}
+
+__global__ void to_bf16_kernel(const float* src, bf16* dst, size_t n) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) dst[i] = (bf16)src[i];
+}
+void launch_to_bf16(const float* src, void* dst, size_t n, hipStream_t st) {
+  if (n == 0 || src == nullptr) return;
+  hipLaunchKernelGGL(to_bf16_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, src, static_cast<bf16*>(dst), n);
 }
 
 __global__ void conv_transpose_kernel(const float* w, float* out, int Co, int Ci, int k) {

@@ -1,10 +1,12 @@
-// LDS-tiled GEMM main loop for gfx950, two arithmetic modes behind one data path:
+// LDS-tiled GEMM main loop for gfx950, three arithmetic modes behind one data path:
 //
 //   PREC_F32   exact fp32 on v_mfma_f32_32x32x2_f32 (a k-ordered fmaf chain per output);
 //   PREC_F16S  split-fp16: every operand is two fp16 planes (hi, lo*2^11, see common.h) and
 //              a*b = ah*bh + (ah*bl + al*bh)*2^-11 on v_mfma_f32_32x32x16_f16 with fp32
 //              accumulation - 3 MFMAs of 32 cycles per 16 k instead of 8 of 64 cycles,
-//              ~2^-22 relative per product.
+//              ~2^-22 relative per product;
+//   PREC_BF16  one bf16 plane per operand on v_mfma_f32_32x32x16_bf16, fp32 accumulation
+//              (8 significand bits per operand: for the Postnet's "bf16 MFMA" configuration).
 //
 //   C[BM x BN] = sum_k A[row, k] * B[col, k]        (both operands K-contiguous,
 //                                                   i.e. activations [M, K] and
@@ -40,7 +42,6 @@
 
 namespace ttsdec {
 
-enum Prec { PREC_F32 = 0, PREC_F16S = 1 };
 
 template <int WM, int WN, int WK, int S, int PREC = PREC_F32, int AUXB = 0>
 struct TileCfg {
@@ -49,7 +50,7 @@ struct TileCfg {
   static_assert(S >= 3, "ring needs at least 3 stages (fragment reads run one tile ahead of the MFMAs)");
   static constexpr int kPrec = PREC;
   static constexpr int EB = (PREC == PREC_F32) ? 4 : 2;      // element bytes
-  static constexpr int NP = (PREC == PREC_F32) ? 1 : 2;      // planes per operand
+  static constexpr int NP = (PREC == PREC_F16S) ? 2 : 1;     // planes per operand
   static constexpr int BM = 32 * WM;
   static constexpr int BN = 32 * WN;
   static constexpr int ROWB = 128 * WK;                      // bytes per tile row per plane
@@ -309,15 +310,15 @@ __device__ __forceinline__ void gemm_tile(const LoaderA& la, const LoaderB& lb, 
         if (t + 1 < nk_run) tile_step(std::integral_constant<int, 1>{});
       }
     } else {
-      // split-fp16: per k16-step s one 16-byte fragment of each of A_hi, A_lo, B_hi, B_lo
+      // 16-bit planes: per k16-step s one 16-byte fragment of A_hi (, A_lo), B_hi (, B_lo)
       int aoff[4], boff[4];
 #pragma unroll
       for (int s = 0; s < 4; ++s) {
         const int c16 = wk * 8 + s * 2 + half;
         aoff[s] = arow * ROWB + ((c16 ^ Cfg::swz(arow)) << 4);
-        boff[s] = 2 * Cfg::kPlaneABytes + brow * ROWB + ((c16 ^ Cfg::swz(brow)) << 4);
+        boff[s] = NP * Cfg::kPlaneABytes + brow * ROWB + ((c16 ^ Cfg::swz(brow)) << 4);
       }
-      f16x8 ah[2][4], al[2][4], bh[2][4], bl[2][4];
+      f16x8 ah[2][4], al[2][4], bh[2][4], bl[2][4];  // (bf16 data travels in the same 16-byte registers)
       auto read_frags = [&](auto buf_c) {
         constexpr int buf = decltype(buf_c)::value;
         const char* st = lds + rstage * Cfg::kStageBytes;
@@ -325,9 +326,11 @@ __device__ __forceinline__ void gemm_tile(const LoaderA& la, const LoaderB& lb, 
 #pragma unroll
         for (int s = 0; s < 4; ++s) {
           ah[buf][s] = *reinterpret_cast<const f16x8*>(st + aoff[s]);
-          al[buf][s] = *reinterpret_cast<const f16x8*>(st + Cfg::kPlaneABytes + aoff[s]);
           bh[buf][s] = *reinterpret_cast<const f16x8*>(st + boff[s]);
-          bl[buf][s] = *reinterpret_cast<const f16x8*>(st + Cfg::kPlaneBBytes + boff[s]);
+          if constexpr (NP == 2) {
+            al[buf][s] = *reinterpret_cast<const f16x8*>(st + Cfg::kPlaneABytes + aoff[s]);
+            bl[buf][s] = *reinterpret_cast<const f16x8*>(st + Cfg::kPlaneBBytes + boff[s]);
+          }
         }
       };
       auto tile_step = [&](auto cur_c) {
@@ -339,9 +342,14 @@ __device__ __forceinline__ void gemm_tile(const LoaderA& la, const LoaderB& lb, 
         if (dbg != 4) {
 #pragma unroll
           for (int s = 0; s < 4; ++s) {
-            acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[cur][s], bh[cur][s], acc, 0, 0, 0);
-            acc2 = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[cur][s], bl[cur][s], acc2, 0, 0, 0);
-            acc2 = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[cur][s], bh[cur][s], acc2, 0, 0, 0);
+            if constexpr (Cfg::kPrec == PREC_F16S) {
+              acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[cur][s], bh[cur][s], acc, 0, 0, 0);
+              acc2 = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[cur][s], bl[cur][s], acc2, 0, 0, 0);
+              acc2 = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[cur][s], bh[cur][s], acc2, 0, 0, 0);
+            } else {
+              acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, ah[cur][s]),
+                                                            __builtin_bit_cast(bf16x8, bh[cur][s]), acc, 0, 0, 0);
+            }
           }
         }
       };
@@ -354,8 +362,10 @@ __device__ __forceinline__ void gemm_tile(const LoaderA& la, const LoaderB& lb, 
         tile_step(std::integral_constant<int, 0>{});
         if (t + 1 < nk_run) tile_step(std::integral_constant<int, 1>{});
       }
+      if constexpr (Cfg::kPrec == PREC_F16S) {
 #pragma unroll
-      for (int i = 0; i < 16; ++i) acc[i] = fmaf(acc2[i], 1.0f / kSplitScale, acc[i]);
+        for (int i = 0; i < 16; ++i) acc[i] = fmaf(acc2[i], 1.0f / kSplitScale, acc[i]);
+      }
     }
   }
   __syncthreads();

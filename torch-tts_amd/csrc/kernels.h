@@ -13,10 +13,13 @@ struct GemmArgs {
   // A_CONV: implicit im2col of x [Bc*T, Cin] with `taps` taps centred on the row's frame:
   //         A[m][tap*Cin + c] = x[b, t + tap - taps/2, c] (zero outside [0, T)).
   Seg3 a;
+  Seg3 a_lo;            // second plane of A (split-fp16 lo), same shape; 16-bit modes only
   int T, Cin, taps;
-  // B operand: W [N, K] row-major with leading dimension ldw.
-  const float* W;
+  // B operand: W [N, K] row-major with leading dimension ldw (element type per `prec`).
+  const void* W;
+  const void* W_lo;     // split-fp16 lo plane of W
   int ldw;
+  int prec;             // PREC_F32 / PREC_F16S / PREC_BF16 (gemm_tile.h): element type of A and W
   int M, N, K;
   // epilogue operands
   const float* bias;   // [N] or nullptr
@@ -25,8 +28,12 @@ struct GemmArgs {
   const float* resid;  // EPI_RESIDUAL: out = resid[m, n] + acc
   float* out;          // [M, ldo]
   int ldo;
-  f16* out_h;          // optional split-fp16 planes of `out` (same shape), or nullptr
+  // optional 16-bit copies of the result for a following 16-bit GEMM (same shape as out):
+  // out_kind 1: split-fp16 planes out_h / out_l; out_kind 2: one bf16 plane in out_h.
+  // `out` itself may be nullptr when only the 16-bit form is consumed.
+  f16* out_h;
   f16* out_l;
+  int out_kind;
   // EPI_RELU_DROPOUT
   int dropout_mode;
   const uint8_t* masks;  // [M, N] keep-mask of this (step, layer)
@@ -123,6 +130,7 @@ void launch_advance(Ctrl* ctrl, int n_slots, hipStream_t st);
 void launch_add_vec(const float* a, const float* b, float* out, int n, hipStream_t st);
 void launch_copy(const float* src, float* dst, size_t n, hipStream_t st);
 void launch_split(const float* src, f16* hi, f16* lo, size_t n, hipStream_t st);
+void launch_to_bf16(const float* src, void* dst, size_t n, hipStream_t st);
 void launch_conv_transpose(const float* w /*[Co,Ci,k]*/, float* out /*[Co,k,Ci]*/, int Co, int Ci, int k, hipStream_t st);
 void launch_bn_fold(const float* gamma, const float* betap, const float* mean, const float* var, float eps, float* alpha,
                     float* beta, int n, hipStream_t st);

@@ -28,7 +28,8 @@ class MelPostnet(nn.Module):
         )
         self.fc_out = nn.Linear(dim_hidden, dim_mel, bias=False)
         self.dim_mel, self.dim_hidden, self.kernel_size, self.num_layers = dim_mel, dim_hidden, kernel_size, num_layers
-        # "f32": exact fp32 matrix instructions; "bf16": bf16 MFMA with fp32 accumulate
+        # "f32": exact fp32 matrix instruction; "split_f16": hi/lo fp16 planes (fp32-grade, faster);
+        # "bf16": bf16 operands with fp32 accumulate (~3 significant digits)
         self.precision = "f32"
         self._engines = EngineCache()
 
@@ -59,5 +60,5 @@ class MelPostnet(nn.Module):
             raise NotImplementedError("MelPostnet on the HIP path is eval-mode only (BatchNorm running stats, no dropout)")
         if torch.is_grad_enabled() and (x.requires_grad or any(p.requires_grad for p in self.parameters())):
             raise NotImplementedError("autograd through the postnet is outside the HIP hot path: call under torch.no_grad()")
-        prec = {"f32": _lib.POSTNET_F32, "bf16": _lib.POSTNET_BF16}[self.precision]
+        prec = {"f32": _lib.POSTNET_F32, "bf16": _lib.POSTNET_BF16, "split_f16": _lib.POSTNET_SPLIT_F16}[self.precision]
         return self.engine(x.device).postnet(x.detach().to(torch.float32).contiguous(), prec)
