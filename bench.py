@@ -182,6 +182,15 @@ def main():
     dom = max(per_kernel, key=lambda k: per_kernel[k]["ms"])
     step_ms_kernels = sum(v["ms"] for v in per_kernel.values())
     decode_step_ms = dec_ms / args.steps / NF
+    # HBM traffic of the dominant kernel from the PMC passes (cannot be collected inside this
+    # process; see profiles/r01_traffic.json for the command and the gfx950 FETCH_SIZE correction)
+    traffic = None
+    try:
+        tj = json.load(open(os.path.join(ROOT, "profiles", "r01_traffic.json")))
+        if args.precision == "split_f16" and B == 256 and L == 120:
+            traffic = tj["per_launch"].get(dom, {}).get("hbm_bytes")
+    except Exception:
+        traffic = None
     roofline = {
         "bound": "hbm",
         "kernel": dom,
@@ -189,7 +198,7 @@ def main():
         "peak": HBM_PEAK_GBS,
         "unit": "GB/s",
         "frac": round(per_kernel[dom]["GBps"] / HBM_PEAK_GBS, 4),
-        "traffic": None,
+        "traffic": traffic,
         "alg_bytes_per_launch": per_kernel[dom]["alg_bytes"],
         "kernel_ms": per_kernel[dom]["ms"],
         "decode_step": {

@@ -241,6 +241,8 @@ enum Node { N_P0, N_P1, N_A, N_A1, N_A2, N_Q, N_T, N_D, N_D1, N_D2, N_J };
 constexpr int kKernelsPerStep = 7;
 const char* const kKernelNames[kKernelsPerStep] = {"prenet0", "prenet1", "lstm_att", "query", "attention", "lstm_dec", "proj"};
 const Node kProfileNodes[kKernelsPerStep] = {N_P0, N_P1, N_A, N_Q, N_T, N_D, N_J};
+// TTSDEC_PROFILE_PARTS=1 times the partial-gate nodes instead of the whole cells
+const Node kProfileNodesParts[kKernelsPerStep] = {N_A1, N_A2, N_A, N_D1, N_T, N_D, N_D2};
 
 // split-fp16 needs every K segment to be whole 16-byte columns of fp16 (multiples of 8)
 bool split_ok(const ttsdec_dims& d) { return !((d.d_pre | d.d_ctx | d.h_att | d.h_dec) & 7); }
@@ -883,10 +885,12 @@ int ttsdec_profile_step(ttsdec_handle* h, const float* memory, int B, int L, int
   hipEvent_t e0, e1;
   HIP_TRY(h, hipEventCreate(&e0));
   HIP_TRY(h, hipEventCreate(&e1));
+  const char* pe = getenv("TTSDEC_PROFILE_PARTS");
+  const Node* nodes = (pe && atoi(pe)) ? kProfileNodesParts : kProfileNodes;
   for (int k = 0; k < kKernelsPerStep; ++k) {
-    for (int i = 0; i < 3; ++i) launch_node(h, sb, io, kProfileNodes[k], st);  // warm
+    for (int i = 0; i < 3; ++i) launch_node(h, sb, io, nodes[k], st);  // warm
     HIP_TRY(h, hipEventRecord(e0, st));
-    for (int i = 0; i < iters; ++i) launch_node(h, sb, io, kProfileNodes[k], st);
+    for (int i = 0; i < iters; ++i) launch_node(h, sb, io, nodes[k], st);
     HIP_TRY(h, hipEventRecord(e1, st));
     HIP_TRY(h, hipEventSynchronize(e1));
     float ms = 0.f;
