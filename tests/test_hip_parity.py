@@ -235,6 +235,87 @@ def test_split_f16_handles_tiny_and_large_values(H):
     H.assert_close(w, ow, RTOL, ATOL, "w")
 
 
+@pytest.mark.parametrize("prec", ["f32", "split_f16"])
+def test_two_frames_per_step_r2(H, prec):
+    """decoder.r = 2 (config-rdh/sandra use r=2): fc_mel emits two frames, only the last is fed
+    back (decoder.py:48), fc_stop emits two logits; teacher frame index is t*r-1 (decoder.py:41-42,66)."""
+    dims = O.DecoderDims(d_mel=24, r=2, d_pre=32, d_ctx=64, h_att=64, h_dec=96)
+    wts = O.random_decoder_weights(dims, seed=8, nonzero_init_state=True)
+    B, L, T = 6, 14, 9
+    mem = O.synthetic_memory(B, L, dims.d_ctx, lengths=[14, 14, 3, 9, 14, 1])
+    masks = O.synthetic_masks(T, B, dims.d_pre, seed=5)
+    oy, os_, ow = O.decode(wts, dims, mem, max_steps=T - 1, masks=masks)
+    assert oy.shape == (B, T * 2, 24) and os_.shape == (B, T * 2, 1)
+    dec = H.make_decoder(dims, wts)
+    dec.precision = prec
+    y, s, w, _ = H.run_decoder_with_masks(dec, mem, masks, max_steps=T - 1)
+    H.assert_close(y, oy, RTOL, ATOL, "y")
+    H.assert_close(s, os_, RTOL, ATOL, "s")
+    H.assert_close(w, ow, RTOL, ATOL, "w")
+    # teacher forcing, r = 2, 17 teacher frames -> 8 steps (the odd frame is dropped, decoder.py:41)
+    g = torch.Generator().manual_seed(3)
+    x = torch.randn(B, 17, 24, generator=g) * 0.5
+    flags = [True, False, True, True, False, True, True]
+    oy2, os2, ow2 = O.decode(wts, dims, mem, masks=masks, x=x, teacher_flags=flags)
+    assert oy2.shape[1] == 16
+    y2, s2, w2, _ = H.run_decoder_with_masks(dec, mem, masks, x=x, flags=flags)
+    H.assert_close(y2, oy2, RTOL, ATOL, "y teacher r=2")
+    H.assert_close(w2, ow2, RTOL, ATOL, "w teacher r=2")
+
+
+@pytest.mark.parametrize("B,L,T", [(2, 1, 5), (3, 2, 6), (4, 301, 8), (33, 77, 5)])
+def test_memory_length_edges(H, B, L, T):
+    """L = 1 (the only column is the absorbing one, e = 1e4), L = 2, and L longer than the
+    LJSpeech case; B = 33 leaves a ragged last row tile."""
+    dims = O.DecoderDims()
+    wts = O.random_decoder_weights(dims, seed=11)
+    mem = O.synthetic_memory(B, L, dims.d_ctx, seed=2)
+    masks = O.synthetic_masks(T, B, dims.d_pre, seed=9)
+    oy, os_, ow = O.decode(wts, dims, mem, max_steps=T - 1, masks=masks)
+    for prec in ("f32", "split_f16"):
+        dec = H.make_decoder(dims, wts)
+        dec.precision = prec
+        y, s, w, _ = H.run_decoder_with_masks(dec, mem, masks, max_steps=T - 1)
+        H.assert_close(y, oy, RTOL, ATOL, f"y {prec}")
+        H.assert_close(w, ow, RTOL, ATOL, f"w {prec}")
+        assert torch.equal(w.argmax(-1), ow.argmax(-1))
+    if L == 1:
+        assert float((ow - 1.0).abs().max()) == 0.0  # all mass stays on the single, absorbing column
+
+
+def test_c_abi_rejects_bad_arguments(H):
+    """Error behaviour at the boundary: codes, never crashes."""
+    from torch_tts_amd import _lib
+
+    dims = O.DecoderDims(d_mel=8, d_pre=16, d_ctx=32, h_att=32, h_dec=32)
+    dec = H.make_decoder(dims, O.random_decoder_weights(dims, seed=1))
+    dev = torch.device("cuda:0")
+    eng = dec.engine(dev)
+    mem = torch.zeros(2, 5, 32, device=dev)
+    y = torch.empty(2, 4, 8, device=dev)
+    s = torch.empty(2, 4, device=dev)
+    w = torch.empty(2, 4, 5, device=dev)
+    t_out = torch.zeros(2, dtype=torch.int32, device=dev)
+    kw = dict(stop_threshold=-2.0, check_stop=True, seed=0, teacher=None, teacher_flags=None, y=y, s=s, w=w, t_out=t_out)
+    with pytest.raises(_lib.TtsdecError) as ei:  # masks mode without masks
+        eng.decode(mem, t_begin=0, n_steps=4, dropout_mode=_lib.DROPOUT_MASKS, masks=None, **kw)
+    assert ei.value.code == _lib.ERR_INVALID_ARG
+    with pytest.raises(_lib.TtsdecError) as ei:  # odd t_begin
+        eng.decode(mem, t_begin=3, n_steps=1, dropout_mode=_lib.DROPOUT_OFF, masks=None, **kw)
+    assert ei.value.code == _lib.ERR_INVALID_ARG
+    with pytest.raises(_lib.TtsdecError) as ei:  # more steps than the output buffers hold
+        eng.decode(mem, t_begin=0, n_steps=5, dropout_mode=_lib.DROPOUT_OFF, masks=None, **kw)
+    assert ei.value.code == _lib.ERR_INVALID_ARG
+    lib = _lib.load()
+    ws = eng.workspace(2, 5)
+    rc = lib.ttsdec_decode(eng._h, mem.data_ptr(), 2, 5, 0, 4, 4, -2.0, 1, 0, None, 0, None, 0, None, y.data_ptr(), s.data_ptr(),
+                           w.data_ptr(), t_out.data_ptr(), ws.data_ptr(), 128, None)  # workspace too small
+    assert rc == _lib.ERR_WORKSPACE
+    eng.decode(mem, t_begin=0, n_steps=4, dropout_mode=_lib.DROPOUT_OFF, masks=None, **kw)  # and a good call still works
+    torch.cuda.synchronize()
+    assert t_out.tolist() == [4, 0]
+
+
 def test_postnet_ljspeech_dims_vs_oracle(H):
     pw = O.random_postnet_weights(80, 512, 3, seed=9)
     g = torch.Generator().manual_seed(2)
