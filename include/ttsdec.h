@@ -59,16 +59,35 @@ typedef struct ttsdec_dims {
   int32_t postnet_hidden;  /* model.postnet.dim_hidden            (512) */
   int32_t postnet_kernel;  /* MelPostnet kernel_size              (5)   */
   float bn_eps;            /* nn.BatchNorm1d eps                  (1e-5)*/
+  int32_t cell_type;       /* TTSDEC_CELL_*: which decoder cell of decoder_cell.py                  */
+  int32_t d_pre_hidden;    /* width of PreNet layer 0; 0 = d_pre (Taco2ProdDecoderCell, decoder_cell.py:152);
+                            * Taco2DecoderCell uses 128 (decoder_cell.py:74-76)                      */
+  int32_t postnet_type;    /* TTSDEC_POSTNET_TYPE_*                                                  */
 } ttsdec_dims;
+
+/* Decoder cells (tacotron/tacotron.py:171-176 picks by model.decoder.type). */
+enum {
+  TTSDEC_CELL_TACO2PROD = 0, /* Taco2ProdDecoderCell (decoder_cell.py:143-195): LJSpeech config.  h_att / h_dec are the
+                              * attention-rnn and decoder-rnn widths.                                               */
+  TTSDEC_CELL_TACO2 = 1      /* Taco2DecoderCell (decoder_cell.py:66-140): rdh / sandra / template configs.  Context from
+                              * the previous weights feeds both stacked LSTMs (h_att = dim_rnn[0], h_dec = dim_rnn[1]);
+                              * query and projection read cat[h0, h1, zeros]; no ctx in the state.                   */
+};
+/* Postnets (tacotron/tacotron.py:199-214 picks by model.postnet.type). */
+enum {
+  TTSDEC_POSTNET_TYPE_MEL = 0,  /* MelPostnet  (modules/modules.py:155-184)                                            */
+  TTSDEC_POSTNET_TYPE_MEL2 = 1  /* MelPostnet2 (modules/modules.py:187-216): postnet_layers residual blocks of
+                                 * Conv1dFix-BN-LeakyReLU x2 + Conv1dFix (mps_fixes.py:6-29)                           */
+};
 
 typedef struct ttsdec_handle ttsdec_handle;
 
 /* Order of the source tensors handed to ttsdec_pack_weights: the reference's
  * state-dict order.  Postnet entries repeat per layer. */
 enum {
-  TTSDEC_W_PRE0_W = 0, /* decoder.decoder_cell.pre_net.layers.0.weight [d_pre, d_mel]        */
-  TTSDEC_W_PRE0_B,     /* ...layers.0.bias   [d_pre]                                          */
-  TTSDEC_W_PRE1_W,     /* ...layers.1.weight [d_pre, d_pre]                                   */
+  TTSDEC_W_PRE0_W = 0, /* decoder.decoder_cell.pre_net.layers.0.weight [d_pre_hidden, d_mel] */
+  TTSDEC_W_PRE0_B,     /* ...layers.0.bias   [d_pre_hidden]                                   */
+  TTSDEC_W_PRE1_W,     /* ...layers.1.weight [d_pre, d_pre_hidden]                            */
   TTSDEC_W_PRE1_B,     /* ...layers.1.bias   [d_pre]                                          */
   TTSDEC_W_QUERY_W,    /* decoder_cell.attention_module.query_layer.weight [d_ctx, h_att]     */
   TTSDEC_W_ATT_IH,     /* decoder_cell.attention_rnn.weight_ih [4*h_att, d_pre+d_ctx]         */
@@ -87,6 +106,9 @@ enum {
   TTSDEC_W_MEL_B,      /* decoder.fc_mel.bias    [r*d_mel]                                    */
   TTSDEC_W_STOP_W,     /* decoder.fc_stop.weight [r, h_dec+d_ctx]                             */
   TTSDEC_W_STOP_B,     /* decoder.fc_stop.bias   [r]                                          */
+  /* TTSDEC_CELL_TACO2 uses the same slots: QUERY_W is [d_ctx, h_att+h_dec+d_ctx]; ATT_* / DEC_* are
+   * decoder_rnn_list.0 / .1 ([4*h_att, d_pre+d_ctx], [4*h_dec, h_att+d_ctx]); MEL_W / STOP_W have
+   * h_att+h_dec+d_ctx columns. */
   TTSDEC_W_DECODER_COUNT, /* = 21; postnet tensors follow:                                   */
   /* per layer i (5 each): postnet.conv.i.0.weight [C_out, C_in, k], conv.i.1.weight [C_out],
    * conv.i.1.bias, conv.i.1.running_mean, conv.i.1.running_var; then postnet.fc_out.weight
@@ -170,8 +192,9 @@ size_t ttsdec_workspace_bytes(const ttsdec_handle* h, int B, int L);
  *                 utterance's stop logit < threshold is the last one produced
  *                 (inclusive, batch-global); later steps of this and following
  *                 calls are skipped.  check_stop = 0 disables it (teacher mode).
- *   dropout_mode  TTSDEC_DROPOUT_*; masks [n_steps, 2, B, d_pre] uint8 for MASKS
- *                 (relative to t_begin); seed for PHILOX
+ *   dropout_mode  TTSDEC_DROPOUT_*; masks for MASKS: per step (relative to t_begin) the keep-mask
+ *                 of PreNet layer 0 [B, d_pre_hidden] followed by layer 1 [B, d_pre], uint8
+ *                 (= [n_steps, 2, B, d_pre] when the two widths are equal); seed for PHILOX
  *   teacher       optional [B, teacher_T, d_mel] ground-truth frames (decoder.py:38-42);
  *   teacher_flags optional uint8 [>= t_begin+n_steps]: flags[t-1] != 0 => the input of
  *                 step t (t >= 1) is teacher frame t*r-1 instead of the model's own
@@ -200,6 +223,8 @@ int ttsdec_postnet(ttsdec_handle* h, const float* y, int B, int T, int precision
  * Not needed by Decoder.forward; provided for API completeness.  State tensors are
  * updated in place: w [B,L], ctx [B,d_ctx], h_att/c_att [B,h_att], h_dec/c_dec [B,h_dec];
  * x [B, d_mel] is the input frame; x_dec [B, h_dec+d_ctx] receives cat[h_dec, ctx].
+ * TTSDEC_CELL_TACO2 (decoder_cell.py:110-140): ctx is output only (the context the LSTMs consumed,
+ * = bmm(w_in, memory)); x_dec is [B, h_att+h_dec+d_ctx] = cat[h0, h1, zeros].
  * masks: [2, B, d_pre] uint8 or NULL per dropout_mode; step only keys the Philox stream. */
 int ttsdec_cell_step(ttsdec_handle* h, const float* x, const float* memory, int B, int L, float* w, float* ctx,
                      float* h_att, float* c_att, float* h_dec, float* c_dec, int dropout_mode, const uint8_t* masks,

@@ -38,3 +38,23 @@ def golden():
         "cases": {k: torch.from_numpy(cases[k]) for k in cases.files},
         "meta": meta,
     }
+
+
+@pytest.fixture(scope="session")
+def golden_taco2():
+    """Golden vectors of Taco2DecoderCell (r=2) + MelPostnet2 from the reference (make_golden_taco2.py)."""
+    import json
+
+    import numpy as np
+    import torch
+
+    model = np.load(os.path.join(GOLDEN, "taco2_model.npz"))
+    cases = np.load(os.path.join(GOLDEN, "taco2_cases.npz"))
+    meta = json.load(open(os.path.join(GOLDEN, "taco2_meta.json")))
+    return {
+        "dec": {k[4:]: torch.from_numpy(model[k]) for k in model.files if k.startswith("dec/")},
+        "post": {k[5:]: torch.from_numpy(model[k]) for k in model.files if k.startswith("post/")},
+        "memory": torch.from_numpy(model["memory"]),
+        "cases": {k: torch.from_numpy(cases[k]) for k in cases.files},
+        "meta": meta,
+    }

@@ -16,6 +16,21 @@ def make_decoder(dims: O.DecoderDims, wts, device="cuda:0", stop_threshold=-2.0)
     return dec.to(device).eval()
 
 
+def make_taco2_decoder(dims: O.DecoderDims, wts, device="cuda:0", stop_threshold=-2.0):
+    cell = T.Taco2DecoderCell(dims.d_ctx, dims.d_mel, dims.r, [dims.h_att, dims.h_dec], dim_pre=dims.d_pre, p_zoneout=dims.p_zoneout)
+    dec = T.Decoder(cell, dims.r, dims.d_mel, stop_threshold=stop_threshold)
+    missing, unexpected = dec.load_state_dict(wts, strict=False)
+    assert not unexpected, unexpected
+    assert all(k.endswith("attention_module.bias") for k in missing), missing
+    return dec.to(device).eval()
+
+
+def flat_masks(m0, m1):
+    """Per step: layer-0 mask [B, 128] then layer-1 mask [B, d_pre], flattened (include/ttsdec.h)."""
+    T_ = m0.shape[0]
+    return torch.cat([m0.reshape(T_, -1), m1.reshape(T_, -1)], dim=1).contiguous()
+
+
 def make_postnet(d_mel, hidden, layers, wts, device="cuda:0", k=5):
     pn = T.MelPostnet(d_mel, dim_hidden=hidden, kernel_size=k, num_layers=layers)
     missing, unexpected = pn.load_state_dict(wts, strict=False)

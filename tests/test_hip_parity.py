@@ -316,6 +316,86 @@ def test_c_abi_rejects_bad_arguments(H):
     assert t_out.tolist() == [4, 0]
 
 
+# --------------------------------------------------------------------------
+# Taco2DecoderCell (config-rdh / sandra / template), golden vectors from the reference
+# --------------------------------------------------------------------------
+def _t2dims(g):
+    d = g["meta"]["dims"]
+    return O.DecoderDims(d_mel=d["d_mel"], r=d["r"], d_pre=d["d_pre"], d_ctx=d["d_ctx"], h_att=d["h_att"], h_dec=d["h_dec"])
+
+
+@pytest.mark.parametrize("prec", ["f32", "split_f16"])
+def test_taco2_cell_golden(golden_taco2, H, prec):
+    g, c = golden_taco2, golden_taco2["cases"]
+    dec = H.make_taco2_decoder(_t2dims(g), g["dec"])
+    dec.precision = prec
+    y, s, w, fired = H.run_decoder_with_masks(dec, g["memory"], H.flat_masks(c["infer/m0"], c["infer/m1"]), max_steps=8)
+    assert not fired and y.shape == c["infer/y"].shape
+    H.assert_close(y, c["infer/y"], RTOL, ATOL, "y")
+    H.assert_close(s, c["infer/s"], RTOL, ATOL, "s")
+    H.assert_close(w, c["infer/w"], RTOL, ATOL, "w")
+    assert torch.equal(w.argmax(-1), c["infer/w"].argmax(-1))
+    y2, s2, w2, _ = H.run_decoder_with_masks(dec, g["memory"], H.flat_masks(c["teacher/m0"], c["teacher/m1"]), x=c["teacher/x"])
+    H.assert_close(y2, c["teacher/y"], RTOL, ATOL, "y teacher")
+    H.assert_close(w2, c["teacher/w"], RTOL, ATOL, "w teacher")
+
+
+def test_taco2_cell_module_forward_reference_rng_and_cell_step(golden_taco2, H):
+    """Decoder.forward around Taco2DecoderCell under the reference's seed, and the bare cell step."""
+    g, c = golden_taco2, golden_taco2["cases"]
+    dims = _t2dims(g)
+    dec = H.make_taco2_decoder(dims, g["dec"])
+    mem = g["memory"].cuda()
+    with torch.no_grad():
+        torch.manual_seed(g["meta"]["seeds"]["infer"])
+        y, s, w = dec(mem, None, None, 8)
+    H.assert_close(y.cpu(), c["infer/y"], RTOL, ATOL, "y")
+    H.assert_close(w.cpu(), c["infer/w"], RTOL, ATOL, "w")
+    # one bare cell step vs the oracle
+    cell = dec.decoder_cell
+    B, L, _ = g["memory"].shape
+    gen = torch.Generator().manual_seed(4)
+    x = torch.randn(B, 2, dims.d_mel, generator=gen)
+    w0 = torch.rand(B, L, generator=gen)
+    w0 = w0 / w0.sum(1, keepdim=True)
+    hc = [(torch.randn(B, H_, generator=gen) * 0.3, torch.randn(B, H_, generator=gen) * 0.3) for H_ in (dims.h_att, dims.h_dec)]
+    torch.manual_seed(9)
+    m0 = torch.empty(B, 128).bernoulli_(0.5).to(torch.uint8)
+    m1 = torch.empty(B, dims.d_pre).bernoulli_(0.5).to(torch.uint8)
+    ox, octx, (ow, ohc) = O.taco2_cell_step(x[:, -1], (w0, hc), g["memory"], g["dec"], dims, [m0, m1])
+    with torch.no_grad():
+        torch.manual_seed(9)
+        xd, ctx, (w1, hc1) = cell(x.cuda(), (w0.cuda(), [(a.cuda(), b.cuda()) for a, b in hc]), mem, None)
+    H.assert_close(xd.cpu(), ox, RTOL, ATOL, "x_dec")
+    H.assert_close(ctx.cpu(), octx, RTOL, ATOL, "ctx")
+    H.assert_close(w1.cpu(), ow, RTOL, ATOL, "w")
+    H.assert_close(hc1[1][0].cpu(), ohc[1][0], RTOL, ATOL, "h1")
+
+
+def test_taco2_cell_rdh_dims_vs_oracle(H):
+    """config-rdh.yaml dims (r=1, dim_rnn [1024, 1024], dim_pre 256, encoder 512) at B=64."""
+    dims = O.DecoderDims(d_mel=80, r=1, d_pre=256, d_ctx=512, h_att=1024, h_dec=1024)
+    wts = O.random_taco2_weights(dims, seed=2)
+    B, L, T = 64, 90, 12
+    mem = O.synthetic_memory(B, L, dims.d_ctx, seed=8)
+    g = torch.Generator().manual_seed(1)
+    m0 = (torch.rand(T, B, 128, generator=g) >= 0.5).to(torch.uint8)
+    m1 = (torch.rand(T, B, 256, generator=g) >= 0.5).to(torch.uint8)
+
+    class M:
+        def __getitem__(self, t):
+            return [m0[t], m1[t]]
+    oy, os_, ow = O.taco2_decode(wts, dims, mem, max_steps=T - 1, masks=M())
+    for prec in ("f32", "split_f16"):
+        dec = H.make_taco2_decoder(dims, wts)
+        dec.precision = prec
+        y, s, w, _ = H.run_decoder_with_masks(dec, mem, H.flat_masks(m0, m1), max_steps=T - 1)
+        H.assert_close(y, oy, RTOL, ATOL, f"y {prec}")
+        H.assert_close(s, os_, RTOL, ATOL, f"s {prec}")
+        H.assert_close(w, ow, RTOL, ATOL, f"w {prec}")
+        assert torch.equal(w.argmax(-1), ow.argmax(-1))
+
+
 def test_postnet_ljspeech_dims_vs_oracle(H):
     pw = O.random_postnet_weights(80, 512, 3, seed=9)
     g = torch.Generator().manual_seed(2)

@@ -193,7 +193,14 @@ def test_lengths_to_mask_and_build_tacotron_surface():
     model2 = pickle.loads(pickle.dumps(model))  # nn.DataParallel / checkpointing need this
     assert set(model2.state_dict().keys()) == set(model.state_dict().keys())
     copy.deepcopy(model)
-    cfg["model"]["decoder"]["type"] = "tacotron2"
+    cfg["model"]["decoder"]["type"] = "tacotron2"  # rdh / sandra / template configs
+    m2 = T.build_tacotron(cfg)
+    assert isinstance(m2.decoder.decoder_cell, T.Taco2DecoderCell)
+    assert m2.decoder.decoder_cell.dim_output == 16 + 12 + 16 and m2.decoder.fc_mel.in_features == 44
+    assert m2.decoder.decoder_cell.pre_net.layers[0].out_features == 128
+    w0, hc = m2.decoder.decoder_cell.initial_state(2, 5, torch.float32, "cpu")
+    assert w0.shape == (2, 5) and len(hc) == 2 and hc[1][0].shape == (2, 12)
+    cfg["model"]["decoder"]["type"] = "tacotron1"  # dead code in the reference
     with pytest.raises(NotImplementedError):
         T.build_tacotron(cfg)
 

@@ -123,3 +123,47 @@ def test_attention_properties_long_run():
     assert bool((pos[:, 1:] >= pos[:, :-1] - 1e-6).all())
     for k in range(5):
         assert float(w[:, k, k + 2 :].abs().max()) == 0.0
+
+
+# ---- Taco2DecoderCell (r = 2) and MelPostnet2 ----
+class _LayerMasks:
+    """masks[step][layer]: the two PreNet layers of this cell have different widths (128, d_pre)."""
+
+    def __init__(self, m0, m1):
+        self.m0, self.m1 = m0, m1
+
+    def __getitem__(self, t):
+        return [self.m0[t], self.m1[t]]
+
+
+def _taco2_dims(g):
+    d = g["meta"]["dims"]
+    return O.DecoderDims(d_mel=d["d_mel"], r=d["r"], d_pre=d["d_pre"], d_ctx=d["d_ctx"], h_att=d["h_att"], h_dec=d["h_dec"])
+
+
+def test_taco2_cell_decode_and_postnet2(golden_taco2):
+    g, c = golden_taco2, golden_taco2["cases"]
+    dims = _taco2_dims(g)
+    y, s, w = O.taco2_decode(g["dec"], dims, g["memory"], max_steps=8, masks=_LayerMasks(c["infer/m0"], c["infer/m1"]))
+    assert y.shape == c["infer/y"].shape  # 9 steps x r=2 frames
+    _close(y, c["infer/y"])
+    _close(s, c["infer/s"])
+    _close(w, c["infer/w"])
+    _close(O.mel_postnet2(y, g["post"], 2), c["infer/y_post"], 2e-6)
+    y2, s2, w2 = O.taco2_decode(g["dec"], dims, g["memory"], masks=_LayerMasks(c["teacher/m0"], c["teacher/m1"]), x=c["teacher/x"])
+    _close(y2, c["teacher/y"])
+    _close(w2, c["teacher/w"])
+    _close(O.mel_postnet2(c["unit/post_y"], g["post"], 2), c["unit/post_out"], 2e-6)
+
+
+def test_conv1d_fix_pairs_flat_weight_with_rolled_copies():
+    """mps_fixes.py:22-29 is NOT torch's conv1d on the same weight tensor: column n*C_in + c of the
+    flat weight meets x[c, t + pad - n].  It equals conv1d with the re-indexed, tap-flipped weight."""
+    g = torch.Generator().manual_seed(0)
+    x = torch.randn(2, 6, 11, generator=g)
+    w = torch.randn(4, 6, 5, generator=g)
+    ours = O.conv1d_fix(x, w, 2)
+    w_eff = w.reshape(4, 5, 6).permute(0, 2, 1).flip(2)  # [o, n, c] -> [o, c, tap = 4 - n]
+    ref = torch.nn.functional.conv1d(x, w_eff, padding=2)
+    assert float((ours - ref).abs().max()) < 1e-5
+    assert float((ours - torch.nn.functional.conv1d(x, w, padding=2)).abs().max()) > 1e-2

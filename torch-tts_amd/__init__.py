@@ -4,12 +4,12 @@ Import as ``torch_tts_amd`` (the directory name ``torch-tts_amd`` is not a Pytho
 identifier; the sibling ``torch_tts_amd/`` package aliases it)."""
 from . import _lib  # noqa: F401
 from .decoder import Decoder
-from .decoder_cell import LSTMZoneoutCell, PreNet, StepwiseMonotonicAttention, Taco2ProdDecoderCell
+from .decoder_cell import LSTMZoneoutCell, PreNet, StepwiseMonotonicAttention, Taco2DecoderCell, Taco2ProdDecoderCell
 from .engine import Engine, EngineDims
 from .postnet import MelPostnet
 from .tacotron import Encoder2, Tacotron, build_tacotron, lengths_to_mask
 
 __all__ = [
-    "Decoder", "Taco2ProdDecoderCell", "PreNet", "LSTMZoneoutCell", "StepwiseMonotonicAttention", "MelPostnet",
+    "Decoder", "Taco2ProdDecoderCell", "Taco2DecoderCell", "PreNet", "LSTMZoneoutCell", "StepwiseMonotonicAttention", "MelPostnet",
     "Tacotron", "Encoder2", "build_tacotron", "lengths_to_mask", "Engine", "EngineDims",
 ]

@@ -15,6 +15,8 @@ ERR_INVALID_ARG, ERR_DIMS, ERR_HIP, ERR_NOT_BOUND, ERR_WORKSPACE, ERR_DEVICE = -
 DROPOUT_OFF, DROPOUT_MASKS, DROPOUT_PHILOX = 0, 1, 2
 POSTNET_F32, POSTNET_BF16, POSTNET_SPLIT_F16 = 0, 1, 2
 PREC_F32, PREC_SPLIT_F16 = 0, 1
+CELL_TACO2PROD, CELL_TACO2 = 0, 1
+POSTNET_TYPE_MEL, POSTNET_TYPE_MEL2 = 0, 1
 W_DECODER_COUNT = 21
 W_POSTNET_PER_LAYER = 5
 
@@ -54,6 +56,9 @@ class Dims(C.Structure):
         ("postnet_hidden", C.c_int32),
         ("postnet_kernel", C.c_int32),
         ("bn_eps", C.c_float),
+        ("cell_type", C.c_int32),
+        ("d_pre_hidden", C.c_int32),
+        ("postnet_type", C.c_int32),
     ]
 
 

@@ -65,6 +65,14 @@ struct ttsdec_handle {
 
 namespace {
 
+// derived sizes that depend on the cell type
+inline int pre_hidden(const ttsdec_dims& d) { return d.d_pre_hidden > 0 ? d.d_pre_hidden : d.d_pre; }
+inline bool is_taco2(const ttsdec_dims& d) { return d.cell_type == TTSDEC_CELL_TACO2; }
+inline int query_ld(const ttsdec_dims& d) { return is_taco2(d) ? d.h_att + d.h_dec + d.d_ctx : d.h_att; }
+inline int query_k(const ttsdec_dims& d) { return is_taco2(d) ? d.h_att + d.h_dec : d.h_att; }
+inline int proj_ld(const ttsdec_dims& d) { return is_taco2(d) ? d.h_att + d.h_dec + d.d_ctx : d.h_dec + d.d_ctx; }
+inline int proj_k(const ttsdec_dims& d) { return is_taco2(d) ? d.h_att + d.h_dec : d.h_dec + d.d_ctx; }
+
 BlobLayout make_blob_layout(const ttsdec_dims& d) {
   BlobLayout L;
   memset(&L, 0, sizeof(L));
@@ -74,12 +82,12 @@ BlobLayout make_blob_layout(const ttsdec_dims& d) {
     off = align_up(off + n, kAlignFloats);
     return o;
   };
-  const size_t Ha = d.h_att, Hd = d.h_dec, D = d.d_ctx, P = d.d_pre, Mel = d.d_mel, R = d.r;
-  L.pre0_w = take(P * Mel);
-  L.pre0_b = take(P);
-  L.pre1_w = take(P * P);
+  const size_t Ha = d.h_att, Hd = d.h_dec, D = d.d_ctx, P = d.d_pre, Mel = d.d_mel, R = d.r, Ph = pre_hidden(d);
+  L.pre0_w = take(Ph * Mel);
+  L.pre0_b = take(Ph);
+  L.pre1_w = take(P * Ph);
   L.pre1_b = take(P);
-  L.wq = take(D * Ha);
+  L.wq = take(D * (size_t)query_ld(d));
   L.att_ih = take(4 * Ha * (P + D));
   L.att_hh = take(4 * Ha * Ha);
   L.att_b = take(4 * Ha);
@@ -95,7 +103,7 @@ BlobLayout make_blob_layout(const ttsdec_dims& d) {
   L.c0a = take(Ha);
   L.h0d = take(Hd);
   L.c0d = take(Hd);
-  L.proj_w = take((R * Mel + R) * (Hd + D));
+  L.proj_w = take((R * Mel + R) * (size_t)proj_ld(d));
   L.proj_b = take(R * Mel + R);
   size_t cin = Mel;
   for (int i = 0; i < d.postnet_layers; ++i) {
@@ -126,7 +134,7 @@ WsLayout make_ws_layout(const ttsdec_dims& d, int B, int Lm) {
   W.ctrl = off;
   off += align_up(sizeof(Ctrl), 256);
   const size_t b = (size_t)B;
-  W.xpre0 = take(b * d.d_pre);
+  W.xpre0 = take(b * pre_hidden(d));
   W.xpre = take(b * d.d_pre);
   W.ctx = take(b * d.d_ctx);
   W.h_att[0] = take(b * d.h_att);
@@ -157,6 +165,9 @@ int check_dims(const ttsdec_dims& d) {
   for (int x : v)
     if (x <= 0 || (x & 3)) return TTSDEC_ERR_DIMS;
   if (d.r < 1 || d.d_ctx > 4096) return TTSDEC_ERR_DIMS;
+  if (d.d_pre_hidden < 0 || (d.d_pre_hidden & 3)) return TTSDEC_ERR_DIMS;
+  if (d.cell_type != TTSDEC_CELL_TACO2PROD && d.cell_type != TTSDEC_CELL_TACO2) return TTSDEC_ERR_DIMS;
+  if (d.postnet_type != TTSDEC_POSTNET_TYPE_MEL && d.postnet_type != TTSDEC_POSTNET_TYPE_MEL2) return TTSDEC_ERR_DIMS;
   if (d.postnet_layers < 0 || d.postnet_layers > kMaxPostnetLayers) return TTSDEC_ERR_DIMS;
   if (d.postnet_layers > 0) {
     if (d.postnet_hidden <= 0 || (d.postnet_hidden & 3)) return TTSDEC_ERR_DIMS;
@@ -246,6 +257,9 @@ const Node kProfileNodesParts[kKernelsPerStep] = {N_A1, N_A2, N_A, N_D1, N_T, N_
 
 // split-fp16 needs every K segment to be whole 16-byte columns of fp16 (multiples of 8)
 bool split_ok(const ttsdec_dims& d) { return !((d.d_pre | d.d_ctx | d.h_att | d.h_dec) & 7); }
+enum { kSerialNodes = 7 };
+// launch order of one step: the Prod cell attends between its two LSTMs, the Taco2 cell after both
+const Node* step_order(const ttsdec_dims& d);
 int lstm_prec(const ttsdec_handle* h) { return (h->precision == TTSDEC_PREC_SPLIT_F16 && split_ok(h->d)) ? 1 : 0; }
 
 void launch_node(const ttsdec_handle* h, const StepBufs& sb, const StepIo& io, Node node, hipStream_t st) {
@@ -265,19 +279,23 @@ void launch_node(const ttsdec_handle* h, const StepBufs& sb, const StepIo& io, N
       const int layer = node == N_P0 ? 0 : 1;
       GemmArgs g;
       memset(&g, 0, sizeof(g));
+      const int Ph = pre_hidden(d);
       if (layer == 0) {
         g.a = make_seg1(sb.ynext, d.d_mel, d.d_mel);
         g.W = blob + bl.pre0_w; g.ldw = d.d_mel; g.K = d.d_mel; g.bias = blob + bl.pre0_b;
-        g.out = sb.xpre0;
+        g.out = sb.xpre0; g.N = Ph; g.ldo = Ph;
       } else {
-        g.a = make_seg1(sb.xpre0, P, P);
-        g.W = blob + bl.pre1_w; g.ldw = P; g.K = P; g.bias = blob + bl.pre1_b;
-        g.out = sb.xpre;
+        g.a = make_seg1(sb.xpre0, Ph, Ph);
+        g.W = blob + bl.pre1_w; g.ldw = Ph; g.K = Ph; g.bias = blob + bl.pre1_b;
+        g.out = sb.xpre; g.N = P; g.ldo = P;
         if (prec) { g.out_h = sb.xpre_h; g.out_l = sb.xpre_l; g.out_kind = 1; }
       }
-      g.M = B; g.N = P; g.ldo = P;
+      g.M = B;
       g.dropout_mode = io.dropout_mode;
-      g.masks = io.masks ? io.masks + (size_t)layer * B * P : nullptr;
+      // masks of one step: layer 0 [B, Ph] then layer 1 [B, P]
+      g.mask_step_stride = (size_t)B * (Ph + P);
+      g.mask_layer_off = layer ? (size_t)B * Ph : 0;
+      g.masks = io.masks ? io.masks + g.mask_layer_off : nullptr;
       g.seed = io.seed; g.layer = layer; g.keep_scale = keep_scale;
       g.r = d.r; g.d_mel = d.d_mel;
       g.ctrl = ctrl; g.slot = io.slot; g.t = io.t;
@@ -323,8 +341,10 @@ void launch_node(const ttsdec_handle* h, const StepBufs& sb, const StepIo& io, N
     case N_Q: {
       GemmArgs g;
       memset(&g, 0, sizeof(g));
-      g.a = make_seg1(sb.h_att[1 - p], Ha, Ha);
-      g.W = blob + bl.wq; g.ldw = Ha; g.K = Ha; g.M = B; g.N = D; g.out = sb.q; g.ldo = D;
+      // query_layer input: h_att (Prod, decoder_cell.py:188) or cat[h0, h1, zeros] (Taco2, :126)
+      if (is_taco2(d)) g.a = make_seg2(sb.h_att[1 - p], Ha, Ha, sb.h_dec[1 - p], Hd, Hd);
+      else g.a = make_seg1(sb.h_att[1 - p], Ha, Ha);
+      g.W = blob + bl.wq; g.ldw = query_ld(d); g.K = query_k(d); g.M = B; g.N = D; g.out = sb.q; g.ldo = D;
       g.ctrl = ctrl; g.slot = io.slot; g.t = io.t;
       launch_gemm(g, A_PLAIN, EPI_PLAIN, st);
       break;
@@ -376,8 +396,10 @@ void launch_node(const ttsdec_handle* h, const StepBufs& sb, const StepIo& io, N
     case N_J: {
       GemmArgs g;
       memset(&g, 0, sizeof(g));
-      g.a = make_seg2(sb.h_dec[1 - p], Hd, Hd, sb.ctx, D, D);
-      g.W = blob + bl.proj_w; g.ldw = Hd + D; g.K = Hd + D; g.M = B; g.N = d.r * d.d_mel + d.r;
+      // projection input: cat[h_dec, ctx] (Prod, decoder_cell.py:192) or cat[h0, h1, zeros] (Taco2, :136)
+      if (is_taco2(d)) g.a = make_seg2(sb.h_att[1 - p], Ha, Ha, sb.h_dec[1 - p], Hd, Hd);
+      else g.a = make_seg2(sb.h_dec[1 - p], Hd, Hd, sb.ctx, D, D);
+      g.W = blob + bl.proj_w; g.ldw = proj_ld(d); g.K = proj_k(d); g.M = B; g.N = d.r * d.d_mel + d.r;
       g.bias = blob + bl.proj_b;
       g.y_out = io.y; g.s_out = io.s; g.ynext = sb.ynext; g.r = d.r; g.d_mel = d.d_mel;
       g.t_rel = io.t_rel; g.t_stride = io.t_stride; g.stop_thr = 0.f; g.check_stop = 0;
@@ -388,10 +410,16 @@ void launch_node(const ttsdec_handle* h, const StepBufs& sb, const StepIo& io, N
   }
 }
 
-// One step on a single stream, in the reference's order.
+const Node kOrderProd[kSerialNodes] = {N_P0, N_P1, N_A, N_Q, N_T, N_D, N_J};   // decoder_cell.py:185-192
+const Node kOrderTaco2[kSerialNodes] = {N_P0, N_P1, N_A, N_D, N_Q, N_T, N_J};  // decoder_cell.py:116-136
+const Node* step_order(const ttsdec_dims& d) { return is_taco2(d) ? kOrderTaco2 : kOrderProd; }
+
+// One step on a single stream, in the reference's order.  (For the Taco2 cell the attention
+// kernel at the end of step t also produces the context bmm(w_t, memory) that step t+1 starts
+// from, decoder_cell.py:118.)
 void launch_step_serial(const ttsdec_handle* h, const StepBufs& sb, const StepIo& io, hipStream_t st) {
-  const Node order[7] = {N_P0, N_P1, N_A, N_Q, N_T, N_D, N_J};
-  for (Node n : order) launch_node(h, sb, io, n, st);
+  const Node* order = step_order(h->d);
+  for (int i = 0; i < kSerialNodes; ++i) launch_node(h, sb, io, order[i], st);
 }
 
 // n_slots steps with the early partial-gate GEMMs on the side stream:
@@ -464,7 +492,7 @@ int ensure_graph(ttsdec_handle* h, const StepBufs& sb, const void* ws, int B, in
   io.B = B; io.L = L; io.use_ctrl = true;
   if (hipStreamBeginCapture(h->cap_stream, hipStreamCaptureModeRelaxed) != hipSuccess) return TTSDEC_ERR_HIP;
   int rc = TTSDEC_OK;
-  if (h->overlap) {
+  if (h->overlap && !is_taco2(h->d)) {
     rc = launch_steps_overlapped(h, sb, io, 0, kGraphSlots, h->cap_stream);
   } else {
     for (int i = 0; i < kGraphSlots; ++i) {
@@ -590,13 +618,14 @@ int ttsdec_pack_weights(ttsdec_handle* h, const float* const* src, int n_src, vo
   const ttsdec_dims& d = h->d;
   const BlobLayout& L = h->bl;
   float* b = static_cast<float*>(blob);
-  const size_t Ha = d.h_att, Hd = d.h_dec, D = d.d_ctx, P = d.d_pre, Mel = d.d_mel, R = d.r;
+  const size_t Ha = d.h_att, Hd = d.h_dec, D = d.d_ctx, P = d.d_pre, Mel = d.d_mel, R = d.r, Ph = pre_hidden(d);
+  const size_t Dp = proj_ld(d);
   HIP_TRY(h, hipMemsetAsync(blob, 0, L.total * sizeof(float), st));
-  launch_copy(src[TTSDEC_W_PRE0_W], b + L.pre0_w, P * Mel, st);
-  launch_copy(src[TTSDEC_W_PRE0_B], b + L.pre0_b, P, st);
-  launch_copy(src[TTSDEC_W_PRE1_W], b + L.pre1_w, P * P, st);
+  launch_copy(src[TTSDEC_W_PRE0_W], b + L.pre0_w, Ph * Mel, st);
+  launch_copy(src[TTSDEC_W_PRE0_B], b + L.pre0_b, Ph, st);
+  launch_copy(src[TTSDEC_W_PRE1_W], b + L.pre1_w, P * Ph, st);
   launch_copy(src[TTSDEC_W_PRE1_B], b + L.pre1_b, P, st);
-  launch_copy(src[TTSDEC_W_QUERY_W], b + L.wq, D * Ha, st);
+  launch_copy(src[TTSDEC_W_QUERY_W], b + L.wq, D * (size_t)query_ld(d), st);
   launch_copy(src[TTSDEC_W_ATT_IH], b + L.att_ih, 4 * Ha * (P + D), st);
   launch_copy(src[TTSDEC_W_ATT_HH], b + L.att_hh, 4 * Ha * Ha, st);
   if (src[TTSDEC_W_ATT_BIH] && src[TTSDEC_W_ATT_BHH])
@@ -615,8 +644,8 @@ int ttsdec_pack_weights(ttsdec_handle* h, const float* const* src, int n_src, vo
   launch_copy(src[TTSDEC_W_INIT_H1], b + L.h0d, Hd, st);
   launch_copy(src[TTSDEC_W_INIT_C1], b + L.c0d, Hd, st);
   // [fc_mel ; fc_stop] stacked on the output axis (decoder.py:13-14)
-  launch_copy(src[TTSDEC_W_MEL_W], b + L.proj_w, R * Mel * (Hd + D), st);
-  launch_copy(src[TTSDEC_W_STOP_W], b + L.proj_w + R * Mel * (Hd + D), R * (Hd + D), st);
+  launch_copy(src[TTSDEC_W_MEL_W], b + L.proj_w, R * Mel * Dp, st);
+  launch_copy(src[TTSDEC_W_STOP_W], b + L.proj_w + R * Mel * Dp, R * Dp, st);
   launch_copy(src[TTSDEC_W_MEL_B], b + L.proj_b, R * Mel, st);
   launch_copy(src[TTSDEC_W_STOP_B], b + L.proj_b + R * Mel, R, st);
   int cin = d.d_mel;
@@ -688,6 +717,7 @@ int ttsdec_decode(ttsdec_handle* h, const float* memory, int B, int L, int t_beg
     ia.ctx = sb.ctx; ia.w = sb.w[0]; ia.ynext = sb.ynext;
     ia.h_att_h = sb.h_att_h[0]; ia.h_att_l = sb.h_att_l[0]; ia.h_dec_h = sb.h_dec_h[0]; ia.h_dec_l = sb.h_dec_l[0];
     ia.ctx_h = sb.ctx_h; ia.ctx_l = sb.ctx_l;
+    ia.memory = is_taco2(d) ? memory : nullptr;
     ia.B = B; ia.L = L; ia.D = d.d_ctx; ia.Ha = d.h_att; ia.Hd = d.h_dec; ia.d_mel = d.d_mel;
     launch_init(ia, st);
   }
@@ -705,7 +735,7 @@ int ttsdec_decode(ttsdec_handle* h, const float* memory, int B, int L, int t_beg
     rc = ensure_graph(h, sb, workspace, B, L);
     if (rc != TTSDEC_OK) return rc;
     for (int done = 0; done < n_steps; done += kGraphSlots) HIP_TRY(h, hipGraphLaunch(h->gexec, st));
-  } else if (h->overlap) {
+  } else if (h->overlap && !is_taco2(h->d)) {
     rc = launch_steps_overlapped(h, sb, io, 0, n_steps, st);
     if (rc != TTSDEC_OK) return hip_fail(h, hipGetLastError(), "decode (overlapped)");
   } else {
@@ -826,16 +856,18 @@ int ttsdec_cell_step(ttsdec_handle* h, const float* x, const float* memory, int 
   const ttsdec_dims& d = h->d;
   const size_t b = (size_t)B;
   const int p = step & 1;
+  const bool t2 = is_taco2(d);
   // caller state -> workspace (the step kernels ping-pong h and w)
   launch_copy(x, sb.ynext, b * d.d_mel, st);
-  launch_copy(ctx, sb.ctx, b * d.d_ctx, st);
+  if (!t2) launch_copy(ctx, sb.ctx, b * d.d_ctx, st);
   launch_copy(w, sb.w[p], b * L, st);
   launch_copy(h_att, sb.h_att[p], b * d.h_att, st);
   launch_copy(c_att, sb.c_att, b * d.h_att, st);
   launch_copy(h_dec, sb.h_dec[p], b * d.h_dec, st);
   launch_copy(c_dec, sb.c_dec, b * d.h_dec, st);
-  if (lstm_prec(h)) {
-    launch_split(ctx, sb.ctx_h, sb.ctx_l, b * d.d_ctx, st);
+  const int prec = lstm_prec(h);
+  if (prec) {
+    if (!t2) launch_split(ctx, sb.ctx_h, sb.ctx_l, b * d.d_ctx, st);
     launch_split(h_att, sb.h_att_h[p], sb.h_att_l[p], b * d.h_att, st);
     launch_split(h_dec, sb.h_dec_h[p], sb.h_dec_l[p], b * d.h_dec, st);
   }
@@ -844,20 +876,47 @@ int ttsdec_cell_step(ttsdec_handle* h, const float* x, const float* memory, int 
   io.memory = memory; io.B = B; io.L = L; io.t = step; io.t_rel = 0; io.t_stride = 1;
   io.dropout_mode = dropout_mode; io.masks = masks; io.seed = seed;
   io.use_ctrl = false;
-  // the projection (fc_mel / fc_stop) belongs to Decoder, not to the cell
-  const Node cell_nodes[6] = {N_P0, N_P1, N_A, N_Q, N_T, N_D};
-  for (Node n : cell_nodes) launch_node(h, sb, io, n, st);
-  launch_copy(sb.ctx, ctx, b * d.d_ctx, st);
+  if (t2) {
+    // Taco2DecoderCell: ctx = bmm(w_prev, memory) first (decoder_cell.py:118), then both LSTMs,
+    // then the weight update; the ctx handed back is the one the LSTMs consumed
+    AttnArgs a;
+    memset(&a, 0, sizeof(a));
+    a.memory = memory; a.w_prev = sb.w[p]; a.w_new = sb.w[1 - p]; a.ctx = sb.ctx; a.ctx_only = 1;
+    if (prec) { a.ctx_h = sb.ctx_h; a.ctx_l = sb.ctx_l; }
+    a.B = B; a.L = L; a.D = d.d_ctx; a.t_stride = 1;
+    launch_attn(a, st);
+    const Node pre[4] = {N_P0, N_P1, N_A, N_D};
+    for (Node n : pre) launch_node(h, sb, io, n, st);
+    launch_copy(sb.ctx, ctx, b * d.d_ctx, st);
+    launch_node(h, sb, io, N_Q, st);
+    launch_node(h, sb, io, N_T, st);
+  } else {
+    // the projection (fc_mel / fc_stop) belongs to Decoder, not to the cell
+    const Node cell_nodes[6] = {N_P0, N_P1, N_A, N_Q, N_T, N_D};
+    for (Node n : cell_nodes) launch_node(h, sb, io, n, st);
+    launch_copy(sb.ctx, ctx, b * d.d_ctx, st);
+  }
   launch_copy(sb.w[1 - p], w, b * L, st);
   launch_copy(sb.h_att[1 - p], h_att, b * d.h_att, st);
   launch_copy(sb.c_att, c_att, b * d.h_att, st);
   launch_copy(sb.h_dec[1 - p], h_dec, b * d.h_dec, st);
   launch_copy(sb.c_dec, c_dec, b * d.h_dec, st);
-  // x_dec = cat[h_dec, ctx] (decoder_cell.py:192)
-  HIP_TRY(h, hipMemcpy2DAsync(x_dec, (size_t)(d.h_dec + d.d_ctx) * sizeof(float), sb.h_dec[1 - p], (size_t)d.h_dec * sizeof(float),
-                              (size_t)d.h_dec * sizeof(float), b, hipMemcpyDeviceToDevice, st));
-  HIP_TRY(h, hipMemcpy2DAsync(x_dec + d.h_dec, (size_t)(d.h_dec + d.d_ctx) * sizeof(float), sb.ctx, (size_t)d.d_ctx * sizeof(float),
-                              (size_t)d.d_ctx * sizeof(float), b, hipMemcpyDeviceToDevice, st));
+  if (t2) {
+    // x_dec = cat[h0, h1, zeros_like(ctx)] (decoder_cell.py:136)
+    const size_t ld = (size_t)(d.h_att + d.h_dec + d.d_ctx) * sizeof(float);
+    HIP_TRY(h, hipMemsetAsync(x_dec, 0, ld * b, st));
+    HIP_TRY(h, hipMemcpy2DAsync(x_dec, ld, sb.h_att[1 - p], (size_t)d.h_att * sizeof(float), (size_t)d.h_att * sizeof(float), b,
+                                hipMemcpyDeviceToDevice, st));
+    HIP_TRY(h, hipMemcpy2DAsync(x_dec + d.h_att, ld, sb.h_dec[1 - p], (size_t)d.h_dec * sizeof(float),
+                                (size_t)d.h_dec * sizeof(float), b, hipMemcpyDeviceToDevice, st));
+  } else {
+    // x_dec = cat[h_dec, ctx] (decoder_cell.py:192)
+    const size_t ld = (size_t)(d.h_dec + d.d_ctx) * sizeof(float);
+    HIP_TRY(h, hipMemcpy2DAsync(x_dec, ld, sb.h_dec[1 - p], (size_t)d.h_dec * sizeof(float), (size_t)d.h_dec * sizeof(float), b,
+                                hipMemcpyDeviceToDevice, st));
+    HIP_TRY(h, hipMemcpy2DAsync(x_dec + d.h_dec, ld, sb.ctx, (size_t)d.d_ctx * sizeof(float), (size_t)d.d_ctx * sizeof(float), b,
+                                hipMemcpyDeviceToDevice, st));
+  }
   return check_launch(h, "cell_step");
 }
 
@@ -886,7 +945,7 @@ int ttsdec_profile_step(ttsdec_handle* h, const float* memory, int B, int L, int
   HIP_TRY(h, hipEventCreate(&e0));
   HIP_TRY(h, hipEventCreate(&e1));
   const char* pe = getenv("TTSDEC_PROFILE_PARTS");
-  const Node* nodes = (pe && atoi(pe)) ? kProfileNodesParts : kProfileNodes;
+  const Node* nodes = (pe && atoi(pe)) ? kProfileNodesParts : kProfileNodes;  // (names stay in Prod order)
   for (int k = 0; k < kKernelsPerStep; ++k) {
     for (int i = 0; i < 3; ++i) launch_node(h, sb, io, nodes[k], st);  // warm
     HIP_TRY(h, hipEventRecord(e0, st));

@@ -80,7 +80,7 @@ __global__ __launch_bounds__(kGemmThreads) void gemm_rows_kernel(GemmArgs g) {
     if (EK == EPI_RELU_DROPOUT) {
       g.dropout_mode = c->dropout_mode;
       g.seed = c->seed;
-      g.masks = c->masks ? c->masks + ((size_t)now.t_rel * 2 + g.layer) * g.M * g.N : nullptr;
+      g.masks = c->masks ? c->masks + (size_t)now.t_rel * g.mask_step_stride + g.mask_layer_off : nullptr;
       if (g.layer == 0) {
         g.teacher = c->teacher;
         g.teacher_T = c->teacher_T;
@@ -392,7 +392,8 @@ __global__ __launch_bounds__(kAttnThreads) void attn_kernel(AttnArgs g) {
 #pragma unroll
   for (int j = 0; j < NJ; ++j) {
     const int c4 = lane + 64 * j;
-    qv[j] = (c4 < D4) ? *reinterpret_cast<const float4*>(g.q + (size_t)b * D + c4 * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
+    qv[j] = (c4 < D4 && !g.ctx_only) ? *reinterpret_cast<const float4*>(g.q + (size_t)b * D + c4 * 4)
+                                     : make_float4(0.f, 0.f, 0.f, 0.f);  // ctx_only: no query, energies unused
   }
   auto load_row = [&](int l, float4 (&r)[NJ]) {
 #pragma unroll
@@ -447,9 +448,10 @@ __global__ __launch_bounds__(kAttnThreads) void attn_kernel(AttnArgs g) {
           const float p0 = isru_sigmoid(en);            // attention.py:118
           const float wl = wprev[l];
           const float w0 = mul_rn(wl, p0);                      // :119
-          const float wn = (l > 0) ? add_rn(w0, w1_prev) : w0;  // :122-123
+          float wn = (l > 0) ? add_rn(w0, w1_prev) : w0;        // :122-123
           w1_prev = mul_rn(wl, sub_rn(1.0f, p0));               // :120
-          if (lane == 0) {
+          if (g.ctx_only) wn = wl;
+          if (lane == 0 && !g.ctx_only) {
             wnew[l] = wn;
             if (wout) wout[l] = wn;
           }
@@ -510,11 +512,10 @@ __global__ void init_state_kernel(InitArgs g) {
     if (g.h_dec_h != nullptr) split_f16(g.h0_dec[i % g.Hd], g.h_dec_h[i], g.h_dec_l[i]);
   }
   if (i < (size_t)g.B * g.D) {
-    g.ctx[i] = 0.f;
-    if (g.ctx_h != nullptr) {
-      g.ctx_h[i] = (f16)0.0f;
-      g.ctx_l[i] = (f16)0.0f;
-    }
+    // w_0 is one-hot at position 0, so bmm(w_0, memory) is memory[:, 0, :]
+    const float c0 = g.memory ? g.memory[(i / g.D) * (size_t)g.L * g.D + (i % g.D)] : 0.f;
+    g.ctx[i] = c0;
+    if (g.ctx_h != nullptr) split_f16(c0, g.ctx_h[i], g.ctx_l[i]);
   }
   if (i < (size_t)g.B * g.L) g.w[i] = (i % g.L == 0) ? 1.0f : 0.f;
   if (i < (size_t)g.B * g.d_mel) g.ynext[i] = 0.f;

@@ -37,6 +37,7 @@ struct GemmArgs {
   // EPI_RELU_DROPOUT
   int dropout_mode;
   const uint8_t* masks;  // [M, N] keep-mask of this (step, layer)
+  size_t mask_step_stride, mask_layer_off;  // ctrl mode: masks = ctrl->masks + t_rel*stride + off
   uint64_t seed;
   int layer;
   float keep_scale;  // 1 / (1 - p)
@@ -94,6 +95,7 @@ struct AttnArgs {
   float* w_out;         // [B, t_stride, L] (row t_rel) or nullptr
   float* ctx;           // [B, D]
   f16 *ctx_h, *ctx_l;   // optional split-fp16 planes of ctx
+  int ctx_only;         // 1: no weight update, just ctx = sum_l w_prev[l] * memory[l] (decoder_cell.py:118)
   int B, L, D, t_rel, t_stride;
   Ctrl* ctrl;  // != nullptr: memory, w_out, t_rel, t_stride come from *ctrl
   int slot;
@@ -109,6 +111,7 @@ struct InitArgs {
   float* w;                                        // [B, L]
   float* ynext;                                    // [B, d_mel]
   f16 *h_att_h, *h_att_l, *h_dec_h, *h_dec_l, *ctx_h, *ctx_l;  // split planes of the initial state
+  const float* memory;  // != nullptr: ctx_0 = bmm(w_0, memory) = memory[:, 0, :] (Taco2DecoderCell, decoder_cell.py:118)
   int B, L, D, Ha, Hd, d_mel;
 };
 void launch_init(const InitArgs& a, hipStream_t st);

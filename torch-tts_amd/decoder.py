@@ -84,7 +84,8 @@ class Decoder(nn.Module):
             mode = _lib.DROPOUT_MASKS
             stream = MaskStream(B, self.decoder_cell.dim_pre, self.decoder_cell.pre_net.p_dropout,
                                 p_no_forcing=p_no_forcing if x is not None else None,
-                                teacher_steps=total_steps if x is not None else None)
+                                teacher_steps=total_steps if x is not None else None,
+                                d_pre_hidden=getattr(self.decoder_cell, "dim_pre_hidden", None))
         elif self.dropout_source == "philox":
             mode, stream = _lib.DROPOUT_PHILOX, None
         elif self.dropout_source == "off":

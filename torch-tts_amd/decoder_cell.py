@@ -63,6 +63,7 @@ class Taco2ProdDecoderCell(nn.Module):
         dim_att_hidden, dim_dec_hidden = dim_rnn[0], dim_rnn[1]
         self.dim_output = dim_dec_hidden + dim_ctx
         self.dim_ctx, self.dim_mel, self.r, self.dim_pre = dim_ctx, dim_mel, r, dim_pre
+        self.dim_pre_hidden = dim_pre
         self.p_zoneout = p_zoneout
 
         self.pre_net = PreNet(dim_mel, dim_pre, always_dropout=True, dim_hidden=dim_pre)
@@ -151,3 +152,94 @@ class Taco2ProdDecoderCell(nn.Module):
         )
         self._step_counter += 1
         return x_dec, ctx, (w, ctx, ((h_att, c_att), (h_dec, c_dec)))
+
+
+class Taco2DecoderCell(nn.Module):
+    """Drop-in for the reference's ``decoder_cell.Taco2DecoderCell`` (tacotron/decoder_cell.py:66-140),
+    the cell of config-rdh / config-sandra / config_template: context from the PREVIOUS attention
+    weights feeds two stacked zoneout LSTMs, the attention input and the cell output are
+    cat[h0, h1, zeros_like(ctx)].  State: (w, [(h0, c0), (h1, c1)])."""
+
+    def __init__(self, dim_ctx, dim_mel, r, dim_rnn, dim_pre=128, dim_att=128, p_zoneout=0.1):
+        super().__init__()
+        if len(dim_rnn) != 2:
+            raise ValueError("Taco2DecoderCell.forward indexes exactly two LSTM layers (decoder_cell.py:126)")
+        self.dim_output = sum(dim_rnn) + dim_ctx
+        self.dim_ctx, self.dim_mel, self.r, self.dim_pre = dim_ctx, dim_mel, r, dim_pre
+        self.dim_pre_hidden = 128  # decoder_cell.py:74-76
+        self.p_zoneout = p_zoneout
+        self.pre_net = PreNet(dim_mel, dim_pre, always_dropout=True, p_dropout=0.5, dim_hidden=128)
+        self.attention_module = StepwiseMonotonicAttention(sum(dim_rnn) + dim_ctx, dim_ctx)
+        rnn_dims = [dim_pre] + list(dim_rnn)
+        self.decoder_rnn_list = nn.ModuleList(
+            [LSTMZoneoutCell(d_in + dim_ctx, d_h, p_zoneout=p_zoneout) for d_in, d_h in zip(rnn_dims[:-1], rnn_dims[1:])]
+        )
+        self.initial_decoder_h = nn.ParameterList([nn.Parameter(torch.zeros(1, d)) for d in dim_rnn])
+        self.initial_decoder_c = nn.ParameterList([nn.Parameter(torch.zeros(1, d)) for d in dim_rnn])
+        self.dropout_source = "reference_rng"
+        self.dropout_seed = 0
+        self._step_counter = 0
+        self._engines = EngineCache()
+
+    def weight_tensors(self) -> List[Optional[torch.Tensor]]:
+        pn, at = self.pre_net, self.attention_module
+        r0, r1 = self.decoder_rnn_list[0], self.decoder_rnn_list[1]
+        return [
+            pn.layers[0].weight, pn.layers[0].bias, pn.layers[1].weight, pn.layers[1].bias,
+            at.query_layer.weight,
+            r0.weight_ih, r0.weight_hh, r0.bias_ih, r0.bias_hh,
+            r1.weight_ih, r1.weight_hh, r1.bias_ih, r1.bias_hh,
+            self.initial_decoder_h[0], self.initial_decoder_h[1], self.initial_decoder_c[0], self.initial_decoder_c[1],
+        ]
+
+    def engine_dims(self) -> EngineDims:
+        return EngineDims(
+            d_mel=self.dim_mel, r=self.r, d_pre=self.dim_pre, d_ctx=self.dim_ctx,
+            h_att=self.decoder_rnn_list[0].hidden_size, h_dec=self.decoder_rnn_list[1].hidden_size,
+            p_zoneout=float(self.p_zoneout or 0.0), p_dropout=float(self.pre_net.p_dropout),
+            cell_type=_lib.CELL_TACO2, d_pre_hidden=self.dim_pre_hidden,
+        )
+
+    def initial_state(self, batch_size, memory_size, dtype, device):
+        """(w_0 one-hot at position 0, [(h, c) per LSTM]) - decoder_cell.py:96-108."""
+        w_0 = torch.zeros(batch_size, memory_size, dtype=dtype, device=device)
+        w_0[:, 0] = 1.0
+        h_dec_0 = [
+            (h.to(dtype=dtype, device=device).expand(batch_size, -1), c.to(dtype=dtype, device=device).expand(batch_size, -1))
+            for h, c in zip(self.initial_decoder_h, self.initial_decoder_c)
+        ]
+        return w_0, h_dec_0
+
+    def forward(self, x, dec_state, memory, mmask):
+        """Returns (x_dec, ctx_att, (w, h_dec)) like decoder_cell.py:110-140.  Inference only."""
+        if not memory.is_cuda:
+            raise RuntimeError("Taco2DecoderCell runs on the HIP path only: move the module and inputs to a ROCm device")
+        if torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters()):
+            raise NotImplementedError(
+                "autograd through the decoder cell is outside the HIP hot path (forward only): call under torch.no_grad()"
+            )
+        w_in, h_dec = dec_state[0], dec_state[1]
+        B = memory.shape[0]
+        eng = self._engines.get(self.engine_dims(), memory.device)
+        eng.ensure_packed(self.weight_tensors() + [None, None, None, None])
+        f = lambda t: t.to(torch.float32).contiguous().clone()
+        w = f(w_in)
+        h0, c0, h1, c1 = f(h_dec[0][0]), f(h_dec[0][1]), f(h_dec[1][0]), f(h_dec[1][1])
+        ctx = torch.empty(B, self.dim_ctx, dtype=torch.float32, device=memory.device)
+        xin = x.flatten(1, 2)[:, -self.dim_mel :].to(torch.float32).contiguous() if x.dim() == 3 else x.contiguous()
+        masks = None
+        if self.dropout_source == "reference_rng":
+            p = self.pre_net.p_dropout
+            m0 = torch.empty(B, self.dim_pre_hidden).bernoulli_(1.0 - p).to(torch.uint8)
+            m1 = torch.empty(B, self.dim_pre).bernoulli_(1.0 - p).to(torch.uint8)
+            masks = torch.cat([m0.reshape(-1), m1.reshape(-1)]).to(memory.device)
+            mode = _lib.DROPOUT_MASKS
+        elif self.dropout_source == "philox":
+            mode = _lib.DROPOUT_PHILOX
+        else:
+            mode = _lib.DROPOUT_OFF
+        x_dec = eng.cell_step(
+            xin, memory.to(torch.float32).contiguous(), w, ctx, h0, c0, h1, c1, mode, masks, self.dropout_seed, self._step_counter
+        )
+        self._step_counter += 1
+        return x_dec, ctx, (w, [(h0, c0), (h1, c1)])

@@ -28,12 +28,24 @@ class EngineDims:
     postnet_hidden: int = 512
     postnet_kernel: int = 5
     bn_eps: float = 1e-5
+    cell_type: int = 0      # _lib.CELL_*
+    d_pre_hidden: int = 0   # 0 = d_pre
+    postnet_type: int = 0   # _lib.POSTNET_TYPE_*
 
     def to_c(self) -> _lib.Dims:
         return _lib.Dims(
             self.d_mel, self.r, self.d_pre, self.d_ctx, self.h_att, self.h_dec, self.p_zoneout, self.p_dropout,
             self.postnet_layers, self.postnet_hidden, self.postnet_kernel, self.bn_eps,
+            self.cell_type, self.d_pre_hidden, self.postnet_type,
         )
+
+    @property
+    def pre_hidden(self) -> int:
+        return self.d_pre_hidden or self.d_pre
+
+    @property
+    def cell_output(self) -> int:
+        return self.h_att + self.h_dec + self.d_ctx if self.cell_type == _lib.CELL_TACO2 else self.h_dec + self.d_ctx
 
 
 def _ptr(t: Optional[Tensor]) -> Optional[int]:
@@ -220,7 +232,7 @@ class Engine:
     def cell_step(self, x, memory, w, ctx, h_att, c_att, h_dec, c_dec, dropout_mode, masks, seed, step) -> Tensor:
         _require_device(memory, "memory")
         B, L, _ = memory.shape
-        x_dec = torch.empty(B, self.dims.h_dec + self.dims.d_ctx, dtype=torch.float32, device=self.device)
+        x_dec = torch.empty(B, self.dims.cell_output, dtype=torch.float32, device=self.device)
         ws = self.workspace(B, L)
         with torch.cuda.device(self.device):
             rc = self._lib.ttsdec_cell_step(

@@ -9,7 +9,7 @@ import torch
 import torch.nn as nn
 
 from .decoder import Decoder
-from .decoder_cell import Taco2ProdDecoderCell
+from .decoder_cell import Taco2DecoderCell, Taco2ProdDecoderCell
 from .postnet import MelPostnet
 
 
@@ -105,11 +105,10 @@ def build_tacotron(config):
     "tacotron2" -> MelPostnet)."""
     text_config, audio_config = config["text"], config["audio"]
     decoder_config, encoder_config = config["model"]["decoder"], config["model"]["encoder"]
-    if decoder_config["type"] in ("tacotron1", "tacotron2"):
-        raise NotImplementedError(
-            f"decoder type {decoder_config['type']!r}: only the Taco2ProdDecoderCell path is built on HIP so far (SURVEY.md 8f)"
-        )
-    decoder_cell = Taco2ProdDecoderCell(
+    if decoder_config["type"] == "tacotron1":
+        raise NotImplementedError("Taco1DecoderCell is dead code in the reference (SURVEY.md section 2) and is not provided")
+    decoder_cell_class = Taco2DecoderCell if decoder_config["type"] == "tacotron2" else Taco2ProdDecoderCell
+    decoder_cell = decoder_cell_class(
         encoder_config["dim_out"], audio_config["num_mels"], r=decoder_config["r"], dim_rnn=decoder_config["dim_rnn"],
         dim_pre=decoder_config["dim_pre"], dim_att=decoder_config["dim_att"],
     )
