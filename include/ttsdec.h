@@ -113,7 +113,11 @@ enum {
   /* per layer i (5 each): postnet.conv.i.0.weight [C_out, C_in, k], conv.i.1.weight [C_out],
    * conv.i.1.bias, conv.i.1.running_mean, conv.i.1.running_var; then postnet.fc_out.weight
    * [d_mel, hidden].  Total = 21 + 5*postnet_layers + 1 (or 21 when postnet_layers == 0). */
-  TTSDEC_W_POSTNET_PER_LAYER = 5
+  TTSDEC_W_POSTNET_PER_LAYER = 5,
+  /* TTSDEC_POSTNET_TYPE_MEL2, per layer i (11 each, no fc_out): postnet.layers.i.1.weight [hidden, d_mel, k],
+   * layers.i.2.{weight,bias,running_mean,running_var}, layers.i.5.weight [hidden, hidden, k],
+   * layers.i.6.{weight,bias,running_mean,running_var}, layers.i.9.weight [d_mel, hidden, k]. */
+  TTSDEC_W_POSTNET2_PER_LAYER = 11
 };
 
 /* Prenet dropout modes (the reference's dropout is always on, modules.py:40). */
@@ -214,7 +218,8 @@ int ttsdec_decode(ttsdec_handle* h, const float* memory, int B, int L, int t_beg
 size_t ttsdec_postnet_workspace_bytes(const ttsdec_handle* h, int B, int T);
 
 /* MelPostnet.forward in eval mode (tacotron/modules/modules.py:178-184):
- * y [B, T, d_mel] -> y_post [B, T, d_mel] = y + fc_out(isru(BN(conv(...)))). */
+ * y [B, T, d_mel] -> y_post [B, T, d_mel] = y + fc_out(isru(BN(conv(...)))); or, for
+ * TTSDEC_POSTNET_TYPE_MEL2, MelPostnet2.forward (modules.py:213-216). */
 int ttsdec_postnet(ttsdec_handle* h, const float* y, int B, int T, int precision, float* y_post, void* workspace,
                    size_t workspace_bytes, void* stream);
 

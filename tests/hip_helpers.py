@@ -69,6 +69,14 @@ def run_decoder_with_masks(dec, memory, masks, *, max_steps=0, x=None, flags=Non
     return y[:, : done * r].cpu(), s[:, : done * r].unsqueeze(2).cpu(), w[:, :done].cpu(), bool(fired)
 
 
+def make_postnet2(d_mel, hidden, layers, wts, device="cuda:0"):
+    pn = T.MelPostnet2(d_mel, dim_hidden=hidden, num_layers=layers)
+    missing, unexpected = pn.load_state_dict(wts, strict=False)
+    assert not unexpected, unexpected
+    assert all(k.endswith("num_batches_tracked") for k in missing), missing
+    return pn.to(device).eval()
+
+
 def assert_close(a, b, rtol=1e-4, atol=1e-5, what=""):
     assert a.shape == b.shape, (what, a.shape, b.shape)
     err = (a - b).abs()

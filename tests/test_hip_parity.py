@@ -396,6 +396,27 @@ def test_taco2_cell_rdh_dims_vs_oracle(H):
         assert torch.equal(w.argmax(-1), ow.argmax(-1))
 
 
+def test_melpostnet2_golden_and_template_dims(golden_taco2, H):
+    """MelPostnet2 (Conv1dFix residual blocks): the reference's own vectors at reduced dims, then
+    config_template dims (num_mels 80, hidden 256, 3 layers) against the oracle in all three modes."""
+    g, c, d = golden_taco2, golden_taco2["cases"], golden_taco2["meta"]["dims"]
+    pn = H.make_postnet2(d["d_mel"], d["postnet_hidden"], d["postnet_layers"], g["post"])
+    with torch.no_grad():
+        H.assert_close(pn(c["infer/y"].cuda()).cpu(), c["infer/y_post"], RTOL, ATOL, "y_post")
+        H.assert_close(pn(c["unit/post_y"].cuda()).cpu(), c["unit/post_out"], RTOL, ATOL, "unit")
+    pw = O.random_postnet2_weights(80, 256, 3, seed=4)
+    gen = torch.Generator().manual_seed(6)
+    y = torch.randn(4, 97, 80, generator=gen)
+    ref = O.mel_postnet2(y, pw, 3)
+    pn = H.make_postnet2(80, 256, 3, pw)
+    for mode, rt, at in (("f32", RTOL, ATOL), ("split_f16", RTOL, ATOL), ("bf16", 5e-2, 5e-2)):
+        pn.precision = mode
+        with torch.no_grad():
+            out = pn(y.cuda()).cpu()
+        print(f"MelPostnet2 {mode}: max abs err {float((out - ref).abs().max()):.3e} (|ref| max {float(ref.abs().max()):.2f})")
+        H.assert_close(out, ref, rt, at, f"postnet2 {mode}")
+
+
 def test_postnet_ljspeech_dims_vs_oracle(H):
     pw = O.random_postnet_weights(80, 512, 3, seed=9)
     g = torch.Generator().manual_seed(2)
@@ -482,6 +503,32 @@ def test_shard_equivalence_bitwise(H):
     ya, sa, wa, _ = H.run_decoder_with_masks(dec, mem[:192], masks[:, :, :192].contiguous(), max_steps=T - 1)
     yb, sb, wb, _ = H.run_decoder_with_masks(dec, mem[192:], masks[:, :, 192:].contiguous(), max_steps=T - 1)
     assert torch.equal(y, torch.cat([ya, yb])) and torch.equal(w, torch.cat([wa, wb])) and torch.equal(s, torch.cat([sa, sb]))
+
+
+def test_tacotron_forward_glue_sandra_style_config(H):
+    """build_tacotron for a config-sandra / config_template style model: Taco2DecoderCell, r = 2,
+    MelPostnet2 (postnet without type), encoder 256."""
+    import torch_tts_amd as T
+
+    cfg = {
+        "text": {"alphabet": "abcdefghijklmnopqrstuvwxyz '.,?!"},
+        "audio": {"num_mels": 80},
+        "model": {
+            "encoder": {"dim_emb": 64, "dim_out": 256},
+            "decoder": {"type": "tacotron2", "r": 2, "dim_pre": 256, "dim_att": 256, "dim_rnn": [512, 512]},
+            "postnet": {"dim_hidden": 256, "num_layers": 3},
+        },
+    }
+    torch.manual_seed(0)
+    model = T.build_tacotron(cfg).cuda().eval()
+    assert isinstance(model.decoder.decoder_cell, T.Taco2DecoderCell) and isinstance(model.postnet, T.MelPostnet2)
+    ids = torch.randint(1, 30, (3, 19)).cuda()
+    lens = torch.tensor([19, 12, 19]).cuda()
+    ids[1, 12:] = 0
+    with torch.no_grad():
+        y, y_post, s, out = model(ids, lens, max_steps=9)
+    assert y.shape == (3, 20, 80) and y_post.shape == y.shape and s.shape == (3, 20, 1) and out["w"].shape == (3, 10, 19)
+    assert torch.isfinite(y_post).all() and float((out["w"].sum(-1) - 1).abs().max()) < 1e-5
 
 
 def test_tacotron_forward_glue(H):

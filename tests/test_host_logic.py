@@ -102,6 +102,23 @@ def test_state_dict_keys_match_the_reference(golden):
     assert ctx0.shape == (3, d["d_ctx"]) and hc[0][0].shape == (3, d["h_att"]) and hc[1][1].shape == (3, d["h_dec"])
 
 
+def test_taco2_and_postnet2_state_dict_keys_match_the_reference(golden_taco2):
+    d = golden_taco2["meta"]["dims"]
+    cell = T.Taco2DecoderCell(d["d_ctx"], d["d_mel"], d["r"], [d["h_att"], d["h_dec"]], dim_pre=d["d_pre"])
+    dec = T.Decoder(cell, d["r"], d["d_mel"])
+    assert set(dec.state_dict().keys()) == set(golden_taco2["dec"].keys())
+    dec.load_state_dict(golden_taco2["dec"], strict=True)
+    assert dec.fc_mel.out_features == d["r"] * d["d_mel"] and dec.fc_stop.out_features == d["r"]
+    pn = T.MelPostnet2(d["d_mel"], d["postnet_hidden"], d["postnet_layers"])
+    keys = {k for k in pn.state_dict().keys() if not k.endswith("num_batches_tracked")}
+    assert keys == set(golden_taco2["post"].keys())
+    ts = pn.weight_tensors()
+    assert len(ts) == 21 + 11 * d["postnet_layers"] and tuple(ts[21].shape) == (d["postnet_hidden"], d["d_mel"], 5)
+    e = T.Engine(pn.engine_dims(), None)
+    assert e.num_weight_tensors() == len(ts)
+    e.close()
+
+
 def test_weight_tensor_order_matches_header_enum(golden):
     d = golden["meta"]["small_dims"]
     cell = T.Taco2ProdDecoderCell(d["d_ctx"], d["d_mel"], d["r"], [d["h_att"], d["h_dec"]], dim_pre=d["d_pre"])

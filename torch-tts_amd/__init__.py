@@ -6,10 +6,10 @@ from . import _lib  # noqa: F401
 from .decoder import Decoder
 from .decoder_cell import LSTMZoneoutCell, PreNet, StepwiseMonotonicAttention, Taco2DecoderCell, Taco2ProdDecoderCell
 from .engine import Engine, EngineDims
-from .postnet import MelPostnet
+from .postnet import Conv1dFix, MelPostnet, MelPostnet2
 from .tacotron import Encoder2, Tacotron, build_tacotron, lengths_to_mask
 
 __all__ = [
-    "Decoder", "Taco2ProdDecoderCell", "Taco2DecoderCell", "PreNet", "LSTMZoneoutCell", "StepwiseMonotonicAttention", "MelPostnet",
+    "Decoder", "Taco2ProdDecoderCell", "Taco2DecoderCell", "PreNet", "LSTMZoneoutCell", "StepwiseMonotonicAttention", "MelPostnet", "MelPostnet2",
     "Tacotron", "Encoder2", "build_tacotron", "lengths_to_mask", "Engine", "EngineDims",
 ]

@@ -19,6 +19,7 @@ CELL_TACO2PROD, CELL_TACO2 = 0, 1
 POSTNET_TYPE_MEL, POSTNET_TYPE_MEL2 = 0, 1
 W_DECODER_COUNT = 21
 W_POSTNET_PER_LAYER = 5
+W_POSTNET2_PER_LAYER = 11
 
 # every symbol include/ttsdec.h declares
 SYMBOLS = (

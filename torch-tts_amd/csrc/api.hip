@@ -27,6 +27,9 @@ struct BlobLayout {  // offsets in floats
   size_t conv_w[kMaxPostnetLayers], conv_alpha[kMaxPostnetLayers], conv_beta[kMaxPostnetLayers];
   size_t conv_wb[kMaxPostnetLayers], conv_wh[kMaxPostnetLayers], conv_wl[kMaxPostnetLayers];  // bf16 / split-fp16 planes
   size_t fc_w, fc_wb, fc_wh, fc_wl;
+  // MelPostnet2: per layer three Conv1dFix weights (+ 16-bit planes) and two folded BatchNorms
+  size_t p2_w[kMaxPostnetLayers][3], p2_wb[kMaxPostnetLayers][3], p2_wh[kMaxPostnetLayers][3], p2_wl[kMaxPostnetLayers][3];
+  size_t p2_alpha[kMaxPostnetLayers][2], p2_beta[kMaxPostnetLayers][2];
   size_t total;
 };
 
@@ -106,6 +109,20 @@ BlobLayout make_blob_layout(const ttsdec_dims& d) {
   L.proj_w = take((R * Mel + R) * (size_t)proj_ld(d));
   L.proj_b = take(R * Mel + R);
   size_t cin = Mel;
+  if (d.postnet_type == TTSDEC_POSTNET_TYPE_MEL2) {
+    const size_t Hh = d.postnet_hidden, k = d.postnet_kernel;
+    const size_t shapes[3][2] = {{Hh, Mel}, {Hh, Hh}, {Mel, Hh}};  // [C_out, C_in] of the three convs
+    for (int i = 0; i < d.postnet_layers; ++i) {
+      for (int c = 0; c < 3; ++c) {
+        const size_t n = shapes[c][0] * shapes[c][1] * k;
+        L.p2_w[i][c] = take(n);
+        L.p2_wb[i][c] = take((n + 1) / 2); L.p2_wh[i][c] = take((n + 1) / 2); L.p2_wl[i][c] = take((n + 1) / 2);
+      }
+      for (int c = 0; c < 2; ++c) { L.p2_alpha[i][c] = take(Hh); L.p2_beta[i][c] = take(Hh); }
+    }
+    L.total = off;
+    return L;
+  }
   for (int i = 0; i < d.postnet_layers; ++i) {
     L.conv_w[i] = take((size_t)d.postnet_hidden * d.postnet_kernel * cin);
     L.conv_alpha[i] = take(d.postnet_hidden);
@@ -590,7 +607,9 @@ int ttsdec_destroy(ttsdec_handle* h) {
 
 int ttsdec_num_weight_tensors(const ttsdec_handle* h) {
   if (!h) return TTSDEC_ERR_INVALID_ARG;
-  return TTSDEC_W_DECODER_COUNT + (h->d.postnet_layers > 0 ? TTSDEC_W_POSTNET_PER_LAYER * h->d.postnet_layers + 1 : 0);
+  if (h->d.postnet_layers <= 0) return TTSDEC_W_DECODER_COUNT;
+  if (h->d.postnet_type == TTSDEC_POSTNET_TYPE_MEL2) return TTSDEC_W_DECODER_COUNT + TTSDEC_W_POSTNET2_PER_LAYER * h->d.postnet_layers;
+  return TTSDEC_W_DECODER_COUNT + TTSDEC_W_POSTNET_PER_LAYER * h->d.postnet_layers + 1;
 }
 
 int ttsdec_set_precision(ttsdec_handle* h, int precision) {
@@ -649,6 +668,27 @@ int ttsdec_pack_weights(ttsdec_handle* h, const float* const* src, int n_src, vo
   launch_copy(src[TTSDEC_W_MEL_B], b + L.proj_b, R * Mel, st);
   launch_copy(src[TTSDEC_W_STOP_B], b + L.proj_b + R * Mel, R, st);
   int cin = d.d_mel;
+  if (d.postnet_type == TTSDEC_POSTNET_TYPE_MEL2) {
+    const int Hh = d.postnet_hidden, k = d.postnet_kernel;
+    const int shapes[3][2] = {{Hh, (int)Mel}, {Hh, Hh}, {(int)Mel, Hh}};
+    for (int i = 0; i < d.postnet_layers; ++i) {
+      // per layer: conv1.w, bn1.{w,b,mean,var}, conv2.w, bn2.{w,b,mean,var}, conv3.w
+      const float* const* ps = src + TTSDEC_W_DECODER_COUNT + TTSDEC_W_POSTNET2_PER_LAYER * i;
+      const int conv_idx[3] = {0, 5, 10};
+      for (int c = 0; c < 3; ++c) {
+        if (!ps[conv_idx[c]]) return TTSDEC_ERR_INVALID_ARG;
+        const size_t n = (size_t)shapes[c][0] * shapes[c][1] * k;
+        launch_conv1dfix_pack(ps[conv_idx[c]], b + L.p2_w[i][c], shapes[c][0], shapes[c][1], k, st);
+        launch_split(b + L.p2_w[i][c], hp(L.p2_wh[i][c]), hp(L.p2_wl[i][c]), n, st);
+        launch_to_bf16(b + L.p2_w[i][c], b + L.p2_wb[i][c], n, st);
+      }
+      for (int c = 0; c < 2; ++c) {
+        const float* const* bn = ps + 1 + 5 * c;
+        if (!bn[0] || !bn[1] || !bn[2] || !bn[3]) return TTSDEC_ERR_INVALID_ARG;
+        launch_bn_fold(bn[0], bn[1], bn[2], bn[3], d.bn_eps, b + L.p2_alpha[i][c], b + L.p2_beta[i][c], Hh, st);
+      }
+    }
+  } else
   for (int i = 0; i < d.postnet_layers; ++i) {
     const float* const* ps = src + TTSDEC_W_DECODER_COUNT + TTSDEC_W_POSTNET_PER_LAYER * i;
     if (!ps[0] || !ps[1] || !ps[2] || !ps[3] || !ps[4]) return TTSDEC_ERR_INVALID_ARG;
@@ -661,7 +701,7 @@ int ttsdec_pack_weights(ttsdec_handle* h, const float* const* src, int n_src, vo
     launch_bn_fold(ps[1], ps[2], ps[3], ps[4], d.bn_eps, b + L.conv_alpha[i], b + L.conv_beta[i], d.postnet_hidden, st);
     cin = d.postnet_hidden;
   }
-  if (d.postnet_layers > 0) {
+  if (d.postnet_layers > 0 && d.postnet_type == TTSDEC_POSTNET_TYPE_MEL) {
     const float* fc = src[TTSDEC_W_DECODER_COUNT + TTSDEC_W_POSTNET_PER_LAYER * d.postnet_layers];
     const size_t n = Mel * (size_t)d.postnet_hidden;
     launch_copy(fc, b + L.fc_w, n, st);
@@ -751,8 +791,10 @@ int ttsdec_decode(ttsdec_handle* h, const float* memory, int B, int L, int t_beg
 size_t ttsdec_postnet_workspace_bytes(const ttsdec_handle* h, int B, int T) {
   if (!h || B <= 0 || T <= 0 || h->d.postnet_layers <= 0) return 0;
   // two activation buffers (fp32, or hi+lo fp16 planes, or one bf16 plane) + 16-bit planes of the input
-  return 2 * align_up((size_t)B * T * h->d.postnet_hidden * sizeof(float), 256) +
-         align_up((size_t)B * T * h->d.d_mel * sizeof(float), 256);
+  // (+ for MelPostnet2: two fp32 residual-stream buffers and a second plane buffer)
+  const size_t act = align_up((size_t)B * T * h->d.postnet_hidden * sizeof(float), 256);
+  const size_t xin = align_up((size_t)B * T * h->d.d_mel * sizeof(float), 256);
+  return 2 * act + (h->d.postnet_type == TTSDEC_POSTNET_TYPE_MEL2 ? 4 * xin : xin);
 }
 
 int ttsdec_postnet(ttsdec_handle* h, const float* y, int B, int T, int precision, float* y_post, void* workspace,
@@ -781,6 +823,71 @@ int ttsdec_postnet(ttsdec_handle* h, const float* y, int B, int T, int precision
   char* act[2] = {wsb, wsb + act_bytes};
   char* yin = wsb + 2 * act_bytes;
   auto plane = [&](size_t float_off) { return reinterpret_cast<const void*>(h->blob + float_off); };
+
+  if (d.postnet_type == TTSDEC_POSTNET_TYPE_MEL2) {
+    // MelPostnet2.forward (modules.py:213-216): x = x + conv3(lrelu(BN(conv2(lrelu(BN(conv1(x))))))) per layer
+    const size_t xin_bytes = align_up(M * d.d_mel * sizeof(float), 256);
+    char* xbuf[2] = {yin, yin + xin_bytes};             // fp32 residual stream, ping-pong
+    char* xpl[2] = {yin + 2 * xin_bytes, yin + 3 * xin_bytes};  // its 16-bit planes, ping-pong
+    const int Hh = d.postnet_hidden, kk = d.postnet_kernel;
+    const float* xcur = y;
+    const void *x0 = y, *x1 = y;
+    if (prec == PREC_F16S) {
+      f16* xh = reinterpret_cast<f16*>(xpl[1]);
+      launch_split(y, xh, xh + M * d.d_mel, M * d.d_mel, st);
+      x0 = xh; x1 = xh + M * d.d_mel;
+    } else if (prec == PREC_BF16) {
+      launch_to_bf16(y, xpl[1], M * d.d_mel, st);
+      x0 = x1 = xpl[1];
+    }
+    auto wsel = [&](int i, int c, bool lo) -> const void* {
+      if (prec == PREC_F32) return h->blob + L.p2_w[i][c];
+      if (prec == PREC_BF16) return plane(L.p2_wb[i][c]);
+      return plane(lo ? L.p2_wl[i][c] : L.p2_wh[i][c]);
+    };
+    for (int i = 0; i < d.postnet_layers; ++i) {
+      const void *a0 = x0, *a1 = x1;
+      int cin2 = d.d_mel;
+      for (int c = 0; c < 2; ++c) {  // conv1 / conv2 + BN + LeakyReLU
+        GemmArgs g;
+        memset(&g, 0, sizeof(g));
+        g.prec = prec;
+        g.a = make_seg1(a0, cin2, cin2); g.a_lo = make_seg1(a1, cin2, cin2);
+        g.T = T; g.Cin = cin2; g.taps = kk; g.ldw = kk * cin2; g.K = kk * cin2;
+        g.W = wsel(i, c, false); g.W_lo = wsel(i, c, true);
+        g.M = (int)M; g.N = Hh; g.ldo = Hh;
+        g.alpha = h->blob + L.p2_alpha[i][c]; g.beta = h->blob + L.p2_beta[i][c];
+        char* o = act[c];
+        if (prec == PREC_F32) { g.out = reinterpret_cast<float*>(o); a0 = a1 = o; }
+        else if (prec == PREC_F16S) {
+          g.out_kind = 1; g.out_h = reinterpret_cast<f16*>(o); g.out_l = g.out_h + M * Hh; a0 = g.out_h; a1 = g.out_l;
+        } else { g.out_kind = 2; g.out_h = reinterpret_cast<f16*>(o); a0 = a1 = o; }
+        launch_gemm(g, A_CONV, EPI_BN_LRELU, st);
+        cin2 = Hh;
+      }
+      GemmArgs g;  // conv3 + residual
+      memset(&g, 0, sizeof(g));
+      g.prec = prec;
+      g.a = make_seg1(a0, Hh, Hh); g.a_lo = make_seg1(a1, Hh, Hh);
+      g.T = T; g.Cin = Hh; g.taps = kk; g.ldw = kk * Hh; g.K = kk * Hh;
+      g.W = wsel(i, 2, false); g.W_lo = wsel(i, 2, true);
+      g.M = (int)M; g.N = d.d_mel; g.ldo = d.d_mel;
+      g.resid = xcur;
+      const bool last = (i == d.postnet_layers - 1);
+      float* xnew = last ? y_post : reinterpret_cast<float*>(xbuf[i & 1]);
+      g.out = xnew;
+      if (!last && prec == PREC_F16S) {
+        g.out_kind = 1; g.out_h = reinterpret_cast<f16*>(xpl[i & 1]); g.out_l = g.out_h + M * d.d_mel; x0 = g.out_h; x1 = g.out_l;
+      } else if (!last && prec == PREC_BF16) {
+        g.out_kind = 2; g.out_h = reinterpret_cast<f16*>(xpl[i & 1]); x0 = x1 = xpl[i & 1];
+      } else if (!last) {
+        x0 = x1 = xnew;
+      }
+      launch_gemm(g, A_CONV, EPI_RESIDUAL, st);
+      xcur = xnew;
+    }
+    return check_launch(h, "postnet2");
+  }
 
   // current layer input as (plane 0, plane 1)
   const void *in0 = y, *in1 = y;

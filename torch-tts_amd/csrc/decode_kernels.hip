@@ -112,7 +112,7 @@ __global__ __launch_bounds__(kGemmThreads) void gemm_rows_kernel(GemmArgs g) {
     pre_mask[j] = 1;
     pre_res[j] = 0.f;
     if (EK == EPI_RELU_DROPOUT && ok && g.dropout_mode == TTSDEC_DROPOUT_MASKS) pre_mask[j] = g.masks[(size_t)m * g.N + n];
-    if (EK == EPI_BN_ISRU && ok) {
+    if ((EK == EPI_BN_ISRU || EK == EPI_BN_LRELU) && ok) {
       pre_bias[j] = g.alpha[n];
       pre_res[j] = g.beta[n];
     }
@@ -149,7 +149,7 @@ __global__ __launch_bounds__(kGemmThreads) void gemm_rows_kernel(GemmArgs g) {
     const int m = m0 + row, n = n0 + col;
     if (m >= g.M || n >= g.N) continue;
     float v = smem[row * LDO + col];
-    if (EK != EPI_BN_ISRU && g.bias != nullptr) v = add_rn(v, pre_bias[j]);
+    if (EK != EPI_BN_ISRU && EK != EPI_BN_LRELU && g.bias != nullptr) v = add_rn(v, pre_bias[j]);
     auto store16 = [&](float val) {  // 16-bit copies for a following 16-bit GEMM
       const size_t o = (size_t)m * g.ldo + n;
       if (g.out_kind == 1) split_f16(val, g.out_h[o], g.out_l[o]);
@@ -187,9 +187,17 @@ __global__ __launch_bounds__(kGemmThreads) void gemm_rows_kernel(GemmArgs g) {
       v = isru(add_rn(mul_rn(v, pre_bias[j]), pre_res[j]));
       if (g.out != nullptr) g.out[(size_t)m * g.ldo + n] = v;
       store16(v);
+    } else if (EK == EPI_BN_LRELU) {
+      // modules.py:196-198 LeakyReLU(BatchNorm1d(conv(x))), default negative_slope 0.01
+      v = add_rn(mul_rn(v, pre_bias[j]), pre_res[j]);
+      v = v > 0.f ? v : mul_rn(v, 0.01f);
+      if (g.out != nullptr) g.out[(size_t)m * g.ldo + n] = v;
+      store16(v);
     } else if (EK == EPI_RESIDUAL) {
-      // modules.py:184 x + fc_out(...)
-      g.out[(size_t)m * g.ldo + n] = add_rn(pre_res[j], v);
+      // modules.py:184 x + fc_out(...)  /  modules.py:215 x + layer(x)
+      v = add_rn(pre_res[j], v);
+      g.out[(size_t)m * g.ldo + n] = v;
+      store16(v);
     }
   }
 }
@@ -221,6 +229,8 @@ static void launch_gemm_prec(const GemmArgs& a, hipStream_t st) {
 void launch_gemm(const GemmArgs& a, AKind ak, EpiKind ek, hipStream_t st) {
   if (a.M <= 0 || a.N <= 0) return;
   if (ak == A_CONV && ek == EPI_BN_ISRU) return launch_gemm_prec<A_CONV, EPI_BN_ISRU>(a, st);
+  if (ak == A_CONV && ek == EPI_BN_LRELU) return launch_gemm_prec<A_CONV, EPI_BN_LRELU>(a, st);
+  if (ak == A_CONV && ek == EPI_RESIDUAL) return launch_gemm_prec<A_CONV, EPI_RESIDUAL>(a, st);
   switch (ek) {
     case EPI_PLAIN: return launch_gemm_cfg<A_PLAIN, EPI_PLAIN, PREC_F32>(a, st);
     case EPI_RELU_DROPOUT: return launch_gemm_cfg<A_PLAIN, EPI_RELU_DROPOUT, PREC_F32>(a, st);
@@ -622,6 +632,20 @@ __global__ void conv_transpose_kernel(const float* w, float* out, int Co, int Ci
 void launch_conv_transpose(const float* w, float* out, int Co, int Ci, int k, hipStream_t st) {
   const size_t n = (size_t)Co * Ci * k;
   hipLaunchKernelGGL(conv_transpose_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, w, out, Co, Ci, k);
+}
+
+__global__ void conv1dfix_pack_kernel(const float* w, float* out, int Co, int Ci, int k) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const size_t n = (size_t)Co * Ci * k;
+  if (i >= n) return;
+  const int ci = (int)(i % Ci);
+  const int tap = (int)((i / Ci) % k);
+  const int co = (int)(i / ((size_t)Ci * k));
+  out[i] = w[(size_t)co * Ci * k + (size_t)(k - 1 - tap) * Ci + ci];
+}
+void launch_conv1dfix_pack(const float* w, float* out, int Co, int Ci, int k, hipStream_t st) {
+  const size_t n = (size_t)Co * Ci * k;
+  hipLaunchKernelGGL(conv1dfix_pack_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, w, out, Co, Ci, k);
 }
 
 __global__ void bn_fold_kernel(const float* gamma, const float* betap, const float* mean, const float* var, float eps,

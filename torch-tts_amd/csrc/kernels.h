@@ -6,7 +6,7 @@ namespace ttsdec {
 
 // ---- generic row-GEMM (PreNet layers, query projection, mel/stop projection, postnet) ----
 enum AKind { A_PLAIN = 0, A_CONV = 1 };
-enum EpiKind { EPI_PLAIN = 0, EPI_RELU_DROPOUT = 1, EPI_PROJ = 2, EPI_BN_ISRU = 3, EPI_RESIDUAL = 4 };
+enum EpiKind { EPI_PLAIN = 0, EPI_RELU_DROPOUT = 1, EPI_PROJ = 2, EPI_BN_ISRU = 3, EPI_RESIDUAL = 4, EPI_BN_LRELU = 5 };
 
 struct GemmArgs {
   // A operand.  A_PLAIN: up to three K segments of an [M, K] activation.
@@ -135,6 +135,9 @@ void launch_copy(const float* src, float* dst, size_t n, hipStream_t st);
 void launch_split(const float* src, f16* hi, f16* lo, size_t n, hipStream_t st);
 void launch_to_bf16(const float* src, void* dst, size_t n, hipStream_t st);
 void launch_conv_transpose(const float* w /*[Co,Ci,k]*/, float* out /*[Co,k,Ci]*/, int Co, int Ci, int k, hipStream_t st);
+// Conv1dFix (mps_fixes.py:22-29) pairs flat-weight column n*Ci + c with x[c, t + pad - n]:
+// out[co][tap][ci] = wflat[co][(k-1-tap)*Ci + ci]
+void launch_conv1dfix_pack(const float* w, float* out, int Co, int Ci, int k, hipStream_t st);
 void launch_bn_fold(const float* gamma, const float* betap, const float* mean, const float* var, float eps, float* alpha,
                     float* beta, int n, hipStream_t st);
 

@@ -62,3 +62,84 @@ class MelPostnet(nn.Module):
             raise NotImplementedError("autograd through the postnet is outside the HIP hot path: call under torch.no_grad()")
         prec = {"f32": _lib.POSTNET_F32, "bf16": _lib.POSTNET_BF16, "split_f16": _lib.POSTNET_SPLIT_F16}[self.precision]
         return self.engine(x.device).postnet(x.detach().to(torch.float32).contiguous(), prec)
+
+
+class Conv1dFix(nn.Module):
+    """Parameter holder for tacotron/mps_fixes/mps_fixes.py:6-29 (key ``weight`` [out, in, k])."""
+
+    def __init__(self, in_channels, out_channels, kernel_size, padding, bias=True):
+        super().__init__()
+        self.padding, self.kernel_size = padding, kernel_size
+        self.in_channels, self.out_channels = in_channels, out_channels
+        self.weight = nn.Parameter(torch.zeros([out_channels, in_channels, kernel_size]))
+        nn.init.xavier_uniform_(self.weight)
+        if bias:
+            self.bias = nn.Parameter(torch.zeros([out_channels]))
+            nn.init.normal_(self.bias)
+        else:
+            self.register_parameter("bias", None)
+
+    def forward(self, x):
+        raise NotImplementedError("Conv1dFix holds parameters only: it runs fused inside MelPostnet2 on the HIP path")
+
+
+class MelPostnet2(nn.Module):
+    """Drop-in for the reference's ``modules.modules.MelPostnet2`` (tacotron/modules/modules.py:187-216),
+    selected when model.postnet.type is not "tacotron2" (tacotron.py:207-212): ``num_layers`` residual
+    blocks of Conv1dFix(k=5)-BN-LeakyReLU-Dropout x2 + Conv1dFix.  Same state-dict keys
+    (layers.{i}.{1,5,9}.weight, layers.{i}.{2,6}.*); eval-mode forward through ``ttsdec_postnet``."""
+
+    def __init__(self, dim_in, dim_hidden=128, num_layers=3):
+        super().__init__()
+        self.layers = nn.ModuleList(
+            [
+                nn.Sequential(
+                    nn.Identity(),  # Transposition (no parameters)
+                    Conv1dFix(dim_in, dim_hidden, kernel_size=5, padding=2, bias=False),
+                    nn.BatchNorm1d(dim_hidden),
+                    nn.LeakyReLU(),
+                    nn.Dropout(0.2),
+                    Conv1dFix(dim_hidden, dim_hidden, kernel_size=5, padding=2, bias=False),
+                    nn.BatchNorm1d(dim_hidden),
+                    nn.LeakyReLU(),
+                    nn.Dropout(0.2),
+                    Conv1dFix(dim_hidden, dim_in, kernel_size=5, padding=2, bias=False),
+                    nn.Identity(),  # Transposition
+                )
+                for _ in range(num_layers)
+            ]
+        )
+        self.dim_in, self.dim_hidden, self.num_layers = dim_in, dim_hidden, num_layers
+        self.precision = "f32"
+        self._engines = EngineCache()
+
+    def weight_tensors(self):
+        ts = [None] * _lib.W_DECODER_COUNT
+        for layer in self.layers:
+            for conv_i, bn_i in ((1, 2), (5, 6)):
+                bn = layer[bn_i]
+                ts += [layer[conv_i].weight, bn.weight, bn.bias, bn.running_mean, bn.running_var]
+            ts.append(layer[9].weight)
+        return ts
+
+    def engine_dims(self) -> EngineDims:
+        return EngineDims(
+            d_mel=self.dim_in, r=1, d_pre=4, d_ctx=4, h_att=4, h_dec=4, p_zoneout=0.0, p_dropout=0.0,
+            postnet_layers=self.num_layers, postnet_hidden=self.dim_hidden, postnet_kernel=5,
+            bn_eps=float(self.layers[0][2].eps), postnet_type=_lib.POSTNET_TYPE_MEL2,
+        )
+
+    def engine(self, device):
+        eng = self._engines.get(self.engine_dims(), device)
+        eng.ensure_packed(self.weight_tensors())
+        return eng
+
+    def forward(self, x):
+        if not x.is_cuda:
+            raise RuntimeError("MelPostnet2 runs on the HIP path only: move the module and input to a ROCm device")
+        if self.training:
+            raise NotImplementedError("MelPostnet2 on the HIP path is eval-mode only (BatchNorm running stats, no dropout)")
+        if torch.is_grad_enabled() and (x.requires_grad or any(p.requires_grad for p in self.parameters())):
+            raise NotImplementedError("autograd through the postnet is outside the HIP hot path: call under torch.no_grad()")
+        prec = {"f32": _lib.POSTNET_F32, "bf16": _lib.POSTNET_BF16, "split_f16": _lib.POSTNET_SPLIT_F16}[self.precision]
+        return self.engine(x.device).postnet(x.detach().to(torch.float32).contiguous(), prec)

@@ -10,7 +10,7 @@ import torch.nn as nn
 
 from .decoder import Decoder
 from .decoder_cell import Taco2DecoderCell, Taco2ProdDecoderCell
-from .postnet import MelPostnet
+from .postnet import MelPostnet, MelPostnet2
 
 
 def lengths_to_mask(lengths):
@@ -120,9 +120,10 @@ def build_tacotron(config):
     postnet_config = config["model"].get("postnet")
     postnet = None
     if postnet_config:
-        if postnet_config.get("type") != "tacotron2":
-            raise NotImplementedError("MelPostnet2 is not built on HIP yet (SURVEY.md 8f)")
-        postnet = MelPostnet(audio_config["num_mels"], dim_hidden=postnet_config["dim_hidden"], num_layers=postnet_config["num_layers"])
+        if postnet_config.get("type") == "tacotron2":
+            postnet = MelPostnet(audio_config["num_mels"], dim_hidden=postnet_config["dim_hidden"], num_layers=postnet_config["num_layers"])
+        else:
+            postnet = MelPostnet2(audio_config["num_mels"], dim_hidden=postnet_config["dim_hidden"], num_layers=postnet_config["num_layers"])
     if config["model"].get("style_encoder"):
         raise NotImplementedError("style encoder (VAE) is outside the hot path and not provided")
     return Tacotron(encoder, decoder, postnet=postnet, refencoder=None)
