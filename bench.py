@@ -81,11 +81,18 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if args.gpus > 1 and world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} needs torch.distributed.run with {args.gpus} ranks (WORLD_SIZE={world})")
-    dev = torch.device("cuda", local_rank)
+    # Rehearsal switch (not for measurements): TTSDEC_BENCH_BACKEND=gloo lets several ranks share the
+    # GPUs of a smaller box to exercise the N > 1 code path; the real run is RCCL, one rank per GPU.
+    backend = os.environ.get("TTSDEC_BENCH_BACKEND", "nccl")
+    ndev = torch.cuda.device_count()
+    dev = torch.device("cuda", local_rank % ndev if backend != "nccl" else local_rank)
     torch.cuda.set_device(dev)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        if backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=world)
 
     import torch_tts_amd as T
     from torch_tts_amd import _lib
