@@ -340,9 +340,15 @@ void launch_lstm(const LstmArgs& a, hipStream_t st) {
       using Cfg = TileCfg<2, 2, 1, 4, PREC_F16S>;  // 64 rows x 16 units, 32 KiB stages (64 k each); S=5 and nt weight loads measured slower
       dim3 grid((a.H + 15) / 16, (a.M + 63) / 64);
       hipLaunchKernelGGL((lstm_kernel<Cfg>), grid, dim3(kGemmThreads), 0, st, a);
-    } else {
+    } else if (a.M >= 96) {
       using Cfg = TileCfg<2, 1, 2, 3, PREC_F16S>;  // 64 rows x 8 units, 48 KiB stages (128 k each)
       dim3 grid((a.H + 7) / 8, (a.M + 63) / 64);
+      hipLaunchKernelGGL((lstm_kernel<Cfg>), grid, dim3(kGemmThreads), 0, st, a);
+    } else {
+      // small batches: 32 rows x 8 units on two MFMA waves, so B = 64 still launches 256 workgroups
+      // (the kernel is bound by streaming its weight rows, which this halves per workgroup)
+      using Cfg = TileCfg<1, 1, 2, 4, PREC_F16S>;  // 32 KiB stages (128 k each)
+      dim3 grid((a.H + 7) / 8, (a.M + 31) / 32);
       hipLaunchKernelGGL((lstm_kernel<Cfg>), grid, dim3(kGemmThreads), 0, st, a);
     }
     return;

@@ -46,7 +46,8 @@ namespace ttsdec {
 template <int WM, int WN, int WK, int S, int PREC = PREC_F32, int AUXB = 0>
 struct TileCfg {
   static constexpr int kAuxB = AUXB;  // cache-policy bits of the B (weight) operand's LDS-DMA: 2 = nt (streamed once)
-  static_assert(WM * WN * WK == 4, "4 MFMA waves per workgroup");
+  static constexpr int NMW = WM * WN * WK;  // active MFMA waves (of the 4 in the workgroup)
+  static_assert(NMW == 4 || NMW == 2, "2 or 4 active MFMA waves per workgroup");
   static_assert(S >= 3, "ring needs at least 3 stages (fragment reads run one tile ahead of the MFMAs)");
   static constexpr int kPrec = PREC;
   static constexpr int EB = (PREC == PREC_F32) ? 4 : 2;      // element bytes
@@ -262,7 +263,13 @@ __device__ __forceinline__ void gemm_tile(const LoaderA& la, const LoaderB& lb, 
     // ============================ MFMA waves ============================
     const int arow = wm * 32 + l32, brow = wn * 32 + l32;
     int rstage = 0;
-    if constexpr (Cfg::kPrec == PREC_F32) {
+    if (wave >= Cfg::NMW) {
+      // spare wave of a 2-MFMA-wave tile: only keeps the workgroup barriers balanced
+      if (live) {
+        __builtin_amdgcn_s_barrier();
+        for (int t = 0; t < nk; ++t) __builtin_amdgcn_s_barrier();
+      }
+    } else if constexpr (Cfg::kPrec == PREC_F32) {
       int aoff[4], boff[4];  // byte offsets inside a stage
 #pragma unroll
       for (int q = 0; q < 4; ++q) {
@@ -372,7 +379,7 @@ __device__ __forceinline__ void gemm_tile(const LoaderA& la, const LoaderB& lb, 
 
   // accumulators -> LDS out tile (aliases the ring).
   // C/D map of the 32x32 MFMA: col = lane & 31, row = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5).
-  if (!is_loader) {
+  if (!is_loader && wave < Cfg::NMW) {
     float* out = smem + wk * BM * LDO;
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
