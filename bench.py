@@ -32,6 +32,21 @@ LJSPEECH = {
         "postnet": {"type": "tacotron2", "dim_hidden": 512, "num_layers": 3},
     },
 }
+# the reference's other shipped configs (configs/config-rdh.yaml:54-69, config-sandra.yaml:54-69):
+# Taco2DecoderCell; sandra additionally r = 2, narrower model and MelPostnet2
+RDH = {
+    "text": {"alphabet": "x" * 39}, "audio": {"num_mels": 80},
+    "model": {"encoder": {"type": "tacotron2", "dim_emb": 512, "dim_out": 512},
+              "decoder": {"type": "tacotron2", "r": 1, "dim_pre": 256, "dim_att": 256, "dim_rnn": [1024, 1024]},
+              "postnet": {"type": "tacotron2", "dim_hidden": 512, "num_layers": 3}},
+}
+SANDRA = {
+    "text": {"alphabet": "x" * 39}, "audio": {"num_mels": 80},
+    "model": {"encoder": {"type": "tacotron2", "dim_emb": 256, "dim_out": 256},
+              "decoder": {"type": "tacotron2", "r": 2, "dim_pre": 256, "dim_att": 256, "dim_rnn": [512, 512]},
+              "postnet": {"dim_hidden": 256, "num_layers": 3}},
+}
+CONFIGS = {"ljspeech": LJSPEECH, "rdh": RDH, "sandra": SANDRA}
 FRAME_SEC = 256.0 / 22050.0
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
 
@@ -70,6 +85,8 @@ def main():
     ap.add_argument("--postnet", choices=["f32", "bf16", "split_f16"], default="split_f16")
     ap.add_argument("--precision", choices=["f32", "split_f16"], default="split_f16",
                     help="arithmetic of the LSTM gate GEMMs (include/ttsdec.h TTSDEC_PREC_*)")
+    ap.add_argument("--config", choices=sorted(CONFIGS), default="ljspeech",
+                    help="model dims: ljspeech = BASELINE.json's config (default); rdh / sandra = the other shipped configs")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-frames", type=int, default=0, help="decode frames for the CPU baseline sample (0 = auto)")
     args = ap.parse_args()
@@ -103,7 +120,10 @@ def main():
 
     # ---- model: LJSpeech dims, random init seed 42 (xavier_normal gain 1.5, default LSTMCell init) ----
     torch.manual_seed(42)
-    model = T.build_tacotron(LJSPEECH).eval()
+    CFG = CONFIGS[args.config]
+    if args.config != "ljspeech":
+        args.no_cpu_baseline = True  # the CPU leg and the byte model below are written for the LJSpeech cell
+    model = T.build_tacotron(CFG).eval()
     model.to(dev)
     dec, post = model.decoder, model.postnet
     dec.dropout_source, dec.dropout_seed = "philox", 123
@@ -130,16 +150,18 @@ def main():
     lens = torch.full((hi - lo,), L, dtype=torch.long, device=dev)
     with torch.no_grad():
         mem = torch.cat([model.encoder(ids[i : i + 64], lens[i : i + 64]) for i in range(0, hi - lo, 64)]).contiguous()
-    assert mem.shape == (B, L, 512)
+    assert mem.shape == (B, L, CFG["model"]["encoder"]["dim_out"])
+    R = CFG["model"]["decoder"]["r"]
+    NS = NF // R  # decode steps for NF frames
 
     y = torch.empty(B, NF, 80, device=dev)
     s = torch.empty(B, NF, device=dev)
-    w = torch.empty(B, NF, L, device=dev)
+    w = torch.empty(B, NS, L, device=dev)
     t_out = torch.zeros(2, dtype=torch.int32, device=dev)
     prec = {"f32": _lib.POSTNET_F32, "bf16": _lib.POSTNET_BF16, "split_f16": _lib.POSTNET_SPLIT_F16}[args.postnet]
 
     def one_step():
-        eng.decode(mem, t_begin=0, n_steps=NF, stop_threshold=-2.0, check_stop=True, dropout_mode=_lib.DROPOUT_PHILOX,
+        eng.decode(mem, t_begin=0, n_steps=NS, stop_threshold=-2.0, check_stop=True, dropout_mode=_lib.DROPOUT_PHILOX,
                    masks=None, seed=123, teacher=None, teacher_flags=None, y=y, s=s, w=w, t_out=t_out)
         return peng.postnet(y, prec)
 
@@ -157,7 +179,7 @@ def main():
     dec_ms = 0.0
     for _ in range(args.steps):
         ev0.record()
-        eng.decode(mem, t_begin=0, n_steps=NF, stop_threshold=-2.0, check_stop=True, dropout_mode=_lib.DROPOUT_PHILOX,
+        eng.decode(mem, t_begin=0, n_steps=NS, stop_threshold=-2.0, check_stop=True, dropout_mode=_lib.DROPOUT_PHILOX,
                    masks=None, seed=123, teacher=None, teacher_flags=None, y=y, s=s, w=w, t_out=t_out)
         ev1.record()
         y_post = peng.postnet(y, prec)
@@ -166,7 +188,7 @@ def main():
         dec_ms += ev0.elapsed_time(ev1)
     fence()
     elapsed = time.perf_counter() - t0
-    assert t_out.tolist() == [NF, 0], f"decode ended early: {t_out.tolist()}"
+    assert t_out.tolist() == [NS, 0], f"decode ended early: {t_out.tolist()}"
     assert bool(torch.isfinite(y_post).all())
     if world > 1:
         tt = torch.tensor([elapsed], dtype=torch.float64, device=dev)
@@ -179,7 +201,7 @@ def main():
 
     # ---- roofline of the dominant kernel: HIP events inside the library, on the launch stream ----
     kms = eng.profile_step(mem, iters=50, dropout_mode=_lib.DROPOUT_PHILOX, masks=None, seed=123)
-    bytes_k = step_bytes(B, L, LJSPEECH["model"]["decoder"])
+    bytes_k = step_bytes(B, L, LJSPEECH["model"]["decoder"])  # (byte model of the LJSpeech cell)
     grp = {"prenet": ["prenet0", "prenet1"], "lstm_att": ["lstm_att"], "query": ["query"], "attention": ["attention"],
            "lstm_dec": ["lstm_dec"], "proj": ["proj"]}
     per_kernel = {}
@@ -188,7 +210,7 @@ def main():
         per_kernel[k] = {"ms": round(ms, 5), "alg_bytes": bytes_k[k], "GBps": round(bytes_k[k] / (ms * 1e-3) / 1e9, 1)}
     dom = max(per_kernel, key=lambda k: per_kernel[k]["ms"])
     step_ms_kernels = sum(v["ms"] for v in per_kernel.values())
-    decode_step_ms = dec_ms / args.steps / NF
+    decode_step_ms = dec_ms / args.steps / NS
     # HBM traffic of the dominant kernel from the PMC passes (cannot be collected inside this
     # process; see profiles/r01_traffic.json for the command and the gfx950 FETCH_SIZE correction)
     traffic = None
@@ -232,7 +254,7 @@ def main():
         "dtype": "f32" if args.precision == "f32" else "f32 via split-fp16 (hi+lo fp16 planes, 3 f16 MFMA products, fp32 accumulate) for the LSTM GEMMs; f32 elsewhere",
         "data": "synthetic",
         "config": {
-            "workload": f"LJSpeech dims, batch={B}/GPU (global {Bg}), L={L}, {NF} decode frames + Postnet({args.postnet}); "
+            "workload": f"{args.config} dims, batch={B}/GPU (global {Bg}), L={L}, {NF} decode frames + Postnet({args.postnet}); "
                         "BASELINE.json configs[2] per GPU, configs[3] at 8 GPUs",
             "global_batch": Bg, "mem_len": L, "frames": NF, "dropout": "philox", "parallelism": f"utterance-shard x{world}",
             "lstm_precision": eng.precision(),
