@@ -283,6 +283,74 @@ def test_memory_length_edges(H, B, L, T):
         assert float((ow - 1.0).abs().max()) == 0.0  # all mass stays on the single, absorbing column
 
 
+def test_teacher_forcing_through_graph_replay(H):
+    """>= 15 steps go through the captured hipGraph: teacher frames, per-step force flags and the
+    masks are all read through the device control block at replay time."""
+    dims = O.DecoderDims(d_mel=16, d_pre=32, d_ctx=64, h_att=64, h_dec=96)
+    wts = O.random_decoder_weights(dims, seed=12, nonzero_init_state=True)
+    B, L, Tx = 5, 21, 47
+    mem = O.synthetic_memory(B, L, dims.d_ctx, lengths=[21, 21, 8, 15, 2])
+    masks = O.synthetic_masks(Tx, B, dims.d_pre, seed=2)
+    g = torch.Generator().manual_seed(1)
+    x = torch.randn(B, Tx, 16, generator=g) * 0.5
+    flags = (torch.rand(Tx - 1, generator=g) > 0.3).tolist()
+    oy, os_, ow = O.decode(wts, dims, mem, masks=masks, x=x, teacher_flags=flags)
+    for prec in ("f32", "split_f16"):
+        dec = H.make_decoder(dims, wts)
+        dec.precision = prec
+        y, s, w, _ = H.run_decoder_with_masks(dec, mem, masks, x=x, flags=flags)
+        H.assert_close(y, oy, RTOL, ATOL, f"y {prec}")
+        H.assert_close(w, ow, RTOL, ATOL, f"w {prec}")
+
+
+def test_back_to_back_calls_with_changing_shapes_and_modes(H):
+    """One Decoder, many calls: batch / memory length / precision / weights change between calls, so
+    the cached graph, workspace and packed blob must each be refreshed exactly when needed."""
+    dims = O.DecoderDims()
+    wts = O.random_decoder_weights(dims, seed=21)
+    dec = H.make_decoder(dims, wts)
+    T = 20
+    ref = {}
+    for (B, L) in [(64, 40), (7, 40), (64, 33), (64, 40)]:
+        mem = O.synthetic_memory(B, L, dims.d_ctx, seed=B + L)
+        masks = O.synthetic_masks(T, B, dims.d_pre, seed=3)
+        if (B, L) not in ref:
+            ref[(B, L)] = O.decode(wts, dims, mem, max_steps=T - 1, masks=masks)
+        for prec in ("split_f16", "f32", "split_f16"):
+            dec.precision = prec
+            y, s, w, _ = H.run_decoder_with_masks(dec, mem, masks, max_steps=T - 1)
+            H.assert_close(y, ref[(B, L)][0], RTOL, ATOL, f"y B={B} L={L} {prec}")
+            H.assert_close(w, ref[(B, L)][2], RTOL, ATOL, f"w B={B} L={L} {prec}")
+    # change the weights in place: the next call must repack (fingerprint = data_ptr + version)
+    with torch.no_grad():
+        dec.fc_mel.bias.add_(0.25)
+    wts2 = dict(wts)
+    wts2["fc_mel.bias"] = wts["fc_mel.bias"] + 0.25
+    mem = O.synthetic_memory(7, 40, dims.d_ctx, seed=47)
+    masks = O.synthetic_masks(T, 7, dims.d_pre, seed=3)
+    oy, _, _ = O.decode(wts2, dims, mem, max_steps=T - 1, masks=masks)
+    y, _, _, _ = H.run_decoder_with_masks(dec, mem, masks, max_steps=T - 1)
+    H.assert_close(y, oy, RTOL, ATOL, "y after in-place weight update")
+
+
+def test_large_single_gpu_batch_runs_and_is_finite(H):
+    """B = 2048 on one GPU (BASELINE.json configs[3] unsharded): many row tiles per kernel."""
+    dims = O.DecoderDims()
+    wts = O.random_decoder_weights(dims, seed=5)
+    B, L, T = 2048, 120, 32
+    mem = O.synthetic_memory(B, L, dims.d_ctx, seed=1).cuda()
+    dec = H.make_decoder(dims, wts)
+    dec.dropout_source, dec.dropout_seed, dec.precision = "philox", 9, "split_f16"
+    with torch.no_grad():
+        y, s, w = dec(mem, None, None, T - 1)
+    assert y.shape == (B, T, 80) and torch.isfinite(y).all()
+    assert float((w.sum(-1) - 1).abs().max()) < 1e-4
+    # rows are independent: the first 192 utterances decoded alone give the same bits
+    with torch.no_grad():
+        y2, _, w2 = dec(mem[:192].contiguous(), None, None, T - 1)
+    assert torch.equal(y[:192], y2) and torch.equal(w[:192], w2)
+
+
 def test_c_abi_rejects_bad_arguments(H):
     """Error behaviour at the boundary: codes, never crashes."""
     from torch_tts_amd import _lib
