@@ -244,6 +244,51 @@ int ttsdec_profile_step(ttsdec_handle* h, const float* memory, int B, int L, int
                         size_t workspace_bytes, void* stream, float* ms_out, const char** names_out, int n_out,
                         int* n_kernels);
 
+/* ---------------------------------------------------------------------------------------
+ * Text encoder: Encoder2.forward in eval mode, tacotron/encoder.py:27-82
+ * with the packed bidirectional LSTM of tacotron/modules/rnn.py:112-127.  Produces the `memory`
+ * the decoder consumes.  Runs once per batch; exact fp32.
+ * ------------------------------------------------------------------------------------- */
+typedef struct ttsenc_dims {
+  int32_t alphabet_size; /* 1 + len(text.alphabet) (+ phonemes), tacotron.py:189-191 */
+  int32_t d_emb;         /* model.encoder.dim_emb (512): embedding and conv channels  */
+  int32_t d_out;         /* model.encoder.dim_out (512): 2 x LSTM hidden              */
+  int32_t conv_kernel;   /* 5                                                          */
+  float bn_eps;          /* 1e-5                                                       */
+} ttsenc_dims;
+typedef struct ttsenc_handle ttsenc_handle;
+
+/* Source tensors for ttsenc_pack_weights, the reference's state-dict order below ``encoder.``. */
+enum {
+  TTSENC_W_EMB = 0,   /* emb.weight [alphabet, d_emb]                                   */
+  TTSENC_W_CONV0,     /* conv.0.weight [d_emb, d_emb, k]                                */
+  TTSENC_W_BN0_W, TTSENC_W_BN0_B, TTSENC_W_BN0_MEAN, TTSENC_W_BN0_VAR, /* conv.1.*      */
+  TTSENC_W_CONV1,     /* conv.3.weight                                                  */
+  TTSENC_W_BN1_W, TTSENC_W_BN1_B, TTSENC_W_BN1_MEAN, TTSENC_W_BN1_VAR, /* conv.4.*      */
+  TTSENC_W_CONV2,     /* conv.6.weight                                                  */
+  TTSENC_W_BN2_MEAN, TTSENC_W_BN2_VAR, /* conv.7.running_{mean,var} (affine=False)      */
+  TTSENC_W_IH_FWD,    /* rnn.rnn.weight_ih_l0 [4H, 2*d_emb], H = d_out/2                */
+  TTSENC_W_HH_FWD,    /* rnn.rnn.weight_hh_l0 [4H, H]                                   */
+  TTSENC_W_IH_REV,    /* rnn.rnn.weight_ih_l0_reverse                                   */
+  TTSENC_W_HH_REV,    /* rnn.rnn.weight_hh_l0_reverse                                   */
+  TTSENC_W_H0,        /* rnn_h0 [1, 1, d_out]                                           */
+  TTSENC_W_C0,        /* rnn_c0 [1, 1, d_out]                                           */
+  TTSENC_W_COUNT
+};
+
+int ttsenc_create(const ttsenc_dims* dims, ttsenc_handle** out);
+int ttsenc_destroy(ttsenc_handle* h);
+const char* ttsenc_last_hip_error(const ttsenc_handle* h);
+int ttsenc_num_weight_tensors(const ttsenc_handle* h);
+size_t ttsenc_packed_bytes(const ttsenc_handle* h);
+int ttsenc_pack_weights(ttsenc_handle* h, const float* const* src, int n_src, void* blob, void* stream);
+int ttsenc_bind_weights(ttsenc_handle* h, const void* blob);
+size_t ttsenc_workspace_bytes(const ttsenc_handle* h, int B, int L);
+/* ids [B, L] int64 (0 = padding), lengths [B] int32 on the device; L_out = max(lengths) (host-known:
+ * the reference pads its output to the longest utterance, rnn.py:126); memory [B, L_out, d_out]. */
+int ttsenc_forward(ttsenc_handle* h, const int64_t* ids, const int32_t* lengths, int B, int L, int L_out, float* memory,
+                   void* workspace, size_t workspace_bytes, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

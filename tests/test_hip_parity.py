@@ -573,6 +573,52 @@ def test_shard_equivalence_bitwise(H):
     assert torch.equal(y, torch.cat([ya, yb])) and torch.equal(w, torch.cat([wa, wb])) and torch.equal(s, torch.cat([sa, sb]))
 
 
+# --------------------------------------------------------------------------
+# Encoder2 on the HIP path
+# --------------------------------------------------------------------------
+def test_encoder2_golden_and_ljspeech_dims(H):
+    import json
+    import os
+
+    import numpy as np
+    import torch_tts_amd as T
+
+    gd = os.path.join(os.path.dirname(__file__), "golden")
+    g = np.load(os.path.join(gd, "encoder_small.npz"))
+    meta = json.load(open(os.path.join(gd, "encoder_meta.json")))
+    wts = {k[2:]: torch.from_numpy(g[k]) for k in g.files if k.startswith("w/")}
+    enc = T.Encoder2(meta["dims"]["alphabet"], dim_out=meta["dims"]["d_out"], dim_emb=meta["dims"]["d_emb"])
+    missing, unexpected = enc.load_state_dict(wts, strict=False)
+    assert not unexpected and all(k.endswith("num_batches_tracked") for k in missing)
+    enc = enc.cuda().eval()
+    with torch.no_grad():
+        for suf in ("", "2"):  # the reference's own vectors (ragged lengths; case 2: no utterance fills the padding)
+            ids, lens, mem = (torch.from_numpy(g[n + suf]) for n in ("ids", "lengths", "memory"))
+            out = enc(ids.cuda(), lens)
+            assert out.shape == mem.shape
+            H.assert_close(out.cpu(), mem, RTOL, ATOL, "memory" + suf)
+            for b, n in enumerate(lens.tolist()):
+                if n < out.shape[1]:
+                    assert float(out[b, n:].abs().max()) == 0.0, "padded rows must be exactly zero (rnn.py:126)"
+        # LJSpeech dims against the oracle, and against the stock PyTorch-ROCm ops of the same module
+        wl = O.random_encoder2_weights(40, 512, 512, seed=3)
+        encl = T.Encoder2(40, dim_out=512, dim_emb=512)
+        encl.load_state_dict(wl, strict=False)
+        encl = encl.cuda().eval()
+        gen = torch.Generator().manual_seed(7)
+        B, L = 6, 47
+        lens = torch.tensor([47, 33, 47, 1, 20, 46])
+        ids = torch.randint(1, 40, (B, L), generator=gen)
+        for b in range(B):
+            ids[b, lens[b]:] = 0
+        ref = O.encoder2(ids, lens, wl)
+        out = encl(ids.cuda(), lens)
+        H.assert_close(out.cpu(), ref, RTOL, ATOL, "memory (LJSpeech dims)")
+        encl.use_hip = False
+        stock = encl(ids.cuda(), lens)
+        H.assert_close(out.cpu(), stock.cpu(), RTOL, ATOL, "HIP vs stock ops")
+
+
 def test_tacotron_forward_glue_sandra_style_config(H):
     """build_tacotron for a config-sandra / config_template style model: Taco2DecoderCell, r = 2,
     MelPostnet2 (postnet without type), encoder 256."""

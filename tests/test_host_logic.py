@@ -18,7 +18,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 def test_library_exports_every_declared_symbol():
     hdr = open(os.path.join(ROOT, "include", "ttsdec.h")).read()
     hdr = re.sub(r"/\*.*?\*/", "", hdr, flags=re.S)
-    declared = set(re.findall(r"\b(ttsdec_[a-z_0-9]+)\s*\(", hdr))
+    declared = set(re.findall(r"\b(tts(?:dec|enc)_[a-z_0-9]+)\s*\(", hdr))
     assert declared == set(_lib.SYMBOLS), declared ^ set(_lib.SYMBOLS)
     lib = _lib.load()
     for sym in declared:
@@ -117,6 +117,23 @@ def test_taco2_and_postnet2_state_dict_keys_match_the_reference(golden_taco2):
     e = T.Engine(pn.engine_dims(), None)
     assert e.num_weight_tensors() == len(ts)
     e.close()
+
+
+def test_encoder_module_keys_and_weight_order():
+    import json
+
+    meta = json.load(open(os.path.join(ROOT, "tests", "golden", "encoder_meta.json")))
+    enc = T.Encoder2(meta["dims"]["alphabet"], dim_out=meta["dims"]["d_out"], dim_emb=meta["dims"]["d_emb"])
+    keys = {k for k in enc.state_dict().keys() if not k.endswith("num_batches_tracked")}
+    assert keys == set(meta["keys"])
+    ts = enc.weight_tensors()
+    assert len(ts) == _lib.ENC_W_COUNT == 20
+    E, H = meta["dims"]["d_emb"], meta["dims"]["d_out"] // 2
+    assert tuple(ts[0].shape) == (meta["dims"]["alphabet"], E) and tuple(ts[14].shape) == (4 * H, 2 * E) and tuple(ts[17].shape) == (4 * H, H)
+    # CPU tensors / training keep the stock PyTorch path (autograd); padded rows come out exactly zero
+    ids = torch.tensor([[3, 1, 2, 5], [4, 2, 0, 0]])
+    out = enc.eval()(ids, torch.tensor([4, 2]))
+    assert out.shape == (2, 4, meta["dims"]["d_out"]) and float(out[1, 2:].abs().max()) == 0.0
 
 
 def test_weight_tensor_order_matches_header_enum(golden):

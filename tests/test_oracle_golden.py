@@ -167,3 +167,20 @@ def test_conv1d_fix_pairs_flat_weight_with_rolled_copies():
     ref = torch.nn.functional.conv1d(x, w_eff, padding=2)
     assert float((ours - ref).abs().max()) < 1e-5
     assert float((ours - torch.nn.functional.conv1d(x, w, padding=2)).abs().max()) > 1e-2
+
+
+# ---- Encoder2 ----
+def test_encoder2_oracle_matches_reference_vectors():
+    import os
+
+    import numpy as np
+
+    g = np.load(os.path.join(os.path.dirname(__file__), "golden", "encoder_small.npz"))
+    wts = {k[2:]: torch.from_numpy(g[k]) for k in g.files if k.startswith("w/")}
+    for suf in ("", "2"):
+        ids, lens, mem = (torch.from_numpy(g[n + suf]) for n in ("ids", "lengths", "memory"))
+        out = O.encoder2(ids, lens, wts)
+        assert out.shape == mem.shape
+        _close(out, mem, 1e-6)
+        for b, n in enumerate(lens.tolist()):
+            assert float(out[b, n:].abs().max()) == 0.0 if n < out.shape[1] else True

@@ -40,7 +40,17 @@ SYMBOLS = (
     "ttsdec_postnet",
     "ttsdec_cell_step",
     "ttsdec_profile_step",
+    "ttsenc_create",
+    "ttsenc_destroy",
+    "ttsenc_last_hip_error",
+    "ttsenc_num_weight_tensors",
+    "ttsenc_packed_bytes",
+    "ttsenc_pack_weights",
+    "ttsenc_bind_weights",
+    "ttsenc_workspace_bytes",
+    "ttsenc_forward",
 )
+ENC_W_COUNT = 20
 
 
 class Dims(C.Structure):
@@ -60,6 +70,16 @@ class Dims(C.Structure):
         ("cell_type", C.c_int32),
         ("d_pre_hidden", C.c_int32),
         ("postnet_type", C.c_int32),
+    ]
+
+
+class EncDims(C.Structure):
+    _fields_ = [
+        ("alphabet_size", C.c_int32),
+        ("d_emb", C.c_int32),
+        ("d_out", C.c_int32),
+        ("conv_kernel", C.c_int32),
+        ("bn_eps", C.c_float),
     ]
 
 
@@ -148,6 +168,24 @@ def load() -> C.CDLL:
             vp, vp, vp, vp, sz, vp,               # y, s, w, workspace, workspace_bytes, stream
             C.POINTER(f32), C.POINTER(C.c_char_p), i32, C.POINTER(i32),
         ]
+        lib.ttsenc_create.restype = i32
+        lib.ttsenc_create.argtypes = [C.POINTER(EncDims), C.POINTER(vp)]
+        lib.ttsenc_destroy.restype = i32
+        lib.ttsenc_destroy.argtypes = [vp]
+        lib.ttsenc_last_hip_error.restype = C.c_char_p
+        lib.ttsenc_last_hip_error.argtypes = [vp]
+        lib.ttsenc_num_weight_tensors.restype = i32
+        lib.ttsenc_num_weight_tensors.argtypes = [vp]
+        lib.ttsenc_packed_bytes.restype = sz
+        lib.ttsenc_packed_bytes.argtypes = [vp]
+        lib.ttsenc_pack_weights.restype = i32
+        lib.ttsenc_pack_weights.argtypes = [vp, C.POINTER(vp), i32, vp, vp]
+        lib.ttsenc_bind_weights.restype = i32
+        lib.ttsenc_bind_weights.argtypes = [vp, vp]
+        lib.ttsenc_workspace_bytes.restype = sz
+        lib.ttsenc_workspace_bytes.argtypes = [vp, i32, i32]
+        lib.ttsenc_forward.restype = i32
+        lib.ttsenc_forward.argtypes = [vp, vp, vp, i32, i32, i32, vp, vp, sz, vp]
         _lib = lib
         return _lib
 

@@ -112,7 +112,7 @@ __global__ __launch_bounds__(kGemmThreads) void gemm_rows_kernel(GemmArgs g) {
     pre_mask[j] = 1;
     pre_res[j] = 0.f;
     if (EK == EPI_RELU_DROPOUT && ok && g.dropout_mode == TTSDEC_DROPOUT_MASKS) pre_mask[j] = g.masks[(size_t)m * g.N + n];
-    if ((EK == EPI_BN_ISRU || EK == EPI_BN_LRELU) && ok) {
+    if ((EK == EPI_BN_ISRU || EK == EPI_BN_LRELU || EK == EPI_BN_ISRLU) && ok) {
       pre_bias[j] = g.alpha[n];
       pre_res[j] = g.beta[n];
     }
@@ -149,7 +149,7 @@ __global__ __launch_bounds__(kGemmThreads) void gemm_rows_kernel(GemmArgs g) {
     const int m = m0 + row, n = n0 + col;
     if (m >= g.M || n >= g.N) continue;
     float v = smem[row * LDO + col];
-    if (EK != EPI_BN_ISRU && EK != EPI_BN_LRELU && g.bias != nullptr) v = add_rn(v, pre_bias[j]);
+    if (EK != EPI_BN_ISRU && EK != EPI_BN_LRELU && EK != EPI_BN_ISRLU && g.bias != nullptr) v = add_rn(v, pre_bias[j]);
     auto store16 = [&](float val) {  // 16-bit copies for a following 16-bit GEMM
       const size_t o = (size_t)m * g.ldo + n;
       if (g.out_kind == 1) split_f16(val, g.out_h[o], g.out_l[o]);
@@ -185,6 +185,12 @@ __global__ __launch_bounds__(kGemmThreads) void gemm_rows_kernel(GemmArgs g) {
     } else if (EK == EPI_BN_ISRU) {
       // modules.py:181 isru(BatchNorm1d(conv(x))) with eval-mode BN as x*alpha + beta
       v = isru(add_rn(mul_rn(v, pre_bias[j]), pre_res[j]));
+      if (g.out != nullptr) g.out[(size_t)m * g.ldo + n] = v;
+      store16(v);
+    } else if (EK == EPI_BN_ISRLU) {
+      // encoder.py:49-57 ISRLU(BatchNorm1d(conv(x))): x >= 0 ? x : x / sqrt(1 + x*x)  (activations.py:13-14)
+      v = add_rn(mul_rn(v, pre_bias[j]), pre_res[j]);
+      v = v >= 0.f ? v : isru(v);
       if (g.out != nullptr) g.out[(size_t)m * g.ldo + n] = v;
       store16(v);
     } else if (EK == EPI_BN_LRELU) {
@@ -230,6 +236,7 @@ void launch_gemm(const GemmArgs& a, AKind ak, EpiKind ek, hipStream_t st) {
   if (a.M <= 0 || a.N <= 0) return;
   if (ak == A_CONV && ek == EPI_BN_ISRU) return launch_gemm_prec<A_CONV, EPI_BN_ISRU>(a, st);
   if (ak == A_CONV && ek == EPI_BN_LRELU) return launch_gemm_prec<A_CONV, EPI_BN_LRELU>(a, st);
+  if (ak == A_CONV && ek == EPI_BN_ISRLU) return launch_gemm_prec<A_CONV, EPI_BN_ISRLU>(a, st);
   if (ak == A_CONV && ek == EPI_RESIDUAL) return launch_gemm_prec<A_CONV, EPI_RESIDUAL>(a, st);
   switch (ek) {
     case EPI_PLAIN: return launch_gemm_cfg<A_PLAIN, EPI_PLAIN, PREC_F32>(a, st);
@@ -277,11 +284,20 @@ __global__ __launch_bounds__(kGemmThreads) void lstm_kernel(LstmArgs g) {
     const int m = m0 + e / BU, unit = u0 + e % BU;
     const bool ok = live && e < BM * BU && m < g.M && unit < H && g.mode != 1;
     const size_t idx = (size_t)m * H + unit;
-    const size_t pidx = (size_t)m * 4 * H + unit;
+    size_t pidx = (size_t)m * 4 * H + unit;
+    const float* part = g.partial;
+    bool pok = ok && g.mode == 2;
+    if (g.seq_lens != nullptr && ok) {  // packed-sequence step: this row's input projection at its own position
+      const int len = g.seq_lens[m];
+      const int pos = g.seq_reverse ? len - 1 - g.seq_t : g.seq_t;
+      pok = g.seq_t < len;
+      part = g.gx;
+      pidx = ((size_t)m * g.seq_L + (pok ? pos : 0)) * g.gx_ld + g.gx_off + unit;
+    }
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
-      pb[j][k] = ok ? g.bsum[k * H + unit] : 0.f;
-      pp[j][k] = (ok && g.mode == 2) ? g.partial[pidx + (size_t)k * H] : 0.f;
+      pb[j][k] = (ok && g.bsum != nullptr) ? g.bsum[k * H + unit] : 0.f;
+      pp[j][k] = pok ? part[pidx + (size_t)k * H] : 0.f;
     }
     pc[j] = ok ? g.c[idx] : 0.f;
     ph[j] = ok ? g.h_prev[idx] : 0.f;
@@ -308,6 +324,16 @@ __global__ __launch_bounds__(kGemmThreads) void lstm_kernel(LstmArgs g) {
       g.partial[pidx + 3 * H] = so;
       continue;
     }
+    const size_t idx = (size_t)m * H + unit;
+    int seq_pos = 0;
+    if (g.seq_lens != nullptr) {
+      const int len = g.seq_lens[m];
+      if (g.seq_t >= len) {  // this utterance has ended: state is carried unchanged, nothing is emitted
+        g.h_out[idx] = ph[j];
+        continue;
+      }
+      seq_pos = g.seq_reverse ? len - 1 - g.seq_t : g.seq_t;
+    }
     if (g.mode == 2) {  // finishing part: early sums + the late segments (fixed order: deterministic)
       si = add_rn(pp[j][0], si);
       sf = add_rn(pp[j][1], sf);
@@ -318,7 +344,6 @@ __global__ __launch_bounds__(kGemmThreads) void lstm_kernel(LstmArgs g) {
     const float gf = add_rn(sf, pb[j][1]);
     const float gg = add_rn(sg, pb[j][2]);
     const float go = add_rn(so, pb[j][3]);
-    const size_t idx = (size_t)m * H + unit;
     const float c_prev = pc[j];
     const float h_prev = ph[j];
     // nn.LSTMCell: c' = sigmoid(f)*c + sigmoid(i)*tanh(g); h' = sigmoid(o)*tanh(c')
@@ -329,6 +354,7 @@ __global__ __launch_bounds__(kGemmThreads) void lstm_kernel(LstmArgs g) {
     const float h = add_rn(mul_rn(g.pz, h_prev), mul_rn(q, h_new));
     g.h_out[idx] = h;
     if (g.h_out_h != nullptr) split_f16(h, g.h_out_h[idx], g.h_out_l[idx]);
+    if (g.seq_out != nullptr) g.seq_out[((size_t)m * g.seq_Lout + seq_pos) * g.seq_out_ld + g.seq_out_off + unit] = h;
     g.c[idx] = add_rn(mul_rn(g.pz, c_prev), mul_rn(q, c_new));
   }
 }
@@ -616,6 +642,30 @@ void launch_split(const float* src, f16* hi, f16* lo, size_t n, hipStream_t st) 
   hipLaunchKernelGGL(split_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, src, hi, lo, n);
 }
 
+__global__ void embed_kernel(const long long* ids, const float* table, int n_rows, int E, float* out_a, int lda, float* out_b,
+                             int ldb) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= (size_t)n_rows * E) return;
+  const int m = (int)(i / E), c = (int)(i % E);
+  const float v = table[(size_t)ids[m] * E + c];
+  out_a[(size_t)m * lda + c] = v;
+  out_b[(size_t)m * ldb + c] = v;
+}
+void launch_embed(const long long* ids, const float* table, int n_rows, int E, float* out_a, int lda, float* out_b, int ldb,
+                  hipStream_t st) {
+  const size_t n = (size_t)n_rows * E;
+  hipLaunchKernelGGL(embed_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, ids, table, n_rows, E, out_a, lda, out_b, ldb);
+}
+
+__global__ void fill_rows_kernel(float* dst, const float* row, int n_rows, int n_cols) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < (size_t)n_rows * n_cols) dst[i] = row[i % n_cols];
+}
+void launch_fill_rows(float* dst, const float* row, int n_rows, int n_cols, hipStream_t st) {
+  const size_t n = (size_t)n_rows * n_cols;
+  hipLaunchKernelGGL(fill_rows_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, dst, row, n_rows, n_cols);
+}
+
 __global__ void to_bf16_kernel(const float* src, bf16* dst, size_t n) {
   const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i < n) dst[i] = (bf16)src[i];
@@ -660,9 +710,9 @@ __global__ void bn_fold_kernel(const float* gamma, const float* betap, const flo
   if (i >= n) return;
   // eval-mode BatchNorm1d as y = x*alpha + beta, alpha = gamma/sqrt(var+eps), beta = b - mean*alpha
   const float invstd = div_rn(1.0f, sqrt_rn(add_rn(var[i], eps)));
-  const float a = mul_rn(invstd, gamma[i]);
+  const float a = gamma ? mul_rn(invstd, gamma[i]) : invstd;  // affine=False: gamma = 1, beta = 0
   alpha[i] = a;
-  beta[i] = sub_rn(betap[i], mul_rn(mean[i], a));
+  beta[i] = sub_rn(betap ? betap[i] : 0.f, mul_rn(mean[i], a));
 }
 void launch_bn_fold(const float* gamma, const float* betap, const float* mean, const float* var, float eps, float* alpha,
                     float* beta, int n, hipStream_t st) {

@@ -6,7 +6,7 @@ namespace ttsdec {
 
 // ---- generic row-GEMM (PreNet layers, query projection, mel/stop projection, postnet) ----
 enum AKind { A_PLAIN = 0, A_CONV = 1 };
-enum EpiKind { EPI_PLAIN = 0, EPI_RELU_DROPOUT = 1, EPI_PROJ = 2, EPI_BN_ISRU = 3, EPI_RESIDUAL = 4, EPI_BN_LRELU = 5 };
+enum EpiKind { EPI_PLAIN = 0, EPI_RELU_DROPOUT = 1, EPI_PROJ = 2, EPI_BN_ISRU = 3, EPI_RESIDUAL = 4, EPI_BN_LRELU = 5, EPI_BN_ISRLU = 6 };
 
 struct GemmArgs {
   // A operand.  A_PLAIN: up to three K segments of an [M, K] activation.
@@ -80,6 +80,17 @@ struct LstmArgs {
   // just before it.  mode 2: the remaining segments, + partial, then the cell update.
   int mode;
   float* partial;
+  // Sequence mode (packed LSTM over a padded batch, Encoder2's BiLSTM): seq_lens != nullptr.
+  // Row b is active while seq_t < seq_lens[b]; it then reads its input projection from
+  // gx[(b*seq_L + pos)*gx_ld + gx_off + gate*H + unit] (pos = seq_t, or len-1-seq_t when reversed)
+  // instead of `partial`, and writes h to seq_out[(b*seq_Lout + pos)*seq_out_ld + seq_out_off + unit].
+  // Inactive rows keep their state.  bsum may be nullptr (no bias).
+  const int* seq_lens;
+  int seq_t, seq_L, seq_Lout, seq_reverse;
+  const float* gx;
+  int gx_ld, gx_off;
+  float* seq_out;
+  int seq_out_ld, seq_out_off;
   Ctrl* ctrl;
   int slot;
   int dbg;  // measurement ablations (ttsdec_profile_step only): 1 = every load reads the zero block
@@ -134,6 +145,10 @@ void launch_add_vec(const float* a, const float* b, float* out, int n, hipStream
 void launch_copy(const float* src, float* dst, size_t n, hipStream_t st);
 void launch_split(const float* src, f16* hi, f16* lo, size_t n, hipStream_t st);
 void launch_to_bf16(const float* src, void* dst, size_t n, hipStream_t st);
+// out_a[m, 0:E] (ld lda) and out_b[m, 0:E] (ld ldb) = table[ids[m], :]   (nn.Embedding lookup)
+void launch_embed(const long long* ids, const float* table, int n_rows, int E, float* out_a, int lda, float* out_b, int ldb,
+                  hipStream_t st);
+void launch_fill_rows(float* dst, const float* row, int n_rows, int n_cols, hipStream_t st);  // dst[m, :] = row[:]
 void launch_conv_transpose(const float* w /*[Co,Ci,k]*/, float* out /*[Co,k,Ci]*/, int Co, int Ci, int k, hipStream_t st);
 // Conv1dFix (mps_fixes.py:22-29) pairs flat-weight column n*Ci + c with x[c, t + pad - n]:
 // out[co][tap][ci] = wflat[co][(k-1-tap)*Ci + ci]

@@ -1,8 +1,8 @@
 """Model assembly with the reference's API (tacotron/tacotron.py:20-56,165-224):
 ``Tacotron(encoder, decoder, postnet, refencoder).forward(...) -> (y, y_post, s,
 {"w", "kl_loss"})`` and ``build_tacotron(config)``.  The decoder and postnet are the
-HIP-backed drop-ins of this package; the encoder runs once per batch, is outside the
-hot path and stays stock PyTorch-ROCm ops."""
+HIP-backed drop-ins of this package; so is the encoder in eval mode (torch-tts_amd/encoder.py;
+it runs once per batch, before the hot path)."""
 from __future__ import annotations
 
 import torch
@@ -10,6 +10,7 @@ import torch.nn as nn
 
 from .decoder import Decoder
 from .decoder_cell import Taco2DecoderCell, Taco2ProdDecoderCell
+from .encoder import Encoder2
 from .postnet import MelPostnet, MelPostnet2
 
 
@@ -26,54 +27,6 @@ def weights_init(m):
             nn.init.xavier_normal_(m.weight, gain=1.5)
         if m.bias is not None:
             nn.init.zeros_(m.bias)
-
-
-class _ISRLU(nn.Module):
-    def forward(self, x):  # activations.py:13-14
-        return torch.where(x >= 0, x, x / torch.sqrt(1 + x * x))
-
-
-class _BiDiLSTM(nn.Module):
-    """Packed bidirectional LSTM wrapper with the reference's key names (rnn.py:112-127)."""
-
-    def __init__(self, input_size, hidden_size, bias=True):
-        super().__init__()
-        self.rnn = nn.LSTM(input_size, hidden_size, batch_first=True, bias=bias, bidirectional=True)
-
-    def forward(self, x, x_lengths, h0, c0):
-        x = nn.utils.rnn.pack_padded_sequence(x, x_lengths.cpu(), batch_first=True, enforce_sorted=False)
-        h0 = torch.cat(torch.chunk(h0, 2, dim=-1), dim=0).contiguous()
-        c0 = torch.cat(torch.chunk(c0, 2, dim=-1), dim=0).contiguous()
-        x, (h, _) = self.rnn(x, (h0, c0))
-        x, _ = nn.utils.rnn.pad_packed_sequence(x, batch_first=True)
-        return x, h
-
-
-class Encoder2(nn.Module):
-    """Text encoder producing ``memory`` (tacotron/encoder.py:27-82): embedding ->
-    3 x (conv5 + BN + ISRLU) -> concat with the embedding -> BiLSTM.  Stock PyTorch."""
-
-    def __init__(self, alphabet_size, dim_out=512, dim_emb=512):
-        super().__init__()
-        self.dim_out, self.dim_emb = dim_out, dim_emb
-        self.emb = nn.Embedding(alphabet_size, dim_emb, padding_idx=0)
-        self.conv = nn.Sequential(
-            nn.Conv1d(dim_emb, dim_emb, kernel_size=5, padding=2, bias=False), nn.BatchNorm1d(dim_emb), _ISRLU(),
-            nn.Conv1d(dim_emb, dim_emb, kernel_size=5, padding=2, bias=False), nn.BatchNorm1d(dim_emb), _ISRLU(),
-            nn.Conv1d(dim_emb, dim_emb, kernel_size=5, padding=2, bias=False), nn.BatchNorm1d(dim_emb, affine=False), _ISRLU(),
-        )
-        self.rnn = _BiDiLSTM(dim_emb * 2, dim_out // 2, bias=False)
-        self.rnn_h0 = nn.Parameter(torch.zeros(1, 1, dim_out))
-        self.rnn_c0 = nn.Parameter(torch.zeros(1, 1, dim_out))
-
-    def forward(self, x, x_lengths):
-        x = self.emb(x)
-        xc = self.conv(x.mT).mT
-        x = torch.cat((xc, x), dim=2)
-        x = nn.functional.dropout(x, p=0.1, training=self.training)
-        B = x.shape[0]
-        x, _ = self.rnn(x, x_lengths, self.rnn_h0.expand(-1, B, -1), self.rnn_c0.expand(-1, B, -1))
-        return x
 
 
 class Tacotron(nn.Module):
