@@ -202,11 +202,11 @@ def main():
     # ---- roofline of the dominant kernel: HIP events inside the library, on the launch stream ----
     kms = eng.profile_step(mem, iters=50, dropout_mode=_lib.DROPOUT_PHILOX, masks=None, seed=123)
     bytes_k = step_bytes(B, L, LJSPEECH["model"]["decoder"])  # (byte model of the LJSpeech cell)
-    grp = {"prenet": ["prenet0", "prenet1"], "lstm_att": ["lstm_att"], "query": ["query"], "attention": ["attention"],
-           "lstm_dec": ["lstm_dec"], "proj": ["proj"]}
+    grp = {"prenet": ["prenet", "prenet0", "prenet1"], "lstm_att": ["lstm_att"], "query": ["query"],
+           "attention": ["attention"], "lstm_dec": ["lstm_dec"], "proj": ["proj"]}
     per_kernel = {}
     for k, names in grp.items():
-        ms = sum(kms[n] for n in names)
+        ms = sum(kms[n] for n in names if n in kms)
         per_kernel[k] = {"ms": round(ms, 5), "alg_bytes": bytes_k[k], "GBps": round(bytes_k[k] / (ms * 1e-3) / 1e9, 1)}
     dom = max(per_kernel, key=lambda k: per_kernel[k]["ms"])
     step_ms_kernels = sum(v["ms"] for v in per_kernel.values())

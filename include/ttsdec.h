@@ -238,7 +238,8 @@ int ttsdec_cell_step(ttsdec_handle* h, const float* x, const float* memory, int 
 /* Measurement aid for bench.py: runs `iters` decode steps on the current
  * workspace state and reports the mean duration (ms, HIP events on `stream`) of each
  * kernel of the step, in launch order, into ms_out[0..n_out) (host array); returns the
- * number of kernels per step in *n_kernels and their names (static strings) in names_out. */
+ * number of kernels per step in *n_kernels and their names (static strings) in names_out.
+ * The profiled step is step 1 of a two-step call: y [B, 2r, d_mel], s [B, 2r], w [B, 2, L]. */
 int ttsdec_profile_step(ttsdec_handle* h, const float* memory, int B, int L, int iters, int dropout_mode,
                         const uint8_t* masks, uint64_t seed, float* y, float* s, float* w, void* workspace,
                         size_t workspace_bytes, void* stream, float* ms_out, const char** names_out, int n_out,

@@ -670,3 +670,76 @@ def test_tacotron_forward_glue(H):
         assert y.shape == (4, 16, 80) and y_post.shape == y.shape and s.shape == (4, 16, 1)
         assert out["w"].shape == (4, 16, 21) and float(out["kl_loss"]) == 0.0
         assert torch.equal(y_post, model.postnet(y))
+
+
+# --------------------------------------------------------------------------
+# the fused frame kernel (d_mel = 80, PreNet hidden 128 / 256) and the split-K projections:
+# stop rule, teacher forcing, call boundaries
+# --------------------------------------------------------------------------
+def _stop_case(wts, dims, mem, masks, T, first=5):
+    """(weights, threshold, k): the batch-global stop rule fires at step k, first <= k < T - 2.  The stop
+    logits of a random model drift one way; if that is upwards the fc_stop sign is flipped."""
+    for sign, first in ((1.0, first), (-1.0, first), (1.0, 2), (-1.0, 2)):
+        w2 = {k: (v * sign if "fc_stop" in k else v) for k, v in wts.items()}
+        _, s_all, _ = O.decode(w2, dims, mem, max_steps=T - 1, masks=masks, dropout="masks" if masks is not None else "off")
+        m = s_all.reshape(s_all.shape[0], T, -1).amin(dim=(0, 2))  # per-step batch minimum
+        run = torch.cummin(m, 0).values
+        cand = [k for k in range(first, T - 2) if m[k] < run[k - 1]]
+        if cand:
+            k = cand[0]
+            return w2, float((m[k] + run[k - 1]) / 2), k
+    raise AssertionError("no mid-sequence record minimum of the stop logit; change the seed")
+
+
+@pytest.mark.parametrize("prec", ["f32", "split_f16"])
+@pytest.mark.parametrize("r,d_pre", [(1, 128), (2, 256)])
+def test_frame_kernel_stop_teacher_and_chunks(H, prec, r, d_pre):
+    dims = O.DecoderDims(d_mel=80, r=r, d_pre=d_pre, d_ctx=64, h_att=256, h_dec=192)
+    wts = O.random_decoder_weights(dims, seed=21, nonzero_init_state=True)
+    B, L, T = 37, 23, 44
+    mem = O.synthetic_memory(B, L, dims.d_ctx, lengths=[23] * 30 + [1, 2, 5, 9, 14, 20, 23], seed=4)
+    masks = O.synthetic_masks(T, B, dims.d_pre, seed=6)
+    # (a) stop rule firing mid-graph: the frame is finished by the NEXT step's first kernel, the
+    # batch-global rule must still be inclusive of the firing step and cut everything after it
+    w2, thr, k = _stop_case(wts, dims, mem, masks, T)
+    oy, os_, ow = O.decode(w2, dims, mem, max_steps=T - 1, masks=masks, stop_threshold=thr)
+    assert ow.shape[1] == k + 1
+    dec = H.make_decoder(dims, w2, stop_threshold=thr)
+    dec.precision = prec
+    y, s, w, fired = H.run_decoder_with_masks(dec, mem, masks, max_steps=T - 1)
+    assert fired and w.shape[1] == k + 1
+    H.assert_close(y, oy, RTOL, ATOL, "y stop")
+    H.assert_close(s, os_, RTOL, ATOL, "s stop")
+    H.assert_close(w, ow, RTOL, ATOL, "w stop")
+    # (b) never firing: T = max_steps + 1, the last frame comes from the end-of-call launch
+    dec2 = H.make_decoder(dims, wts)
+    dec2.precision = prec
+    oy, os_, ow = O.decode(wts, dims, mem, max_steps=T - 1, masks=masks)
+    y, s, w, fired = H.run_decoder_with_masks(dec2, mem, masks, max_steps=T - 1)
+    assert not fired and y.shape == oy.shape
+    H.assert_close(y, oy, RTOL, ATOL, "y")
+    H.assert_close(s, os_, RTOL, ATOL, "s")
+    assert torch.equal(w.argmax(-1), ow.argmax(-1))
+    # (c) teacher forcing with per-step flags through graph replay
+    g = torch.Generator().manual_seed(9)
+    Tx = 41 * r + (r - 1)
+    x = torch.randn(B, Tx, 80, generator=g) * 0.5
+    flags = (torch.rand(Tx // r - 1, generator=g) > 0.3).tolist()
+    oy, os_, ow = O.decode(wts, dims, mem, masks=masks, x=x, teacher_flags=flags)
+    y, s, w, _ = H.run_decoder_with_masks(dec2, mem, masks, x=x, flags=flags)
+    H.assert_close(y, oy, RTOL, ATOL, "y teacher")
+    H.assert_close(s, os_, RTOL, ATOL, "s teacher")
+    H.assert_close(w, ow, RTOL, ATOL, "w teacher")
+    # (d) unbounded decode in chunks: every call boundary hands the pending frame over
+    w2, thr, k = _stop_case(wts, dims, mem, None, T)
+    oy, os_, ow = O.decode(w2, dims, mem, max_steps=0, dropout="off", stop_threshold=thr)
+    dec3 = H.make_decoder(dims, w2, stop_threshold=thr)
+    dec3.precision = prec
+    dec3.dropout_source = "off"
+    dec3.chunk_steps = 4
+    with torch.no_grad():
+        y, s, w = dec3(mem.cuda(), None, None, 0)
+    assert w.shape[1] == k + 1
+    H.assert_close(y.cpu(), oy, RTOL, ATOL, "y chunks")
+    H.assert_close(s.cpu(), os_, RTOL, ATOL, "s chunks")
+    H.assert_close(w.cpu(), ow, RTOL, ATOL, "w chunks")

@@ -19,6 +19,7 @@ ap.add_argument("--batch", type=int, default=256)
 ap.add_argument("--mem-len", type=int, default=120)
 ap.add_argument("--iters", type=int, default=20)
 ap.add_argument("--precision", default="f32", choices=["f32", "split_f16"])
+ap.add_argument("--dropout", default="philox", choices=["philox", "off"])
 args = ap.parse_args()
 dev = torch.device("cuda:0")
 torch.manual_seed(42)
@@ -31,6 +32,7 @@ dec = dec.to(dev).eval()
 dec.precision = args.precision
 eng = dec.engine(dev)
 mem = torch.tanh(torch.randn(args.batch, args.mem_len, 512, device=dev) * 0.5)
-ms = eng.profile_step(mem, iters=args.iters, dropout_mode=_lib.DROPOUT_PHILOX, masks=None, seed=1)
+ms = eng.profile_step(mem, iters=args.iters, dropout_mode=_lib.DROPOUT_PHILOX if args.dropout == "philox" else _lib.DROPOUT_OFF,
+                      masks=None, seed=1)
 torch.cuda.synchronize()
 print(json.dumps({k: round(v * 1e3, 2) for k, v in ms.items()}))

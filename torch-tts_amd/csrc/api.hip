@@ -36,14 +36,18 @@ struct BlobLayout {  // offsets in floats
 struct WsLayout {  // offsets in bytes
   size_t ctrl, xpre0, xpre, ctx, h_att[2], c_att, h_dec[2], c_dec, q, ynext, w[2];
   size_t xpre_h, xpre_l, ctx_h, ctx_l, h_att_h[2], h_att_l[2], h_dec_h[2], h_dec_l[2];  // split-fp16 planes
-  size_t gates_att, gates_dec;  // early partial gate sums [B, 4H]
+  size_t jparts;  // split-K partial sums of the mel/stop projection [kProjSplit][B, proj_ldp]
   size_t total;
 };
 
 }  // namespace
 
 constexpr int kGraphSlots = 30;  // decode steps per captured graph (even: buffer parity is baked per slot)
-constexpr int kEventsPerSlot = 4;
+// Split-K factors of the two small GEMMs of a step (their consumers add the slabs in order):
+// at B=256 the query projection then launches 256 workgroups instead of 128 and the mel/stop
+// projection 96 instead of 24, each with a proportionally shorter K loop.
+constexpr int kQuerySplit = 2;
+constexpr int kProjSplit = 4;
 
 struct ttsdec_handle {
   ttsdec_dims d;
@@ -52,18 +56,15 @@ struct ttsdec_handle {
   BlobLayout bl;
   const float* blob;
   std::string hip_err;
-  // multi-stream step loop
-  bool overlap;     // early partial-gate GEMMs on a side stream
   bool use_graph;   // replay a captured hipGraph instead of launching every kernel
-  hipStream_t cap_stream, side_stream;
-  hipEvent_t ev[kGraphSlots * kEventsPerSlot + 2];
+  hipStream_t cap_stream;
   bool streams_ready;
-  // one cached graph: valid for exactly this (workspace, blob, B, L, precision, overlap)
+  // one cached graph: valid for exactly this (workspace, blob, B, L, precision)
   hipGraphExec_t gexec;
   hipGraph_t graph;
   const void* g_ws;
   const void* g_blob;
-  int g_B, g_L, g_prec, g_overlap;
+  int g_B, g_L, g_prec;
 };
 
 namespace {
@@ -75,6 +76,15 @@ inline int query_ld(const ttsdec_dims& d) { return is_taco2(d) ? d.h_att + d.h_d
 inline int query_k(const ttsdec_dims& d) { return is_taco2(d) ? d.h_att + d.h_dec : d.h_att; }
 inline int proj_ld(const ttsdec_dims& d) { return is_taco2(d) ? d.h_att + d.h_dec + d.d_ctx : d.h_dec + d.d_ctx; }
 inline int proj_k(const ttsdec_dims& d) { return is_taco2(d) ? d.h_att + d.h_dec : d.h_dec + d.d_ctx; }
+inline int proj_n(const ttsdec_dims& d) { return d.r * d.d_mel + d.r; }
+inline int proj_ldp(const ttsdec_dims& d) { return (proj_n(d) + 3) & ~3; }
+// The fused frame kernel (frame_kernel.hip) covers the shipped PreNet shapes; other dims keep the
+// three-launch form (proj with its own epilogue, prenet0, prenet1).
+inline bool use_frame(const ttsdec_dims& d) { return frame_supported(d.d_mel, pre_hidden(d), d.d_pre); }
+inline int split_of(int K, int want) {  // split-K factor: slices must be whole 128-element K tiles
+  while (want > 1 && (K % want || (K / want) % 128)) --want;
+  return want;
+}
 
 BlobLayout make_blob_layout(const ttsdec_dims& d) {
   BlobLayout L;
@@ -160,7 +170,7 @@ WsLayout make_ws_layout(const ttsdec_dims& d, int B, int Lm) {
   W.h_dec[0] = take(b * d.h_dec);
   W.h_dec[1] = take(b * d.h_dec);
   W.c_dec = take(b * d.h_dec);
-  W.q = take(b * d.d_ctx);
+  W.q = take((size_t)kQuerySplit * b * d.d_ctx);
   W.ynext = take(b * d.d_mel);
   W.w[0] = take(b * Lm);
   W.w[1] = take(b * Lm);
@@ -171,8 +181,7 @@ WsLayout make_ws_layout(const ttsdec_dims& d, int B, int Lm) {
     W.h_att_h[i] = takeh(b * d.h_att); W.h_att_l[i] = takeh(b * d.h_att);
     W.h_dec_h[i] = takeh(b * d.h_dec); W.h_dec_l[i] = takeh(b * d.h_dec);
   }
-  W.gates_att = take(b * 4 * d.h_att);
-  W.gates_dec = take(b * 4 * d.h_dec);
+  W.jparts = take((size_t)kProjSplit * b * proj_ldp(d));
   W.total = off;
   return W;
 }
@@ -223,7 +232,7 @@ struct StepBufs {
   Ctrl* ctrl;
   float *xpre0, *xpre, *ctx, *h_att[2], *c_att, *h_dec[2], *c_dec, *q, *ynext, *w[2];
   f16 *xpre_h, *xpre_l, *ctx_h, *ctx_l, *h_att_h[2], *h_att_l[2], *h_dec_h[2], *h_dec_l[2];
-  float *gates_att, *gates_dec;
+  float* jparts;
 };
 
 StepBufs carve(const WsLayout& W, void* ws) {
@@ -241,7 +250,7 @@ StepBufs carve(const WsLayout& W, void* ws) {
     s.h_att_h[i] = hf(W.h_att_h[i]); s.h_att_l[i] = hf(W.h_att_l[i]);
     s.h_dec_h[i] = hf(W.h_dec_h[i]); s.h_dec_l[i] = hf(W.h_dec_l[i]);
   }
-  s.gates_att = f(W.gates_att); s.gates_dec = f(W.gates_dec);
+  s.jparts = f(W.jparts);
   return s;
 }
 
@@ -258,25 +267,26 @@ struct StepIo {
   uint64_t seed;
   float *y, *s, *w;
   bool use_ctrl;
+  int finalize;  // !use_ctrl, frame kernel: the projection partial sums are the previous step's frame
   int dbg;
 };
 
-// The kernels of one decode step.  A1/D1 are the early partial-gate GEMMs of the two LSTMs
-// (the K segments that do not wait for the kernel just before them), A2/D2 the finishing
-// parts; A/D are the unsplit cells.
-enum Node { N_P0, N_P1, N_A, N_A1, N_A2, N_Q, N_T, N_D, N_D1, N_D2, N_J };
+// The kernels of one decode step.  N_F is the fused frame kernel (finish the previous step's
+// projection + both PreNet layers), N_FIN its end-of-call form; N_P0 / N_P1 are the separate
+// PreNet layers used when the dims are outside what the frame kernel covers.
+enum Node { N_F, N_FIN, N_P0, N_P1, N_A, N_Q, N_T, N_D, N_J };
 
-constexpr int kKernelsPerStep = 7;
-const char* const kKernelNames[kKernelsPerStep] = {"prenet0", "prenet1", "lstm_att", "query", "attention", "lstm_dec", "proj"};
-const Node kProfileNodes[kKernelsPerStep] = {N_P0, N_P1, N_A, N_Q, N_T, N_D, N_J};
-// TTSDEC_PROFILE_PARTS=1 times the partial-gate nodes instead of the whole cells
-const Node kProfileNodesParts[kKernelsPerStep] = {N_A1, N_A2, N_A, N_D1, N_T, N_D, N_D2};
+constexpr int kMaxKernelsPerStep = 7;
+struct StepOrder {
+  int n;
+  Node nodes[kMaxKernelsPerStep];
+  const char* names[kMaxKernelsPerStep];
+};
 
 // split-fp16 needs every K segment to be whole 16-byte columns of fp16 (multiples of 8)
 bool split_ok(const ttsdec_dims& d) { return !((d.d_pre | d.d_ctx | d.h_att | d.h_dec) & 7); }
-enum { kSerialNodes = 7 };
 // launch order of one step: the Prod cell attends between its two LSTMs, the Taco2 cell after both
-const Node* step_order(const ttsdec_dims& d);
+const StepOrder& step_order(const ttsdec_dims& d);
 int lstm_prec(const ttsdec_handle* h) { return (h->precision == TTSDEC_PREC_SPLIT_F16 && split_ok(h->d)) ? 1 : 0; }
 
 void launch_node(const ttsdec_handle* h, const StepBufs& sb, const StepIo& io, Node node, hipStream_t st) {
@@ -291,6 +301,30 @@ void launch_node(const ttsdec_handle* h, const StepBufs& sb, const StepIo& io, N
   auto plane = [&](size_t float_off) { return reinterpret_cast<const f16*>(blob + float_off); };
 
   switch (node) {
+    case N_F:
+    case N_FIN: {
+      FrameArgs f;
+      memset(&f, 0, sizeof(f));
+      const int Ph = pre_hidden(d);
+      f.parts = sb.jparts; f.n_parts = split_of(proj_k(d), kProjSplit); f.ldp = proj_ldp(d);
+      f.part_stride = (size_t)B * proj_ldp(d);
+      f.proj_bias = blob + bl.proj_b;
+      f.y_out = io.y; f.s_out = io.s; f.ynext = sb.ynext;
+      f.r = d.r; f.d_mel = d.d_mel; f.t_rel = io.t_rel; f.t_stride = io.t_stride;
+      f.finalize = io.finalize; f.only_finalize = node == N_FIN ? 1 : 0;
+      f.dbg = io.dbg;
+      if (io.dbg & 1) f.finalize = 0;       // measurement ablations (profile_step only)
+      if (io.dbg & 8) f.only_finalize = 1;
+      f.W0 = blob + bl.pre0_w; f.b0 = blob + bl.pre0_b; f.W1 = blob + bl.pre1_w; f.b1 = blob + bl.pre1_b;
+      f.Ph = Ph; f.P = P;
+      f.dropout_mode = io.dropout_mode; f.masks = io.masks; f.mask_step_stride = (size_t)B * (Ph + P);
+      f.seed = io.seed; f.keep_scale = keep_scale;
+      f.xpre = sb.xpre;
+      if (prec) { f.xpre_h = sb.xpre_h; f.xpre_l = sb.xpre_l; }
+      f.M = B; f.ctrl = ctrl; f.slot = io.slot; f.t = io.t;
+      launch_frame(f, st);
+      break;
+    }
     case N_P0:
     case N_P1: {
       const int layer = node == N_P0 ? 0 : 1;
@@ -319,15 +353,11 @@ void launch_node(const ttsdec_handle* h, const StepBufs& sb, const StepIo& io, N
       launch_gemm(g, A_PLAIN, EPI_RELU_DROPOUT, st);
       break;
     }
-    case N_A:
-    case N_A1:
-    case N_A2: {
+    case N_A: {
       // attention LSTM: input cat[x_pre, ctx_prev] (decoder_cell.py:187), state h_att
       LstmArgs a;
       memset(&a, 0, sizeof(a));
       a.prec = prec;
-      a.mode = node == N_A ? 0 : (node == N_A1 ? 1 : 2);
-      a.partial = sb.gates_att;
       const int wld = P + D;
       // segment lists: whole = [x_pre | ctx | h], early = [ctx | h], late = [x_pre]
       const void *x0 = prec ? (const void*)sb.xpre_h : sb.xpre, *x0l = prec ? (const void*)sb.xpre_l : sb.xpre;
@@ -338,17 +368,9 @@ void launch_node(const ttsdec_handle* h, const StepBufs& sb, const StepIo& io, N
       auto W0 = [&](bool lo) { return prec ? (const void*)(lo ? wih_l : wih_h) : (const void*)wih; };
       auto W1 = [&](bool lo) { return prec ? (const void*)((lo ? wih_l : wih_h) + P) : (const void*)(wih + P); };
       auto W2 = [&](bool lo) { return prec ? (const void*)(lo ? whh_l : whh_h) : (const void*)whh; };
-      if (a.mode == 0) {
-        a.a = make_seg3(x0, P, P, x1, D, D, x2, Ha, Ha); a.a_lo = make_seg3(x0l, P, P, x1l, D, D, x2l, Ha, Ha);
-        a.w = make_seg3(W0(false), wld, P, W1(false), wld, D, W2(false), Ha, Ha);
-        a.w_lo = make_seg3(W0(true), wld, P, W1(true), wld, D, W2(true), Ha, Ha);
-      } else if (a.mode == 1) {
-        a.a = make_seg2(x1, D, D, x2, Ha, Ha); a.a_lo = make_seg2(x1l, D, D, x2l, Ha, Ha);
-        a.w = make_seg2(W1(false), wld, D, W2(false), Ha, Ha); a.w_lo = make_seg2(W1(true), wld, D, W2(true), Ha, Ha);
-      } else {
-        a.a = make_seg1(x0, P, P); a.a_lo = make_seg1(x0l, P, P);
-        a.w = make_seg1(W0(false), wld, P); a.w_lo = make_seg1(W0(true), wld, P);
-      }
+      a.a = make_seg3(x0, P, P, x1, D, D, x2, Ha, Ha); a.a_lo = make_seg3(x0l, P, P, x1l, D, D, x2l, Ha, Ha);
+      a.w = make_seg3(W0(false), wld, P, W1(false), wld, D, W2(false), Ha, Ha);
+      a.w_lo = make_seg3(W0(true), wld, P, W1(true), wld, D, W2(true), Ha, Ha);
       if (prec) { a.h_out_h = sb.h_att_h[1 - p]; a.h_out_l = sb.h_att_l[1 - p]; }
       a.bsum = blob + bl.att_b; a.h_prev = sb.h_att[p]; a.c = sb.c_att; a.h_out = sb.h_att[1 - p];
       a.M = B; a.H = Ha; a.K = P + D + Ha; a.pz = d.p_zoneout; a.ctrl = ctrl; a.slot = io.slot; a.dbg = io.dbg;
@@ -362,6 +384,7 @@ void launch_node(const ttsdec_handle* h, const StepBufs& sb, const StepIo& io, N
       if (is_taco2(d)) g.a = make_seg2(sb.h_att[1 - p], Ha, Ha, sb.h_dec[1 - p], Hd, Hd);
       else g.a = make_seg1(sb.h_att[1 - p], Ha, Ha);
       g.W = blob + bl.wq; g.ldw = query_ld(d); g.K = query_k(d); g.M = B; g.N = D; g.out = sb.q; g.ldo = D;
+      g.ksplit = split_of(g.K, kQuerySplit); g.kchunk = g.K / g.ksplit; g.split_stride = (size_t)B * D;
       g.ctrl = ctrl; g.slot = io.slot; g.t = io.t;
       launch_gemm(g, A_PLAIN, EPI_PLAIN, st);
       break;
@@ -370,20 +393,17 @@ void launch_node(const ttsdec_handle* h, const StepBufs& sb, const StepIo& io, N
       AttnArgs a;
       memset(&a, 0, sizeof(a));
       if (prec) { a.ctx_h = sb.ctx_h; a.ctx_l = sb.ctx_l; }
-      a.memory = io.memory; a.q = sb.q; a.w_prev = sb.w[p]; a.w_new = sb.w[1 - p]; a.w_out = io.w; a.ctx = sb.ctx;
+      a.memory = io.memory; a.q = sb.q; a.q_parts = split_of(query_k(d), kQuerySplit); a.q_stride = (size_t)B * D;
+      a.w_prev = sb.w[p]; a.w_new = sb.w[1 - p]; a.w_out = io.w; a.ctx = sb.ctx;
       a.B = B; a.L = io.L; a.D = D; a.t_rel = io.t_rel; a.t_stride = io.t_stride; a.ctrl = ctrl; a.slot = io.slot;
       launch_attn(a, st);
       break;
     }
-    case N_D:
-    case N_D1:
-    case N_D2: {
+    case N_D: {
       // decoder LSTM: input cat[h_att, ctx] (decoder_cell.py:191), state h_dec
       LstmArgs a;
       memset(&a, 0, sizeof(a));
       a.prec = prec;
-      a.mode = node == N_D ? 0 : (node == N_D1 ? 1 : 2);
-      a.partial = sb.gates_dec;
       const int wld = Ha + D;
       const void *x0 = prec ? (const void*)sb.h_att_h[1 - p] : sb.h_att[1 - p], *x0l = prec ? (const void*)sb.h_att_l[1 - p] : sb.h_att[1 - p];
       const void *x1 = prec ? (const void*)sb.ctx_h : sb.ctx, *x1l = prec ? (const void*)sb.ctx_l : sb.ctx;
@@ -393,17 +413,9 @@ void launch_node(const ttsdec_handle* h, const StepBufs& sb, const StepIo& io, N
       auto W0 = [&](bool lo) { return prec ? (const void*)(lo ? wih_l : wih_h) : (const void*)wih; };
       auto W1 = [&](bool lo) { return prec ? (const void*)((lo ? wih_l : wih_h) + Ha) : (const void*)(wih + Ha); };
       auto W2 = [&](bool lo) { return prec ? (const void*)(lo ? whh_l : whh_h) : (const void*)whh; };
-      if (a.mode == 0) {
-        a.a = make_seg3(x0, Ha, Ha, x1, D, D, x2, Hd, Hd); a.a_lo = make_seg3(x0l, Ha, Ha, x1l, D, D, x2l, Hd, Hd);
-        a.w = make_seg3(W0(false), wld, Ha, W1(false), wld, D, W2(false), Hd, Hd);
-        a.w_lo = make_seg3(W0(true), wld, Ha, W1(true), wld, D, W2(true), Hd, Hd);
-      } else if (a.mode == 1) {  // early: [h_att | h_dec_prev]
-        a.a = make_seg2(x0, Ha, Ha, x2, Hd, Hd); a.a_lo = make_seg2(x0l, Ha, Ha, x2l, Hd, Hd);
-        a.w = make_seg2(W0(false), wld, Ha, W2(false), Hd, Hd); a.w_lo = make_seg2(W0(true), wld, Ha, W2(true), Hd, Hd);
-      } else {  // late: [ctx]
-        a.a = make_seg1(x1, D, D); a.a_lo = make_seg1(x1l, D, D);
-        a.w = make_seg1(W1(false), wld, D); a.w_lo = make_seg1(W1(true), wld, D);
-      }
+      a.a = make_seg3(x0, Ha, Ha, x1, D, D, x2, Hd, Hd); a.a_lo = make_seg3(x0l, Ha, Ha, x1l, D, D, x2l, Hd, Hd);
+      a.w = make_seg3(W0(false), wld, Ha, W1(false), wld, D, W2(false), Hd, Hd);
+      a.w_lo = make_seg3(W0(true), wld, Ha, W1(true), wld, D, W2(true), Hd, Hd);
       if (prec) { a.h_out_h = sb.h_dec_h[1 - p]; a.h_out_l = sb.h_dec_l[1 - p]; }
       a.bsum = blob + bl.dec_b; a.h_prev = sb.h_dec[p]; a.c = sb.c_dec; a.h_out = sb.h_dec[1 - p];
       a.M = B; a.H = Hd; a.K = Ha + D + Hd; a.pz = d.p_zoneout; a.ctrl = ctrl; a.slot = io.slot; a.dbg = io.dbg;
@@ -416,78 +428,46 @@ void launch_node(const ttsdec_handle* h, const StepBufs& sb, const StepIo& io, N
       // projection input: cat[h_dec, ctx] (Prod, decoder_cell.py:192) or cat[h0, h1, zeros] (Taco2, :136)
       if (is_taco2(d)) g.a = make_seg2(sb.h_att[1 - p], Ha, Ha, sb.h_dec[1 - p], Hd, Hd);
       else g.a = make_seg2(sb.h_dec[1 - p], Hd, Hd, sb.ctx, D, D);
-      g.W = blob + bl.proj_w; g.ldw = proj_ld(d); g.K = proj_k(d); g.M = B; g.N = d.r * d.d_mel + d.r;
+      g.W = blob + bl.proj_w; g.ldw = proj_ld(d); g.K = proj_k(d); g.M = B; g.N = proj_n(d);
+      g.ctrl = ctrl; g.slot = io.slot; g.t = io.t;
+      if (use_frame(d)) {
+        // raw split-K partial sums; bias, leaky-ReLU, y / s / stop rule happen in the next frame kernel
+        g.out = sb.jparts; g.ldo = proj_ldp(d);
+        g.ksplit = split_of(g.K, kProjSplit); g.kchunk = g.K / g.ksplit; g.split_stride = (size_t)B * proj_ldp(d);
+        launch_gemm(g, A_PLAIN, EPI_PLAIN, st);
+        break;
+      }
       g.bias = blob + bl.proj_b;
       g.y_out = io.y; g.s_out = io.s; g.ynext = sb.ynext; g.r = d.r; g.d_mel = d.d_mel;
       g.t_rel = io.t_rel; g.t_stride = io.t_stride; g.stop_thr = 0.f; g.check_stop = 0;
-      g.ctrl = ctrl; g.slot = io.slot; g.t = io.t;
       launch_gemm(g, A_PLAIN, EPI_PROJ, st);
       break;
     }
   }
 }
 
-const Node kOrderProd[kSerialNodes] = {N_P0, N_P1, N_A, N_Q, N_T, N_D, N_J};   // decoder_cell.py:185-192
-const Node kOrderTaco2[kSerialNodes] = {N_P0, N_P1, N_A, N_D, N_Q, N_T, N_J};  // decoder_cell.py:116-136
-const Node* step_order(const ttsdec_dims& d) { return is_taco2(d) ? kOrderTaco2 : kOrderProd; }
+const StepOrder kOrderProd = {7, {N_P0, N_P1, N_A, N_Q, N_T, N_D, N_J},   // decoder_cell.py:185-192
+                              {"prenet0", "prenet1", "lstm_att", "query", "attention", "lstm_dec", "proj"}};
+const StepOrder kOrderTaco2 = {7, {N_P0, N_P1, N_A, N_D, N_Q, N_T, N_J},  // decoder_cell.py:116-136
+                               {"prenet0", "prenet1", "lstm_att", "lstm_dec", "query", "attention", "proj"}};
+const StepOrder kOrderProdF = {6, {N_F, N_A, N_Q, N_T, N_D, N_J}, {"prenet", "lstm_att", "query", "attention", "lstm_dec", "proj"}};
+const StepOrder kOrderTaco2F = {6, {N_F, N_A, N_D, N_Q, N_T, N_J}, {"prenet", "lstm_att", "lstm_dec", "query", "attention", "proj"}};
+const StepOrder& step_order(const ttsdec_dims& d) {
+  if (use_frame(d)) return is_taco2(d) ? kOrderTaco2F : kOrderProdF;
+  return is_taco2(d) ? kOrderTaco2 : kOrderProd;
+}
 
 // One step on a single stream, in the reference's order.  (For the Taco2 cell the attention
 // kernel at the end of step t also produces the context bmm(w_t, memory) that step t+1 starts
 // from, decoder_cell.py:118.)
 void launch_step_serial(const ttsdec_handle* h, const StepBufs& sb, const StepIo& io, hipStream_t st) {
-  const Node* order = step_order(h->d);
-  for (int i = 0; i < kSerialNodes; ++i) launch_node(h, sb, io, order[i], st);
-}
-
-// n_slots steps with the early partial-gate GEMMs on the side stream:
-//   main:  P0 P1 .......... A2 Q  T ........ D2 J        (critical path)
-//   side:        A1(t) .......   D1(t) .....    A1(t+1)
-// A1(t) needs ctx and h_att of step t-1 (after T(t-1)); D1(t) needs h_att of step t (after
-// A2(t)) and h_dec of step t-1.  Every cross-stream edge is an event; under stream capture
-// the same calls become graph edges.
-int launch_steps_overlapped(ttsdec_handle* h, const StepBufs& sb, StepIo io, int slot0, int n_slots, hipStream_t mainst) {
-  hipStream_t side = h->side_stream;
-  hipEvent_t* ev = h->ev;
-  bool ok = true;
-  auto rec = [&](hipEvent_t e, hipStream_t s) { ok &= (hipEventRecord(e, s) == hipSuccess); };
-  auto wait = [&](hipStream_t s, hipEvent_t e) { ok &= (hipStreamWaitEvent(s, e, 0) == hipSuccess); };
-  hipEvent_t ev_start = ev[kGraphSlots * kEventsPerSlot];
-  rec(ev_start, mainst);
-  wait(side, ev_start);
-  for (int i = 0; i < n_slots; ++i) {
-    io.slot = slot0 + i;
-    hipEvent_t* e = ev + (i % kGraphSlots) * kEventsPerSlot;  // [0] A1 done, [1] A2 done, [2] T done, [3] D1 done
-    launch_node(h, sb, io, N_A1, side);
-    rec(e[0], side);
-    launch_node(h, sb, io, N_P0, mainst);
-    launch_node(h, sb, io, N_P1, mainst);
-    wait(mainst, e[0]);
-    launch_node(h, sb, io, N_A2, mainst);
-    rec(e[1], mainst);
-    wait(side, e[1]);
-    launch_node(h, sb, io, N_D1, side);
-    rec(e[3], side);
-    launch_node(h, sb, io, N_Q, mainst);
-    launch_node(h, sb, io, N_T, mainst);
-    rec(e[2], mainst);
-    wait(side, e[2]);  // the next A1 reads this step's ctx
-    wait(mainst, e[3]);
-    launch_node(h, sb, io, N_D2, mainst);
-    launch_node(h, sb, io, N_J, mainst);
-  }
-  // join the side stream's trailing wait so a capture ends with a single leaf
-  hipEvent_t ev_end = ev[kGraphSlots * kEventsPerSlot + 1];
-  rec(ev_end, side);
-  wait(mainst, ev_end);
-  return (ok && hipGetLastError() == hipSuccess) ? TTSDEC_OK : TTSDEC_ERR_HIP;
+  const StepOrder& order = step_order(h->d);
+  for (int i = 0; i < order.n; ++i) launch_node(h, sb, io, order.nodes[i], st);
 }
 
 int ensure_streams(ttsdec_handle* h) {
   if (h->streams_ready) return TTSDEC_OK;
   if (hipStreamCreateWithFlags(&h->cap_stream, hipStreamNonBlocking) != hipSuccess) return TTSDEC_ERR_HIP;
-  if (hipStreamCreateWithFlags(&h->side_stream, hipStreamNonBlocking) != hipSuccess) return TTSDEC_ERR_HIP;
-  for (auto& e : h->ev)
-    if (hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) return TTSDEC_ERR_HIP;
   h->streams_ready = true;
   return TTSDEC_OK;
 }
@@ -500,22 +480,16 @@ void drop_graph(ttsdec_handle* h) {
 // Captures kGraphSlots steps (+ the t_cur advance) once per (workspace, blob, B, L, mode).
 int ensure_graph(ttsdec_handle* h, const StepBufs& sb, const void* ws, int B, int L) {
   const int prec = lstm_prec(h);
-  if (h->gexec && h->g_ws == ws && h->g_blob == h->blob && h->g_B == B && h->g_L == L && h->g_prec == prec &&
-      h->g_overlap == (int)h->overlap)
-    return TTSDEC_OK;
+  if (h->gexec && h->g_ws == ws && h->g_blob == h->blob && h->g_B == B && h->g_L == L && h->g_prec == prec) return TTSDEC_OK;
   drop_graph(h);
   StepIo io;
   memset(&io, 0, sizeof(io));
   io.B = B; io.L = L; io.use_ctrl = true;
   if (hipStreamBeginCapture(h->cap_stream, hipStreamCaptureModeRelaxed) != hipSuccess) return TTSDEC_ERR_HIP;
   int rc = TTSDEC_OK;
-  if (h->overlap && !is_taco2(h->d)) {
-    rc = launch_steps_overlapped(h, sb, io, 0, kGraphSlots, h->cap_stream);
-  } else {
-    for (int i = 0; i < kGraphSlots; ++i) {
-      io.slot = i;
-      launch_step_serial(h, sb, io, h->cap_stream);
-    }
+  for (int i = 0; i < kGraphSlots; ++i) {
+    io.slot = i;
+    launch_step_serial(h, sb, io, h->cap_stream);
   }
   launch_advance(sb.ctrl, kGraphSlots, h->cap_stream);
   hipGraph_t graph = nullptr;
@@ -534,7 +508,7 @@ int ensure_graph(ttsdec_handle* h, const StepBufs& sb, const void* ws, int B, in
     return TTSDEC_ERR_HIP;
   }
   h->graph = graph; h->gexec = exec;
-  h->g_ws = ws; h->g_blob = h->blob; h->g_B = B; h->g_L = L; h->g_prec = prec; h->g_overlap = (int)h->overlap;
+  h->g_ws = ws; h->g_blob = h->blob; h->g_B = B; h->g_L = L; h->g_prec = prec;
   return TTSDEC_OK;
 }
 
@@ -574,13 +548,12 @@ int ttsdec_create(const ttsdec_dims* dims, ttsdec_handle** out) {
   h->gexec = nullptr;
   h->graph = nullptr;
   h->g_ws = h->g_blob = nullptr;
-  // Measurement switches.  The two-stream schedule (early partial-gate GEMMs beside the small
-  // critical-path kernels) measured SLOWER on MI355X (126 vs 96 us per step at B=256: the early
-  // GEMM's 256 workgroups hold every CU's LDS, so the small kernels queue behind them), so it
-  // is opt-in; graph replay is on.
-  const char* e1 = getenv("TTSDEC_OVERLAP");
+  // Measurement switch: TTSDEC_NO_GRAPH=1 launches every step kernel from the host instead of
+  // replaying the captured graph.  (A two-stream schedule that ran the LSTMs' early K segments
+  // beside the small critical-path kernels was built and measured SLOWER on MI355X - 126 vs 96 us
+  // per step at B=256: the early GEMM's 256 workgroups hold every CU's LDS, so the small kernels
+  // queue behind them - and was removed; see DESIGN.md.)
   const char* e2 = getenv("TTSDEC_NO_GRAPH");
-  h->overlap = (e1 && atoi(e1));
   h->use_graph = !(e2 && atoi(e2));
   int ndev = 0, dev = -1;
   if (hipGetDeviceCount(&ndev) == hipSuccess && ndev > 0 && hipGetDevice(&dev) == hipSuccess) {
@@ -596,11 +569,7 @@ int ttsdec_create(const ttsdec_dims* dims, ttsdec_handle** out) {
 int ttsdec_destroy(ttsdec_handle* h) {
   if (!h) return TTSDEC_OK;
   drop_graph(h);
-  if (h->streams_ready) {
-    for (auto& e : h->ev) (void)hipEventDestroy(e);
-    (void)hipStreamDestroy(h->cap_stream);
-    (void)hipStreamDestroy(h->side_stream);
-  }
+  if (h->streams_ready) (void)hipStreamDestroy(h->cap_stream);
   delete h;
   return TTSDEC_OK;
 }
@@ -775,15 +744,13 @@ int ttsdec_decode(ttsdec_handle* h, const float* memory, int B, int L, int t_beg
     rc = ensure_graph(h, sb, workspace, B, L);
     if (rc != TTSDEC_OK) return rc;
     for (int done = 0; done < n_steps; done += kGraphSlots) HIP_TRY(h, hipGraphLaunch(h->gexec, st));
-  } else if (h->overlap && !is_taco2(h->d)) {
-    rc = launch_steps_overlapped(h, sb, io, 0, n_steps, st);
-    if (rc != TTSDEC_OK) return hip_fail(h, hipGetLastError(), "decode (overlapped)");
   } else {
     for (int i = 0; i < n_steps; ++i) {
       io.slot = i;
       launch_step_serial(h, sb, io, st);
     }
   }
+  if (use_frame(d)) launch_node(h, sb, io, N_FIN, st);  // the last step's frame: y, s, stop rule, next input
   launch_finish(sb.ctrl, T_out, st);
   return check_launch(h, "decode");
 }
@@ -992,14 +959,18 @@ int ttsdec_cell_step(ttsdec_handle* h, const float* x, const float* memory, int 
     if (prec) { a.ctx_h = sb.ctx_h; a.ctx_l = sb.ctx_l; }
     a.B = B; a.L = L; a.D = d.d_ctx; a.t_stride = 1;
     launch_attn(a, st);
-    const Node pre[4] = {N_P0, N_P1, N_A, N_D};
-    for (Node n : pre) launch_node(h, sb, io, n, st);
+    if (use_frame(d)) launch_node(h, sb, io, N_F, st);  // (io.finalize = 0: the input frame is x itself)
+    else { launch_node(h, sb, io, N_P0, st); launch_node(h, sb, io, N_P1, st); }
+    launch_node(h, sb, io, N_A, st);
+    launch_node(h, sb, io, N_D, st);
     launch_copy(sb.ctx, ctx, b * d.d_ctx, st);
     launch_node(h, sb, io, N_Q, st);
     launch_node(h, sb, io, N_T, st);
   } else {
     // the projection (fc_mel / fc_stop) belongs to Decoder, not to the cell
-    const Node cell_nodes[6] = {N_P0, N_P1, N_A, N_Q, N_T, N_D};
+    if (use_frame(d)) launch_node(h, sb, io, N_F, st);
+    else { launch_node(h, sb, io, N_P0, st); launch_node(h, sb, io, N_P1, st); }
+    const Node cell_nodes[4] = {N_A, N_Q, N_T, N_D};
     for (Node n : cell_nodes) launch_node(h, sb, io, n, st);
     launch_copy(sb.ctx, ctx, b * d.d_ctx, st);
   }
@@ -1032,8 +1003,9 @@ int ttsdec_profile_step(ttsdec_handle* h, const float* memory, int B, int L, int
                         size_t workspace_bytes, void* stream, float* ms_out, const char** names_out, int n_out,
                         int* n_kernels) {
   if (!h || !memory || !y || !s || !w || !workspace || !ms_out || iters <= 0) return TTSDEC_ERR_INVALID_ARG;
-  if (n_kernels) *n_kernels = kKernelsPerStep;
-  if (n_out < kKernelsPerStep) return TTSDEC_ERR_INVALID_ARG;
+  const StepOrder& order = step_order(h->d);
+  if (n_kernels) *n_kernels = order.n;
+  if (n_out < order.n) return TTSDEC_ERR_INVALID_ARG;
   if (dropout_mode == TTSDEC_DROPOUT_MASKS && !masks) return TTSDEC_ERR_INVALID_ARG;
   if (!h->blob) return TTSDEC_ERR_NOT_BOUND;
   int rc = check_device(h);
@@ -1047,13 +1019,13 @@ int ttsdec_profile_step(ttsdec_handle* h, const float* memory, int B, int L, int
   io.memory = memory; io.B = B; io.L = L; io.t = 0; io.t_rel = 0; io.t_stride = 1;
   io.dropout_mode = dropout_mode; io.masks = masks; io.seed = seed;
   io.y = y; io.s = s; io.w = w; io.use_ctrl = false;
+  io.t = 1; io.t_rel = 1; io.t_stride = 2; io.finalize = 1;  // a mid-sequence step: the frame kernel also finishes step 0's frame
   if (const char* e = getenv("TTSDEC_PROFILE_ABLATION")) io.dbg = atoi(e);  // measurement only
   hipEvent_t e0, e1;
   HIP_TRY(h, hipEventCreate(&e0));
   HIP_TRY(h, hipEventCreate(&e1));
-  const char* pe = getenv("TTSDEC_PROFILE_PARTS");
-  const Node* nodes = (pe && atoi(pe)) ? kProfileNodesParts : kProfileNodes;  // (names stay in Prod order)
-  for (int k = 0; k < kKernelsPerStep; ++k) {
+  const Node* nodes = order.nodes;
+  for (int k = 0; k < order.n; ++k) {
     for (int i = 0; i < 3; ++i) launch_node(h, sb, io, nodes[k], st);  // warm
     HIP_TRY(h, hipEventRecord(e0, st));
     for (int i = 0; i < iters; ++i) launch_node(h, sb, io, nodes[k], st);
@@ -1062,7 +1034,7 @@ int ttsdec_profile_step(ttsdec_handle* h, const float* memory, int B, int L, int
     float ms = 0.f;
     HIP_TRY(h, hipEventElapsedTime(&ms, e0, e1));
     ms_out[k] = ms / iters;
-    if (names_out) names_out[k] = kKernelNames[k];
+    if (names_out) names_out[k] = order.names[k];
   }
   (void)hipEventDestroy(e0);
   (void)hipEventDestroy(e1);

@@ -74,13 +74,16 @@ __device__ __forceinline__ float isru_sigmoid(float x) { return mul_rn(add_rn(1.
 __device__ __forceinline__ float sigmoid_f(float x) { return div_rn(1.0f, add_rn(1.0f, expf(-x))); }
 
 // ---------------------------------------------------------------------------
-// Philox4x32-10 (Salmon et al. 2011), used for the on-device Prenet dropout.
-// keep(step, layer, b, unit) = bit 0 of word 0 of philox(counter = {unit, b, step*2+layer, 0},
-// key = {seed_lo, seed_hi}).  The oracle carries the same function.
+// Philox4x32-10 (Salmon et al. 2011), used for the on-device PreNet dropout.  One call yields
+// 128 keep bits: keep(step, layer, b, unit) = bit (unit & 31) of word ((unit >> 5) & 3) of
+// philox(counter = {unit >> 7, b, step*2+layer, 0}, key = {seed_lo, seed_hi}).  (The 32-bit
+// multiplies are quarter rate on CDNA: one call per unit cost more than the PreNet GEMMs.)
+// The oracle carries the same function.
 // ---------------------------------------------------------------------------
-__host__ __device__ __forceinline__ uint32_t philox_keep(uint64_t seed, uint32_t step, uint32_t layer, uint32_t b,
-                                                         uint32_t unit) {
-  uint32_t c0 = unit, c1 = b, c2 = step * 2u + layer, c3 = 0u;
+struct Philox4 {
+  uint32_t w[4];
+};
+__host__ __device__ __forceinline__ Philox4 philox4x32_10(uint64_t seed, uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3) {
   uint32_t k0 = (uint32_t)seed, k1 = (uint32_t)(seed >> 32);
 #pragma unroll
   for (int i = 0; i < 10; ++i) {
@@ -94,7 +97,21 @@ __host__ __device__ __forceinline__ uint32_t philox_keep(uint64_t seed, uint32_t
     k0 += 0x9E3779B9u;
     k1 += 0xBB67AE85u;
   }
-  return c0 & 1u;
+  Philox4 r;
+  r.w[0] = c0; r.w[1] = c1; r.w[2] = c2; r.w[3] = c3;
+  return r;
+}
+// the 128 keep bits of units [128*group, 128*group + 128) of row b
+__host__ __device__ __forceinline__ Philox4 philox_keep_group(uint64_t seed, uint32_t step, uint32_t layer, uint32_t b,
+                                                              uint32_t group) {
+  return philox4x32_10(seed, group, b, step * 2u + layer, 0u);
+}
+__host__ __device__ __forceinline__ uint32_t philox_keep(uint64_t seed, uint32_t step, uint32_t layer, uint32_t b,
+                                                         uint32_t unit) {
+  const Philox4 r = philox_keep_group(seed, step, layer, b, unit >> 7);
+  const uint32_t w = (unit >> 5) & 3u;
+  const uint32_t word = w == 0 ? r.w[0] : (w == 1 ? r.w[1] : (w == 2 ? r.w[2] : r.w[3]));
+  return (word >> (unit & 31u)) & 1u;
 }
 
 // ---------------------------------------------------------------------------
@@ -144,6 +161,25 @@ __device__ __forceinline__ int seg_len(const Seg3& s, int seg) {
   return seg == 0 ? s.e0 : (seg == 1 ? s.e1 - s.e0 : s.e2 - s.e1);
 }
 __device__ __forceinline__ int seg_count(const Seg3& s) { return s.e2 > s.e1 ? 3 : (s.e1 > s.e0 ? 2 : 1); }
+
+// The part [lo, hi) of the virtual K axis of s (EB-byte elements), empty segments squeezed out:
+// what one workgroup of a split-K launch contracts over.
+__device__ __forceinline__ Seg3 seg_window(const Seg3& s, int lo, int hi, int eb) {
+  auto cut = [&](const void* p, int b, int e, const char*& q, int& n) {
+    const int a = lo > b ? lo : b, z = hi < e ? hi : e;
+    n = z > a ? z - a : 0;
+    q = static_cast<const char*>(p) + (size_t)(a - b) * eb;
+  };
+  const char *q0, *q1, *q2;
+  int n0, n1, n2, l0 = s.ld0, l1 = s.ld1, l2 = s.ld2;
+  cut(s.p0, 0, s.e0, q0, n0);
+  cut(s.p1, s.e0, s.e1, q1, n1);
+  cut(s.p2, s.e1, s.e2, q2, n2);
+  if (n0 == 0) { q0 = q1; n0 = n1; l0 = l1; q1 = q2; n1 = n2; l1 = l2; n2 = 0; }
+  if (n0 == 0) { q0 = q1; n0 = n1; l0 = l1; n1 = 0; }
+  if (n1 == 0) { q1 = q2; n1 = n2; l1 = l2; n2 = 0; }
+  return make_seg3(q0, l0, n0, q1, l1, n1, q2, l2, n2);
+}
 
 // ---------------------------------------------------------------------------
 // Split-fp16 representation of an fp32 value: x ~= hi + lo * 2^-11 with hi = fp16(x)

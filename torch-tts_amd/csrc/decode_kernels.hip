@@ -131,9 +131,17 @@ __global__ __launch_bounds__(kGemmThreads) void gemm_rows_kernel(GemmArgs g) {
       s = make_seg1(g.teacher + (size_t)(g.t * g.r - 1) * g.d_mel, g.teacher_T * g.d_mel, g.d_mel);
       s_lo = s;
     }
+    int kbase = 0;
+    if (EK == EPI_PLAIN && g.ksplit > 1) {  // this workgroup's slice of the K axis
+      kbase = blockIdx.z * g.kchunk;
+      const int kend = kbase + g.kchunk < g.K ? kbase + g.kchunk : g.K;
+      s = seg_window(s, kbase, kend, EB);
+      s_lo = seg_window(s_lo, kbase, kend, EB);
+      g.out += (size_t)blockIdx.z * g.split_stride;
+    }
     // W is one [N, K] matrix: cut it at A's segment boundaries
     const int k0 = s.e0, k1 = s.e1 - s.e0, k2 = s.e2 - s.e1;
-    const char *w = static_cast<const char*>(g.W), *wl = static_cast<const char*>(g.W_lo);
+    const char *w = static_cast<const char*>(g.W) + (size_t)kbase * EB, *wl = static_cast<const char*>(g.W_lo) + (size_t)kbase * EB;
     const Seg3 ws = make_seg3(w, g.ldw, k0, w + (size_t)k0 * EB, g.ldw, k1, w + (size_t)(k0 + k1) * EB, g.ldw, k2);
     const Seg3 wsl = make_seg3(wl, g.ldw, k0, wl + (size_t)k0 * EB, g.ldw, k1, wl + (size_t)(k0 + k1) * EB, g.ldw, k2);
     const LoaderW<EB> lb{ws, wsl, n0, g.N};
@@ -216,11 +224,11 @@ static void launch_gemm_cfg(const GemmArgs& a, hipStream_t st) {
   if (PREC != PREC_F32 || (a.M >= 64 && tiles_big >= 512)) {
     // 64x64 tiles; ring: fp32 4 x 16 KiB, bf16 5 x 16 KiB, split-fp16 4 x 32 KiB
     using Cfg = TileCfg<2, 2, 1, (PREC == PREC_BF16 ? 5 : 4), PREC>;
-    dim3 grid((a.N + Cfg::BN - 1) / Cfg::BN, (a.M + Cfg::BM - 1) / Cfg::BM);
+    dim3 grid((a.N + Cfg::BN - 1) / Cfg::BN, (a.M + Cfg::BM - 1) / Cfg::BM, (EK == EPI_PLAIN && a.ksplit > 1) ? a.ksplit : 1);
     hipLaunchKernelGGL((gemm_rows_kernel<Cfg, AK, EK>), grid, dim3(kGemmThreads), 0, st, a);
   } else {
     using Cfg = TileCfg<1, 1, 4, 4>;
-    dim3 grid((a.N + Cfg::BN - 1) / Cfg::BN, (a.M + Cfg::BM - 1) / Cfg::BM);
+    dim3 grid((a.N + Cfg::BN - 1) / Cfg::BN, (a.M + Cfg::BM - 1) / Cfg::BM, (EK == EPI_PLAIN && a.ksplit > 1) ? a.ksplit : 1);
     hipLaunchKernelGGL((gemm_rows_kernel<Cfg, AK, EK>), grid, dim3(kGemmThreads), 0, st, a);
   }
 }
@@ -436,6 +444,19 @@ __global__ __launch_bounds__(kAttnThreads) void attn_kernel(AttnArgs g) {
     const int c4 = lane + 64 * j;
     qv[j] = (c4 < D4 && !g.ctx_only) ? *reinterpret_cast<const float4*>(g.q + (size_t)b * D + c4 * 4)
                                      : make_float4(0.f, 0.f, 0.f, 0.f);  // ctx_only: no query, energies unused
+  }
+  if (!g.ctx_only) {  // split-K query: add the partial slabs in index order
+    for (int z = 1; z < g.q_parts; ++z) {
+#pragma unroll
+      for (int j = 0; j < NJ; ++j) {
+        const int c4 = lane + 64 * j;
+        if (c4 < D4) {
+          const float4 v = *reinterpret_cast<const float4*>(g.q + z * g.q_stride + (size_t)b * D + c4 * 4);
+          qv[j].x = add_rn(qv[j].x, v.x); qv[j].y = add_rn(qv[j].y, v.y);
+          qv[j].z = add_rn(qv[j].z, v.z); qv[j].w = add_rn(qv[j].w, v.w);
+        }
+      }
+    }
   }
   auto load_row = [&](int l, float4 (&r)[NJ]) {
 #pragma unroll

@@ -28,6 +28,11 @@ struct GemmArgs {
   const float* resid;  // EPI_RESIDUAL: out = resid[m, n] + acc
   float* out;          // [M, ldo]
   int ldo;
+  // Split-K over workgroups (A_PLAIN + EPI_PLAIN only): gridDim.z = ksplit, slice z contracts
+  // k in [z*kchunk, (z+1)*kchunk) and stores its raw partial sums to out + z*split_stride.
+  // The consumer adds the slabs in index order (deterministic); bias must be nullptr.
+  int ksplit, kchunk;
+  size_t split_stride;
   // optional 16-bit copies of the result for a following 16-bit GEMM (same shape as out):
   // out_kind 1: split-fp16 planes out_h / out_l; out_kind 2: one bf16 plane in out_h.
   // `out` itself may be nullptr when only the 16-bit form is consumed.
@@ -100,7 +105,9 @@ void launch_lstm(const LstmArgs& a, hipStream_t st);
 // ---- stepwise monotonic attention + context ----
 struct AttnArgs {
   const float* memory;  // [B, L, D]
-  const float* q;       // [B, D]
+  const float* q;       // [B, D]; q_parts > 1: q_parts partial slabs q_stride floats apart, summed in order
+  int q_parts;
+  size_t q_stride;
   const float* w_prev;  // [B, L]
   float* w_new;         // [B, L]
   float* w_out;         // [B, t_stride, L] (row t_rel) or nullptr
@@ -112,6 +119,47 @@ struct AttnArgs {
   int slot;
 };
 void launch_attn(const AttnArgs& a, hipStream_t st);
+
+// ---- frame kernel: finish the previous step's mel/stop projection, then the PreNet ----
+// The projection GEMM of step t-1 leaves split-K partial sums; this kernel (first launch of step t)
+// adds them up, applies bias / leaky-ReLU (decoder.py:52-54), writes y, s and the stop rule
+// (decoder.py:68) for step t-1, picks the next input frame (decoder.py:48, teacher forcing :61-66)
+// and runs both PreNet layers on it (modules/modules.py:37-41).  Everything here is local to a
+// block of batch rows, so it is one launch instead of three.
+struct FrameArgs {
+  const float* parts;  // [n_parts][M][ldp] partial sums of [fc_mel; fc_stop]
+  int n_parts, ldp;
+  size_t part_stride;
+  const float* proj_bias;  // [r*d_mel + r]
+  float* y_out;            // [B, t_stride*r, d_mel]
+  float* s_out;            // [B, t_stride*r]
+  float* ynext;            // [B, d_mel] input frame of the next step (kept for the call boundary / cell_step)
+  int r, d_mel, t_rel, t_stride;
+  float stop_thr;
+  int check_stop;
+  // ctrl == nullptr: 1 = the partial sums are step t-1's frame; 0 = the input frame is ynext as it stands
+  int finalize;
+  int only_finalize;  // end-of-call launch: finish the last step's frame, no PreNet
+  const float* teacher;
+  int teacher_T;
+  const uint8_t* teacher_flags;
+  const float *W0, *b0, *W1, *b1;  // PreNet: [Ph, d_mel], [Ph], [P, Ph], [P]
+  int Ph, P;
+  int dropout_mode;
+  const uint8_t* masks;  // this step's keep-masks: layer 0 [M, Ph] then layer 1 [M, P]
+  size_t mask_step_stride;
+  uint64_t seed;
+  float keep_scale;
+  float* xpre;           // [M, P]
+  f16 *xpre_h, *xpre_l;  // optional split-fp16 planes
+  int M;
+  Ctrl* ctrl;
+  int slot;
+  int t;    // ctrl == nullptr
+  int dbg;  // measurement ablations (ttsdec_profile_step only): bit 1 = no layer-0 MFMAs, bit 2 = no layer-1 MFMAs
+};
+bool frame_supported(int d_mel, int Ph, int P);
+void launch_frame(const FrameArgs& a, hipStream_t st);
 
 // ---- state init / bookkeeping ----
 struct InitArgs {

@@ -247,9 +247,9 @@ class Engine:
         """Mean per-kernel duration (ms) of one decode step; see ttsdec_profile_step."""
         B, L, _ = memory.shape
         d = self.dims
-        y = torch.empty(B, d.r, d.d_mel, device=self.device)
-        s = torch.empty(B, d.r, device=self.device)
-        w = torch.empty(B, 1, L, device=self.device)
+        y = torch.empty(B, 2 * d.r, d.d_mel, device=self.device)  # (the profiled step is step 1 of 2)
+        s = torch.empty(B, 2 * d.r, device=self.device)
+        w = torch.empty(B, 2, L, device=self.device)
         ws = self.workspace(B, L)
         ms = (C.c_float * 16)()
         names = (C.c_char_p * 16)()
