@@ -20,6 +20,7 @@ inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 
 struct BlobLayout {  // offsets in floats
   size_t pre0_w, pre0_b, pre1_w, pre1_b, wq;
+  size_t pre0_h, pre0_l, pre1_h, pre1_l;  // split-fp16 planes of the PreNet weights
   size_t att_ih, att_hh, att_b, dec_ih, dec_hh, dec_b;
   size_t att_ih_h, att_ih_l, att_hh_h, att_hh_l, dec_ih_h, dec_ih_l, dec_hh_h, dec_hh_l;  // split-fp16 planes
   size_t h0a, c0a, h0d, c0d;
@@ -80,7 +81,7 @@ inline int proj_n(const ttsdec_dims& d) { return d.r * d.d_mel + d.r; }
 inline int proj_ldp(const ttsdec_dims& d) { return (proj_n(d) + 3) & ~3; }
 // The fused frame kernel (frame_kernel.hip) covers the shipped PreNet shapes; other dims keep the
 // three-launch form (proj with its own epilogue, prenet0, prenet1).
-inline bool use_frame(const ttsdec_dims& d) { return frame_supported(d.d_mel, pre_hidden(d), d.d_pre); }
+inline bool use_frame(const ttsdec_dims& d) { return frame_supported(d.d_mel, d.r, pre_hidden(d), d.d_pre); }
 inline int split_of(int K, int want) {  // split-K factor: slices must be whole 128-element K tiles
   while (want > 1 && (K % want || (K / want) % 128)) --want;
   return want;
@@ -108,6 +109,8 @@ BlobLayout make_blob_layout(const ttsdec_dims& d) {
   L.dec_hh = take(4 * Hd * Hd);
   L.dec_b = take(4 * Hd);
   // fp16 planes occupy half a float per element
+  L.pre0_h = take((Ph * Mel + 1) / 2); L.pre0_l = take((Ph * Mel + 1) / 2);
+  L.pre1_h = take((P * Ph + 1) / 2); L.pre1_l = take((P * Ph + 1) / 2);
   L.att_ih_h = take(2 * Ha * (P + D)); L.att_ih_l = take(2 * Ha * (P + D));
   L.att_hh_h = take(2 * Ha * Ha);      L.att_hh_l = take(2 * Ha * Ha);
   L.dec_ih_h = take(2 * Hd * (Ha + D)); L.dec_ih_l = take(2 * Hd * (Ha + D));
@@ -316,6 +319,8 @@ void launch_node(const ttsdec_handle* h, const StepBufs& sb, const StepIo& io, N
       if (io.dbg & 1) f.finalize = 0;       // measurement ablations (profile_step only)
       if (io.dbg & 8) f.only_finalize = 1;
       f.W0 = blob + bl.pre0_w; f.b0 = blob + bl.pre0_b; f.W1 = blob + bl.pre1_w; f.b1 = blob + bl.pre1_b;
+      f.W0h = plane(bl.pre0_h); f.W0l = plane(bl.pre0_l); f.W1h = plane(bl.pre1_h); f.W1l = plane(bl.pre1_l);
+      f.prec = prec ? PREC_F16S : PREC_F32;
       f.Ph = Ph; f.P = P;
       f.dropout_mode = io.dropout_mode; f.masks = io.masks; f.mask_step_stride = (size_t)B * (Ph + P);
       f.seed = io.seed; f.keep_scale = keep_scale;
@@ -623,6 +628,8 @@ int ttsdec_pack_weights(ttsdec_handle* h, const float* const* src, int n_src, vo
   if (src[TTSDEC_W_DEC_BIH] && src[TTSDEC_W_DEC_BHH])
     launch_add_vec(src[TTSDEC_W_DEC_BIH], src[TTSDEC_W_DEC_BHH], b + L.dec_b, (int)(4 * Hd), st);
   auto hp = [&](size_t float_off) { return reinterpret_cast<f16*>(b + float_off); };
+  launch_split(src[TTSDEC_W_PRE0_W], hp(L.pre0_h), hp(L.pre0_l), Ph * Mel, st);
+  launch_split(src[TTSDEC_W_PRE1_W], hp(L.pre1_h), hp(L.pre1_l), P * Ph, st);
   launch_split(src[TTSDEC_W_ATT_IH], hp(L.att_ih_h), hp(L.att_ih_l), 4 * Ha * (P + D), st);
   launch_split(src[TTSDEC_W_ATT_HH], hp(L.att_hh_h), hp(L.att_hh_l), 4 * Ha * Ha, st);
   launch_split(src[TTSDEC_W_DEC_IH], hp(L.dec_ih_h), hp(L.dec_ih_l), 4 * Hd * (Ha + D), st);

@@ -144,6 +144,8 @@ struct FrameArgs {
   int teacher_T;
   const uint8_t* teacher_flags;
   const float *W0, *b0, *W1, *b1;  // PreNet: [Ph, d_mel], [Ph], [P, Ph], [P]
+  const f16 *W0h, *W0l, *W1h, *W1l;  // split-fp16 planes of W0 / W1 (prec = PREC_F16S)
+  int prec;                          // PREC_F32: exact fp32 MFMAs; PREC_F16S: split-fp16 (same accuracy class)
   int Ph, P;
   int dropout_mode;
   const uint8_t* masks;  // this step's keep-masks: layer 0 [M, Ph] then layer 1 [M, P]
@@ -158,7 +160,7 @@ struct FrameArgs {
   int t;    // ctrl == nullptr
   int dbg;  // measurement ablations (ttsdec_profile_step only): bit 1 = no layer-0 MFMAs, bit 2 = no layer-1 MFMAs
 };
-bool frame_supported(int d_mel, int Ph, int P);
+bool frame_supported(int d_mel, int r, int Ph, int P);
 void launch_frame(const FrameArgs& a, hipStream_t st);
 
 // ---- state init / bookkeeping ----
