@@ -1,0 +1,72 @@
+"""Pins oracle/vits2_oracle.py to vectors produced by the reference's own vits2 building blocks
+(tests/golden/make_golden_vits2.py).  CPU only."""
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import vits2_oracle as V
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+
+
+@pytest.fixture(scope="module")
+def gv():
+    z = np.load(os.path.join(HERE, "golden", "vits2_small.npz"))
+    meta = json.load(open(os.path.join(HERE, "golden", "vits2_meta.json")))
+    wts = {k[2:]: torch.from_numpy(z[k]) for k in z.files if k.startswith("w/")}
+    cases = {k: torch.from_numpy(z[k]) for k in z.files if not k.startswith("w/")}
+    return {"wts": wts, "c": cases, "dims": V.Vits2Dims(**meta["dims"]), "meta": meta}
+
+
+def close(a, b, tol=2e-6):
+    assert a.shape == b.shape
+    err = (a - b).abs().max().item()
+    assert err <= tol * max(1.0, b.abs().max().item()), err
+
+
+def test_text_encoder_matches_reference_blocks(gv):
+    c, d = gv["c"], gv["dims"]
+    x, m, logs, mask = V.text_encoder(c["te/ids"], c["te/lengths"], gv["wts"], d)
+    close(x, c["te/x"]); close(m, c["te/m"]); close(logs, c["te/logs"])
+    assert mask.shape == (3, 1, 13) and mask.sum().item() == 21
+    assert float(x[2, :, 1:].abs().max()) == 0.0  # padded frames are exactly zero
+
+
+def test_units_match_reference_blocks(gv):
+    c, d, w = gv["c"], gv["dims"], gv["wts"]
+    mask = V.sequence_mask(c["te/lengths"], 13).unsqueeze(1).float()
+    am = mask.unsqueeze(2) * mask.unsqueeze(-1)
+    close(V.mha(c["unit/x"], am, w, "enc_p.encoder.attn_layers.0", d.n_heads, d.window_size), c["unit/mha_win"])
+    close(V.ffn(c["unit/x"], mask, w, "enc_p.encoder.ffn_layers.0", d.kernel_size), c["unit/ffn"])
+    close(V.layer_norm_c(c["unit/x"], w["enc_p.encoder.norm_layers_1.0.gamma"], w["enc_p.encoder.norm_layers_1.0.beta"]), c["unit/ln"])
+    s = c["unit/gate_a"] + c["unit/gate_b"]
+    close(torch.tanh(s[:, :8]) * torch.sigmoid(s[:, 8:]), c["unit/gate"])
+    ymask = V.sequence_mask(c["flow/lengths"], 17).unsqueeze(1).float()
+    close(V.wn(c["unit/wn_in"] * ymask, ymask, w, "flow.flows.0.enc", d.flow_wn_layers, d.flow_kernel), c["unit/wn_out"])
+    close(V.encoder_stack(c["unit/enc_nowin_in"] * ymask, ymask, w, "flow.flows.0.pre_transformer", d.flow_tf_layers, d.flow_tf_heads,
+                          None, d.flow_tf_kernel), c["unit/enc_nowin_out"])
+
+
+def test_flow_reverse_matches_reference_blocks(gv):
+    c, d = gv["c"], gv["dims"]
+    ymask = V.sequence_mask(c["flow/lengths"], 17).unsqueeze(1).float()
+    out = V.flow_reverse(c["flow/z"], ymask, gv["wts"], d)
+    close(out, c["flow/out"], 5e-6)
+    # the layer applied last (flows.0) leaves its x0 half untouched: out[:, :half] is an input-only function of the
+    # previous layers, and the padded frames of the transformed half are exactly zero
+    half = d.inter_channels // 2
+    assert float(out[2, half:, 2:].abs().max()) == 0.0
+
+
+def test_random_weights_cover_every_key_the_functions_read():
+    d = V.Vits2Dims(n_vocab=11, inter_channels=8, hidden_channels=16, filter_channels=24, n_layers=1, flow_hidden=8, flow_wn_layers=2, n_flows=2)
+    w = V.random_vits2_weights(d, seed=3)
+    ids = torch.randint(0, 11, (2, 9)); lens = torch.tensor([9, 4])
+    x, m, logs, mask = V.text_encoder(ids, lens, w, d)
+    assert x.shape == (2, 16, 9) and m.shape == (2, 8, 9)
+    z = torch.randn(2, 8, 12)
+    out = V.flow_reverse(z, V.sequence_mask(torch.tensor([12, 5]), 12).unsqueeze(1).float(), w, d)
+    assert out.shape == z.shape and bool(torch.isfinite(out).all())
