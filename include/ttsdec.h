@@ -290,6 +290,63 @@ size_t ttsenc_workspace_bytes(const ttsenc_handle* h, int B, int L);
 int ttsenc_forward(ttsenc_handle* h, const int64_t* ids, const int32_t* lengths, int B, int L, int L_out, float* memory,
                    void* workspace, size_t workspace_bytes, void* stream);
 
+/* ---------------------------------------------------------------------------------------
+ * VITS2 second hot path (BASELINE.json configs[4]):
+ *   ttsvits_text_encoder  = TextEncoder.forward, vits2/models.py:369-380
+ *       (attentions.Encoder :76-93, MultiHeadAttention.attention :246-295 with the relative-position
+ *        window :297-368, FFN :411-419, modules.LayerNorm modules.py:24-27)
+ *   ttsvits_flow_reverse  = ResidualCouplingTransformersBlock.forward(reverse=True), models.py:803-810
+ *       over ResidualCouplingTransformersLayer.forward, models.py:506-531 (mean-only), with
+ *       modules.WN.forward modules.py:185-210, commons.fused_add_tanh_sigmoid_multiply commons.py:102-109
+ *       and modules.Flip modules.py:374-381.
+ * Eval mode, no speaker conditioning (g = None), exact fp32.  Activations at this boundary are
+ * CHANNEL-LAST: [B, T, C] (the reference's [B, C, T] transposed).
+ * ------------------------------------------------------------------------------------- */
+typedef struct ttsvits_dims {
+  int32_t n_vocab;          /* len(symbols)                                              */
+  int32_t inter_channels;   /* 192: flow channels; TextEncoder emits m, logs of this width */
+  int32_t hidden_channels;  /* 192                                                       */
+  int32_t filter_channels;  /* 768                                                       */
+  int32_t n_heads;          /* 2                                                         */
+  int32_t n_layers;         /* 6                                                         */
+  int32_t kernel_size;      /* 3 (FFN convs of the text encoder)                         */
+  int32_t window_size;      /* 4 (relative-position window; heads share the tables)      */
+  int32_t flow_hidden;      /* 192: WN width                                             */
+  int32_t flow_kernel;      /* 5:   WN conv taps (dilation_rate 1)                       */
+  int32_t flow_wn_layers;   /* 4                                                         */
+  int32_t n_flows;          /* 4 coupling layers (each followed by a Flip)               */
+  int32_t flow_tf_layers;   /* 2: pre_transformer = Encoder(half, half, 2 heads, 2 layers, k=3, no window) */
+  int32_t flow_tf_heads;    /* 2                                                         */
+  int32_t flow_tf_kernel;   /* 3                                                         */
+} ttsvits_dims;
+typedef struct ttsvits_handle ttsvits_handle;
+
+/* Source tensors for ttsvits_pack_weights (device fp32, the reference's parameter shapes), in this order:
+ *   enc_p.emb.weight;
+ *   per text-encoder layer i: attn_layers.i.conv_{q,k,v,o}.{weight,bias} (8), emb_rel_k, emb_rel_v,
+ *       norm_layers_1.i.{gamma,beta}, ffn_layers.i.conv_1.{weight,bias}, conv_2.{weight,bias},
+ *       norm_layers_2.i.{gamma,beta}                                            (18 per layer);
+ *   enc_p.proj.{weight,bias};
+ *   per coupling layer f (flow.flows.{2f}): per pre_transformer layer the same 16 tensors without the
+ *       emb_rel pair; pre.{weight,bias}; per WN layer j: in_layers.j EFFECTIVE weight (g*v/||v||), bias,
+ *       res_skip_layers.j effective weight, bias; post.{weight,bias}.
+ * A NULL entry leaves that tensor zero (a module that owns only the text encoder or only the flow). */
+int ttsvits_create(const ttsvits_dims* dims, ttsvits_handle** out);
+int ttsvits_destroy(ttsvits_handle* h);
+const char* ttsvits_last_hip_error(const ttsvits_handle* h);
+int ttsvits_num_weight_tensors(const ttsvits_handle* h);
+size_t ttsvits_packed_bytes(const ttsvits_handle* h);
+int ttsvits_pack_weights(ttsvits_handle* h, const float* const* src, int n_src, void* blob, void* stream);
+int ttsvits_bind_weights(ttsvits_handle* h, const void* blob);
+size_t ttsvits_text_encoder_workspace_bytes(const ttsvits_handle* h, int B, int T);
+/* ids [B, T] int64, lengths [B] int32 (device).  x [B, T, hidden], m and logs [B, T, inter]; padded frames are zero. */
+int ttsvits_text_encoder(ttsvits_handle* h, const int64_t* ids, const int32_t* lengths, int B, int T, float* x, float* m,
+                         float* logs, void* workspace, size_t workspace_bytes, void* stream);
+size_t ttsvits_flow_workspace_bytes(const ttsvits_handle* h, int B, int T);
+/* z [B, T, inter] -> out [B, T, inter]; lengths [B] int32 (device) give y_mask. */
+int ttsvits_flow_reverse(ttsvits_handle* h, const float* z, const int32_t* lengths, int B, int T, float* out, void* workspace,
+                         size_t workspace_bytes, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

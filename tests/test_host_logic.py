@@ -18,7 +18,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 def test_library_exports_every_declared_symbol():
     hdr = open(os.path.join(ROOT, "include", "ttsdec.h")).read()
     hdr = re.sub(r"/\*.*?\*/", "", hdr, flags=re.S)
-    declared = set(re.findall(r"\b(tts(?:dec|enc)_[a-z_0-9]+)\s*\(", hdr))
+    declared = set(re.findall(r"\b(tts(?:dec|enc|vits)_[a-z_0-9]+)\s*\(", hdr))
     assert declared == set(_lib.SYMBOLS), declared ^ set(_lib.SYMBOLS)
     lib = _lib.load()
     for sym in declared:
@@ -271,3 +271,41 @@ print("OK", len(ref_keys))
     env = dict(os.environ, PYTHONDONTWRITEBYTECODE="1")
     r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, env=env, timeout=300)
     assert r.returncode == 0 and r.stdout.startswith("OK"), r.stdout + r.stderr
+
+
+def test_vits2_modules_keys_tensor_counts_and_refusals():
+    import json
+    import warnings
+
+    import numpy as np
+
+    warnings.filterwarnings("ignore", category=FutureWarning)
+    z = np.load(os.path.join(ROOT, "tests", "golden", "vits2_small.npz"))
+    d = json.load(open(os.path.join(ROOT, "tests", "golden", "vits2_meta.json")))["dims"]
+    ref_keys = {k[2:] for k in z.files if k.startswith("w/")}
+    te = T.vits2.TextEncoder(d["n_vocab"], d["inter_channels"], d["hidden_channels"], d["filter_channels"], d["n_heads"], d["n_layers"], d["kernel_size"], 0.1)
+    assert {"enc_p." + k for k in te.state_dict()} == {k for k in ref_keys if k.startswith("enc_p.")}
+    fl = T.vits2.ResidualCouplingTransformersBlock(d["inter_channels"], d["flow_hidden"], d["flow_kernel"], 1, d["flow_wn_layers"], n_flows=d["n_flows"],
+                                                   use_transformer_flows=True)
+    mine = {"flow." + k for k in fl.state_dict() if "post_transformer" not in k}
+    assert mine == {k for k in ref_keys if k.startswith("flow.")}
+    # tensor counts the C ABI expects (include/ttsdec.h): 1 + 18/layer + 2 ; per flow 16/tf-layer + 2 + 4/WN-layer + 2
+    lib = _lib.load()
+    import ctypes as C
+
+    h = C.c_void_p()
+    dims = _lib.VitsDims(*[int(d[n]) for n, _ in _lib.VitsDims._fields_])
+    assert lib.ttsvits_create(C.byref(dims), C.byref(h)) == _lib.OK
+    n_text = 1 + 18 * d["n_layers"] + 2
+    n_flow = d["n_flows"] * (16 * d["flow_tf_layers"] + 2 + 4 * d["flow_wn_layers"] + 2)
+    assert lib.ttsvits_num_weight_tensors(h) == n_text + n_flow
+    assert len([te.emb.weight] + te.encoder.weight_tensors() + [te.proj.weight, te.proj.bias]) == n_text
+    assert sum(len(fl.flows[2 * i].weight_tensors()) for i in range(d["n_flows"])) == n_flow
+    assert lib.ttsvits_packed_bytes(h) % 256 == 0 and lib.ttsvits_text_encoder_workspace_bytes(h, 2, 13) > 0
+    assert lib.ttsvits_flow_reverse(h, 256, 256, 1, 4, 256, 256, 1 << 30, None) == _lib.ERR_NOT_BOUND
+    lib.ttsvits_destroy(h)
+    bad = _lib.VitsDims(*[int(d[n]) for n, _ in _lib.VitsDims._fields_])
+    bad.inter_channels = 18  # half = 9 is not a multiple of 4
+    assert lib.ttsvits_create(C.byref(bad), C.byref(h)) == _lib.ERR_DIMS
+    with pytest.raises(RuntimeError):
+        te.eval()(torch.zeros(1, 4, dtype=torch.long), torch.tensor([4]))  # CPU tensors: no fallback

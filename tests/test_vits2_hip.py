@@ -1,0 +1,116 @@
+"""GPU parity of the VITS2 path: ttsvits_* through the drop-in modules against
+(a) vectors from the reference's own blocks and (b) the CPU oracle at the ModelConfig-default sizes."""
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import vits2_oracle as V
+
+pytestmark = pytest.mark.gpu
+HERE = os.path.dirname(os.path.abspath(__file__))
+RTOL, ATOL = 1e-4, 1e-5
+
+
+def _close(a, b, what, rtol=RTOL, atol=ATOL):
+    a, b = a.detach().cpu(), b.detach().cpu()
+    assert a.shape == b.shape, (what, a.shape, b.shape)
+    err = (a - b).abs()
+    bad = err > atol + rtol * b.abs()
+    assert not bool(bad.any()), f"{what}: max abs err {err.max().item():.3e} (ref max {b.abs().max().item():.3e}), {int(bad.sum())} elements out"
+
+
+@pytest.fixture(scope="module")
+def gv():
+    z = np.load(os.path.join(HERE, "golden", "vits2_small.npz"))
+    meta = json.load(open(os.path.join(HERE, "golden", "vits2_meta.json")))
+    wts = {k[2:]: torch.from_numpy(z[k]) for k in z.files if k.startswith("w/")}
+    cases = {k: torch.from_numpy(z[k]) for k in z.files if not k.startswith("w/")}
+    return {"wts": wts, "c": cases, "d": meta["dims"]}
+
+
+def _text_encoder(d, wts):
+    import torch_tts_amd as T
+
+    te = T.vits2.TextEncoder(d["n_vocab"], d["inter_channels"], d["hidden_channels"], d["filter_channels"], d["n_heads"], d["n_layers"],
+                             d["kernel_size"], 0.1)
+    sd = {k[len("enc_p."):]: v for k, v in wts.items() if k.startswith("enc_p.")}
+    te.load_state_dict(sd, strict=True)
+    return te.cuda().eval()
+
+
+def _flow(d, wts):
+    import torch_tts_amd as T
+
+    fl = T.vits2.ResidualCouplingTransformersBlock(d["inter_channels"], d["flow_hidden"], d["flow_kernel"], 1, d["flow_wn_layers"],
+                                                   n_flows=d["n_flows"], use_transformer_flows=True)
+    sd = {k[len("flow."):]: v for k, v in wts.items() if k.startswith("flow.")}
+    missing, unexpected = fl.load_state_dict(sd, strict=False)
+    assert not unexpected and all("post_transformer" in k for k in missing), (missing, unexpected)
+    return fl.cuda().eval()
+
+
+def test_text_encoder_golden(gv):
+    c = gv["c"]
+    te = _text_encoder(gv["d"], gv["wts"])
+    with torch.no_grad():
+        x, m, logs, mask = te(c["te/ids"].cuda(), c["te/lengths"].cuda())
+    _close(x, c["te/x"], "x")
+    _close(m, c["te/m"], "m")
+    _close(logs, c["te/logs"], "logs")
+    assert mask.shape == (3, 1, 13) and float(x[2, :, 1:].abs().max()) == 0.0
+
+
+def test_flow_reverse_golden(gv):
+    c = gv["c"]
+    fl = _flow(gv["d"], gv["wts"])
+    ymask = V.sequence_mask(c["flow/lengths"], 17).unsqueeze(1).float()
+    with torch.no_grad():
+        out = fl(c["flow/z"].cuda(), ymask.cuda(), reverse=True)
+    _close(out, c["flow/out"], "flow out")
+
+
+@pytest.mark.parametrize("B,T,lengths", [(4, 120, [120, 77, 31, 1]), (2, 37, None)])
+def test_text_encoder_default_dims_vs_oracle(B, T, lengths):
+    d = V.Vits2Dims()
+    wts = V.random_vits2_weights(d, seed=5)
+    g = torch.Generator().manual_seed(2)
+    ids = torch.randint(0, d.n_vocab, (B, T), generator=g)
+    lens = torch.tensor(lengths if lengths else [T] * B)
+    ox, om, ol, _ = V.text_encoder(ids, lens, wts, d)
+    te = _text_encoder({**d.__dict__}, wts)
+    with torch.no_grad():
+        x, m, logs, _ = te(ids.cuda(), lens.cuda())
+    _close(x, ox, "x")
+    _close(m, om, "m")
+    _close(logs, ol, "logs")
+
+
+@pytest.mark.parametrize("B,T,lengths", [(4, 600, [600, 411, 87, 2]), (3, 50, None)])
+def test_flow_reverse_default_dims_vs_oracle(B, T, lengths):
+    d = V.Vits2Dims()
+    wts = V.random_vits2_weights(d, seed=6)
+    g = torch.Generator().manual_seed(3)
+    z = torch.randn(B, d.inter_channels, T, generator=g)
+    lens = torch.tensor(lengths if lengths else [T] * B)
+    ymask = V.sequence_mask(lens, T).unsqueeze(1).float()
+    ref = V.flow_reverse(z, ymask, wts, d)
+    fl = _flow({**d.__dict__}, wts)
+    with torch.no_grad():
+        out = fl(z.cuda(), ymask.cuda(), reverse=True)
+    _close(out, ref, "flow out", rtol=2e-4, atol=2e-4)
+    # reverse flow only ever subtracts from x1: the x0 half of the last layer passes through bit-exactly
+    assert torch.equal(out.cpu()[:, : d.inter_channels // 2] != 0, ref[:, : d.inter_channels // 2] != 0)
+
+
+def test_vits_modules_refuse_what_is_outside_the_path():
+    import torch_tts_amd as T
+
+    fl = T.vits2.ResidualCouplingTransformersBlock(192, 192, 5, 1, 4, use_transformer_flows=True).cuda().eval()
+    x = torch.zeros(1, 192, 8, device="cuda")
+    with torch.no_grad(), pytest.raises(NotImplementedError):
+        fl(x, torch.ones(1, 1, 8, device="cuda"), reverse=False)
+    with pytest.raises(NotImplementedError):
+        T.vits2.ResidualCouplingTransformersBlock(192, 192, 5, 1, 4, use_transformer_flows=False)

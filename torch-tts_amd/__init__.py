@@ -8,6 +8,7 @@ from .decoder_cell import LSTMZoneoutCell, PreNet, StepwiseMonotonicAttention, T
 from .engine import Engine, EngineDims
 from .postnet import Conv1dFix, MelPostnet, MelPostnet2
 from .tacotron import Encoder2, Tacotron, build_tacotron, lengths_to_mask
+from . import vits2  # noqa: F401  (TextEncoder, ResidualCouplingTransformersBlock)
 
 __all__ = [
     "Decoder", "Taco2ProdDecoderCell", "Taco2DecoderCell", "PreNet", "LSTMZoneoutCell", "StepwiseMonotonicAttention", "MelPostnet", "MelPostnet2",

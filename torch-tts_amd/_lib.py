@@ -49,6 +49,17 @@ SYMBOLS = (
     "ttsenc_bind_weights",
     "ttsenc_workspace_bytes",
     "ttsenc_forward",
+    "ttsvits_create",
+    "ttsvits_destroy",
+    "ttsvits_last_hip_error",
+    "ttsvits_num_weight_tensors",
+    "ttsvits_packed_bytes",
+    "ttsvits_pack_weights",
+    "ttsvits_bind_weights",
+    "ttsvits_text_encoder_workspace_bytes",
+    "ttsvits_text_encoder",
+    "ttsvits_flow_workspace_bytes",
+    "ttsvits_flow_reverse",
 )
 ENC_W_COUNT = 20
 
@@ -81,6 +92,12 @@ class EncDims(C.Structure):
         ("conv_kernel", C.c_int32),
         ("bn_eps", C.c_float),
     ]
+
+
+class VitsDims(C.Structure):
+    _fields_ = [(n, C.c_int32) for n in (
+        "n_vocab", "inter_channels", "hidden_channels", "filter_channels", "n_heads", "n_layers", "kernel_size", "window_size",
+        "flow_hidden", "flow_kernel", "flow_wn_layers", "n_flows", "flow_tf_layers", "flow_tf_heads", "flow_tf_kernel")]
 
 
 class TtsdecError(RuntimeError):
@@ -186,6 +203,28 @@ def load() -> C.CDLL:
         lib.ttsenc_workspace_bytes.argtypes = [vp, i32, i32]
         lib.ttsenc_forward.restype = i32
         lib.ttsenc_forward.argtypes = [vp, vp, vp, i32, i32, i32, vp, vp, sz, vp]
+        lib.ttsvits_create.restype = i32
+        lib.ttsvits_create.argtypes = [C.POINTER(VitsDims), C.POINTER(vp)]
+        lib.ttsvits_destroy.restype = i32
+        lib.ttsvits_destroy.argtypes = [vp]
+        lib.ttsvits_last_hip_error.restype = C.c_char_p
+        lib.ttsvits_last_hip_error.argtypes = [vp]
+        lib.ttsvits_num_weight_tensors.restype = i32
+        lib.ttsvits_num_weight_tensors.argtypes = [vp]
+        lib.ttsvits_packed_bytes.restype = sz
+        lib.ttsvits_packed_bytes.argtypes = [vp]
+        lib.ttsvits_pack_weights.restype = i32
+        lib.ttsvits_pack_weights.argtypes = [vp, C.POINTER(vp), i32, vp, vp]
+        lib.ttsvits_bind_weights.restype = i32
+        lib.ttsvits_bind_weights.argtypes = [vp, vp]
+        lib.ttsvits_text_encoder_workspace_bytes.restype = sz
+        lib.ttsvits_text_encoder_workspace_bytes.argtypes = [vp, i32, i32]
+        lib.ttsvits_text_encoder.restype = i32
+        lib.ttsvits_text_encoder.argtypes = [vp, vp, vp, i32, i32, vp, vp, vp, vp, sz, vp]
+        lib.ttsvits_flow_workspace_bytes.restype = sz
+        lib.ttsvits_flow_workspace_bytes.argtypes = [vp, i32, i32]
+        lib.ttsvits_flow_reverse.restype = i32
+        lib.ttsvits_flow_reverse.argtypes = [vp, vp, vp, i32, i32, vp, vp, sz, vp]
         _lib = lib
         return _lib
 

@@ -101,7 +101,7 @@ __global__ __launch_bounds__(kGemmThreads) void gemm_rows_kernel(GemmArgs g) {
   const int n0 = blockIdx.x * BN;
 
   // Epilogue operands are requested BEFORE the K loop (their latency hides under it).
-  float pre_bias[EPT], pre_res[EPT];
+  float pre_bias[EPT], pre_res[EPT], pre_rm[EPT];
   uint8_t pre_mask[EPT];
 #pragma unroll
   for (int j = 0; j < EPT; ++j) {
@@ -117,6 +117,11 @@ __global__ __launch_bounds__(kGemmThreads) void gemm_rows_kernel(GemmArgs g) {
       pre_res[j] = g.beta[n];
     }
     if (EK == EPI_RESIDUAL && ok) pre_res[j] = g.resid[(size_t)m * g.ldo + n];
+    pre_rm[j] = 1.0f;
+    if (EK == EPI_GENERIC && ok) {
+      if (g.resid != nullptr) pre_res[j] = g.resid[(size_t)m * g.ldo + n];
+      if (g.row_mask != nullptr) pre_rm[j] = g.row_mask[m];
+    }
   }
 
   constexpr int EB = Cfg::EB;
@@ -207,6 +212,11 @@ __global__ __launch_bounds__(kGemmThreads) void gemm_rows_kernel(GemmArgs g) {
       v = v > 0.f ? v : mul_rn(v, 0.01f);
       if (g.out != nullptr) g.out[(size_t)m * g.ldo + n] = v;
       store16(v);
+    } else if (EK == EPI_GENERIC) {
+      if (g.act == 1) v = v > 0.f ? v : 0.f;
+      if (g.row_mask != nullptr) v = mul_rn(v, pre_rm[j]);
+      if (g.resid != nullptr) v = add_rn(pre_res[j], v);
+      g.out[(size_t)m * g.ldo + n] = v;
     } else if (EK == EPI_RESIDUAL) {
       // modules.py:184 x + fc_out(...)  /  modules.py:215 x + layer(x)
       v = add_rn(pre_res[j], v);
@@ -246,6 +256,8 @@ void launch_gemm(const GemmArgs& a, AKind ak, EpiKind ek, hipStream_t st) {
   if (ak == A_CONV && ek == EPI_BN_LRELU) return launch_gemm_prec<A_CONV, EPI_BN_LRELU>(a, st);
   if (ak == A_CONV && ek == EPI_BN_ISRLU) return launch_gemm_prec<A_CONV, EPI_BN_ISRLU>(a, st);
   if (ak == A_CONV && ek == EPI_RESIDUAL) return launch_gemm_prec<A_CONV, EPI_RESIDUAL>(a, st);
+  if (ak == A_CONV && ek == EPI_GENERIC) return launch_gemm_cfg<A_CONV, EPI_GENERIC, PREC_F32>(a, st);
+  if (ek == EPI_GENERIC) return launch_gemm_cfg<A_PLAIN, EPI_GENERIC, PREC_F32>(a, st);
   switch (ek) {
     case EPI_PLAIN: return launch_gemm_cfg<A_PLAIN, EPI_PLAIN, PREC_F32>(a, st);
     case EPI_RELU_DROPOUT: return launch_gemm_cfg<A_PLAIN, EPI_RELU_DROPOUT, PREC_F32>(a, st);

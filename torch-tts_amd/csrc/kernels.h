@@ -6,7 +6,7 @@ namespace ttsdec {
 
 // ---- generic row-GEMM (PreNet layers, query projection, mel/stop projection, postnet) ----
 enum AKind { A_PLAIN = 0, A_CONV = 1 };
-enum EpiKind { EPI_PLAIN = 0, EPI_RELU_DROPOUT = 1, EPI_PROJ = 2, EPI_BN_ISRU = 3, EPI_RESIDUAL = 4, EPI_BN_LRELU = 5, EPI_BN_ISRLU = 6 };
+enum EpiKind { EPI_PLAIN = 0, EPI_RELU_DROPOUT = 1, EPI_PROJ = 2, EPI_BN_ISRU = 3, EPI_RESIDUAL = 4, EPI_BN_LRELU = 5, EPI_BN_ISRLU = 6, EPI_GENERIC = 7 };
 
 struct GemmArgs {
   // A operand.  A_PLAIN: up to three K segments of an [M, K] activation.
@@ -26,6 +26,10 @@ struct GemmArgs {
   const float* alpha;  // EPI_BN_ISRU: out = isru(acc * alpha[n] + beta[n])
   const float* beta;
   const float* resid;  // EPI_RESIDUAL: out = resid[m, n] + acc
+  // EPI_GENERIC: out = [resid[m, n] +] row_mask[m] * act(acc + bias[n]); act 0 = identity, 1 = relu;
+  // row_mask / resid / bias may each be nullptr (resid has leading dimension ldo)
+  int act;
+  const float* row_mask;
   float* out;          // [M, ldo]
   int ldo;
   // Split-K over workgroups (A_PLAIN + EPI_PLAIN only): gridDim.z = ksplit, slice z contracts

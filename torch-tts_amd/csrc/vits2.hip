@@ -1,0 +1,629 @@
+// C ABI of the VITS2 second hot path (BASELINE.json configs[4]):
+//   ttsvits_text_encoder   TextEncoder.forward                      vits2/models.py:369-380
+//   ttsvits_flow_reverse   ResidualCouplingTransformersBlock.forward(reverse=True)   models.py:506-531, 803-810
+// built on the decoder path's GEMM core (1x1 convs are row GEMMs, k-tap convs implicit GEMMs over
+// channel-last activations, bias / ReLU / frame mask / residual in the epilogue) plus four small
+// kernels of its own: channel LayerNorm, relative-position multi-head attention, the WN gate and the
+// coupling update.  Activations are channel-last [B*T, C] (one row per frame) throughout - the
+// reference's [B, C, T] is transposed once at the boundary by the host module.  Exact fp32.
+#include <math.h>
+#include <string.h>
+
+#include <new>
+#include <string>
+
+#include "kernels.h"
+
+using namespace ttsdec;
+
+namespace {
+constexpr size_t kAlign = 64;  // floats
+constexpr int kMaxLayers = 12, kMaxFlows = 8, kMaxWn = 8;
+inline size_t up(size_t v, size_t a) { return (v + a - 1) / a * a; }
+
+// one attentions.Encoder stack (attentions.py:14-93)
+struct StackBlob {
+  size_t wqkv[kMaxLayers], bqkv[kMaxLayers], wo[kMaxLayers], bo[kMaxLayers], ek[kMaxLayers], ev[kMaxLayers];
+  size_t g1[kMaxLayers], b1[kMaxLayers], w1[kMaxLayers], c1[kMaxLayers], w2[kMaxLayers], c2[kMaxLayers], g2[kMaxLayers], b2[kMaxLayers];
+};
+struct StackDims {
+  int C, F, heads, layers, kernel, window;  // window < 0: no relative-position terms
+};
+struct FlowBlob {
+  StackBlob tf;
+  size_t pre_w, pre_b, in_w[kMaxWn], in_b[kMaxWn], rs_w[kMaxWn], rs_b[kMaxWn], post_w, post_b;
+};
+struct VitsBlob {  // offsets in floats
+  size_t emb;
+  StackBlob enc;
+  size_t proj_w, proj_b;
+  FlowBlob flow[kMaxFlows];
+  size_t total;
+};
+}  // namespace
+
+struct ttsvits_handle {
+  ttsvits_dims d;
+  VitsBlob bl;
+  const float* blob;
+  std::string hip_err;
+};
+
+namespace {
+
+StackDims enc_dims(const ttsvits_dims& d) { return {d.hidden_channels, d.filter_channels, d.n_heads, d.n_layers, d.kernel_size, d.window_size}; }
+StackDims tf_dims(const ttsvits_dims& d) {
+  const int half = d.inter_channels / 2;
+  return {half, half, d.flow_tf_heads, d.flow_tf_layers, d.flow_tf_kernel, -1};
+}
+
+VitsBlob make_layout(const ttsvits_dims& d) {
+  VitsBlob L;
+  memset(&L, 0, sizeof(L));
+  size_t off = 0;
+  auto take = [&](size_t n) { const size_t o = off; off = up(off + n, kAlign); return o; };
+  auto stack = [&](StackBlob& s, const StackDims& sd) {
+    const size_t C = sd.C, F = sd.F, k = sd.kernel, dk = sd.C / sd.heads;
+    for (int i = 0; i < sd.layers; ++i) {
+      s.wqkv[i] = take(3 * C * C); s.bqkv[i] = take(3 * C); s.wo[i] = take(C * C); s.bo[i] = take(C);
+      if (sd.window >= 0) { s.ek[i] = take((2 * sd.window + 1) * dk); s.ev[i] = take((2 * sd.window + 1) * dk); }
+      s.g1[i] = take(C); s.b1[i] = take(C);
+      s.w1[i] = take(F * k * C); s.c1[i] = take(F); s.w2[i] = take(C * k * F); s.c2[i] = take(C);
+      s.g2[i] = take(C); s.b2[i] = take(C);
+    }
+  };
+  const size_t H = d.hidden_channels, I = d.inter_channels, half = I / 2, Fh = d.flow_hidden;
+  L.emb = take((size_t)d.n_vocab * H);
+  stack(L.enc, enc_dims(d));
+  L.proj_w = take(2 * I * H); L.proj_b = take(2 * I);
+  for (int f = 0; f < d.n_flows; ++f) {
+    FlowBlob& fb = L.flow[f];
+    stack(fb.tf, tf_dims(d));
+    fb.pre_w = take(Fh * half); fb.pre_b = take(Fh);
+    for (int j = 0; j < d.flow_wn_layers; ++j) {
+      const size_t cr = j < d.flow_wn_layers - 1 ? 2 * Fh : Fh;
+      fb.in_w[j] = take(2 * Fh * d.flow_kernel * Fh); fb.in_b[j] = take(2 * Fh);
+      fb.rs_w[j] = take(cr * Fh); fb.rs_b[j] = take(cr);
+    }
+    fb.post_w = take(half * Fh); fb.post_b = take(half);
+  }
+  L.total = off;
+  return L;
+}
+
+int n_stack_tensors(const StackDims& sd) { return sd.layers * (sd.window >= 0 ? 18 : 16); }
+int n_text_tensors(const ttsvits_dims& d) { return 1 + n_stack_tensors(enc_dims(d)) + 2; }
+int n_flow_tensors(const ttsvits_dims& d) { return d.n_flows * (n_stack_tensors(tf_dims(d)) + 2 + 4 * d.flow_wn_layers + 2); }
+
+int vits_fail(ttsvits_handle* h, const char* where) {
+  hipError_t e = hipGetLastError();
+  if (e == hipSuccess) return TTSDEC_OK;
+  if (h) h->hip_err = std::string(where) + ": " + hipGetErrorString(e);
+  return TTSDEC_ERR_HIP;
+}
+
+// ===========================================================================
+// kernels
+// ===========================================================================
+// TextEncoder.forward, models.py:370-376: x = emb(ids) * sqrt(H), masked; also the per-frame mask
+__global__ void embed_scale_kernel(const long long* ids, const int* lengths, const float* table, int T, int H, float scale, float* x,
+                                   float* mask, int M) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= (size_t)M * H) return;
+  const int m = (int)(i / H), c = (int)(i % H);
+  const int b = m / T, t = m - b * T;
+  const float mk = t < lengths[b] ? 1.0f : 0.0f;
+  x[i] = mul_rn(mul_rn(table[(size_t)ids[m] * H + c], scale), mk);
+  if (c == 0) mask[m] = mk;
+}
+__global__ void frame_mask_kernel(const int* lengths, int T, float* mask, int M) {
+  const int m = blockIdx.x * blockDim.x + threadIdx.x;
+  if (m < M) mask[m] = (m % T) < lengths[m / T] ? 1.0f : 0.0f;
+}
+
+// modules.LayerNorm (modules.py:24-27) over the channels of one frame; one wave per row.
+// out = LN(in) ; out_m = LN(in) * mask  (either may be nullptr)
+__global__ __launch_bounds__(256) void layernorm_rows_kernel(const float* in, const float* gamma, const float* beta, const float* mask,
+                                                             float* out, float* out_m, int M, int C, float eps) {
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+  if (row >= M) return;
+  const float* x = in + (size_t)row * C;
+  float v[16];  // C <= 1024
+  float s = 0.f;
+#pragma unroll
+  for (int j = 0; j < 16; ++j) {
+    const int c = lane + 64 * j;
+    v[j] = c < C ? x[c] : 0.f;
+    s += v[j];
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
+  const float mean = s / (float)C;
+  float q = 0.f;
+#pragma unroll
+  for (int j = 0; j < 16; ++j) {
+    const int c = lane + 64 * j;
+    const float dlt = c < C ? v[j] - mean : 0.f;
+    q += dlt * dlt;
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) q += __shfl_xor(q, o);
+  const float rstd = 1.0f / sqrt_rn(add_rn(q / (float)C, eps));
+  const float mk = mask ? mask[row] : 1.0f;
+#pragma unroll
+  for (int j = 0; j < 16; ++j) {
+    const int c = lane + 64 * j;
+    if (c < C) {
+      const float y = add_rn(mul_rn(mul_rn(v[j] - mean, rstd), gamma[c]), beta[c]);
+      if (out) out[(size_t)row * C + c] = y;
+      if (out_m) out_m[(size_t)row * C + c] = mul_rn(y, mk);
+    }
+  }
+}
+
+// MultiHeadAttention.attention (attentions.py:246-295), self-attention with the frame mask and the
+// optional relative-position window.  One workgroup = 16 query frames of one (utterance, head).
+//   scores[i, j] = (q_i / sqrt(dk)) . k_j  [+ (q_i / sqrt(dk)) . E_k[j - i + w] if |j - i| <= w]
+//   scores[i, j] = -1e4 where mask_i * mask_j == 0 ; p = softmax_j
+//   out[i] = sum_j p[i, j] v_j  [+ sum_{|j-i|<=w} p[i, j] E_v[j - i + w]]
+constexpr int kMhaRows = 16, kMhaChunk = 64, kMhaThreads = 256;
+struct MhaArgs {
+  const float* qkv;  // [B*T, 3C]: q | k | v, head h = channels [h*dk, (h+1)*dk)
+  const float* mask;  // [B*T]
+  const float *ek, *ev;  // [2w+1, dk] or nullptr
+  float* out;            // [B*T, C]
+  int T, C, dk, window;
+  float qscale;  // sqrt(dk): q is DIVIDED by it, as the reference does
+};
+__global__ __launch_bounds__(kMhaThreads) void mha_kernel(MhaArgs g) {
+  extern __shared__ __attribute__((aligned(16))) float sm[];
+  const int T = g.T, dk = g.dk, C = g.C, w = g.window;
+  const int KS = dk + 1;
+  float* qs = sm;                           // [16][dk]
+  float* kv = qs + kMhaRows * dk;           // [64][dk+1]
+  float* rel = kv + kMhaChunk * KS;         // [2][2w+1][dk]  (E_k, E_v)
+  const int nrel = w >= 0 ? 2 * w + 1 : 0;
+  float* S = rel + 2 * nrel * dk;           // [16][T]
+  const int tid = threadIdx.x, b = blockIdx.z, hd = blockIdx.y, i0 = blockIdx.x * kMhaRows;
+  const size_t rowb = (size_t)b * T;
+  const float* base = g.qkv + rowb * 3 * C + hd * dk;
+  for (int e = tid; e < kMhaRows * dk; e += kMhaThreads) {
+    const int i = e / dk, d = e - i * dk;
+    qs[e] = (i0 + i < T) ? div_rn(base[(size_t)(i0 + i) * 3 * C + d], g.qscale) : 0.f;
+  }
+  for (int e = tid; e < nrel * dk; e += kMhaThreads) {
+    rel[e] = g.ek[e];
+    rel[nrel * dk + e] = g.ev[e];
+  }
+  const int ri = tid >> 4, rj = tid & 15;  // this thread's query row / key lane
+  const float mi = (i0 + ri < T) ? g.mask[rowb + i0 + ri] : 0.f;
+  // ---- pass 1: scores ----
+  for (int c0 = 0; c0 < T; c0 += kMhaChunk) {
+    __syncthreads();
+    for (int e = tid; e < kMhaChunk * dk; e += kMhaThreads) {
+      const int j = e / dk, d = e - j * dk;
+      kv[j * KS + d] = (c0 + j < T) ? base[(size_t)(c0 + j) * 3 * C + C + d] : 0.f;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int jj = 0; jj < kMhaChunk / 16; ++jj) {
+      const int jl = rj + 16 * jj, j = c0 + jl;
+      if (j >= T) continue;
+      const float* qr = qs + ri * dk;
+      const float* kr = kv + jl * KS;
+      float s = 0.f;
+      for (int d = 0; d < dk; ++d) s = fmaf(qr[d], kr[d], s);
+      const int r = j - (i0 + ri) + w;
+      if (w >= 0 && r >= 0 && r <= 2 * w) {
+        const float* er = rel + r * dk;
+        float s2 = 0.f;
+        for (int d = 0; d < dk; ++d) s2 = fmaf(qr[d], er[d], s2);
+        s = add_rn(s, s2);
+      }
+      if (mi * g.mask[rowb + j] == 0.f) s = -1e4f;
+      S[ri * T + j] = s;
+    }
+  }
+  __syncthreads();
+  // ---- softmax: wave v owns rows 4v .. 4v+3 ----
+  {
+    const int wave = tid >> 6, lane = tid & 63;
+    for (int rr = 0; rr < 4; ++rr) {
+      float* row = S + (wave * 4 + rr) * T;
+      float mx = -3.4e38f;
+      for (int j = lane; j < T; j += 64) mx = fmaxf(mx, row[j]);
+#pragma unroll
+      for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o));
+      float sum = 0.f;
+      for (int j = lane; j < T; j += 64) {
+        const float e = expf(row[j] - mx);
+        row[j] = e;
+        sum += e;
+      }
+#pragma unroll
+      for (int o = 32; o > 0; o >>= 1) sum += __shfl_xor(sum, o);
+      for (int j = lane; j < T; j += 64) row[j] = div_rn(row[j], sum);
+    }
+  }
+  // ---- pass 2: out = p v (+ relative values) ----
+  constexpr int ND = 16;  // dk <= 256
+  float acc[ND];
+#pragma unroll
+  for (int dd = 0; dd < ND; ++dd) acc[dd] = 0.f;
+  for (int c0 = 0; c0 < T; c0 += kMhaChunk) {
+    __syncthreads();
+    for (int e = tid; e < kMhaChunk * dk; e += kMhaThreads) {
+      const int j = e / dk, d = e - j * dk;
+      kv[j * KS + d] = (c0 + j < T) ? base[(size_t)(c0 + j) * 3 * C + 2 * C + d] : 0.f;
+    }
+    __syncthreads();
+    const int jn = (T - c0) < kMhaChunk ? (T - c0) : kMhaChunk;
+    const float* pr = S + ri * T + c0;
+    for (int j = 0; j < jn; ++j) {
+      const float p = pr[j];
+#pragma unroll
+      for (int dd = 0; dd < ND; ++dd) {
+        const int d = rj + 16 * dd;
+        if (d < dk) acc[dd] = fmaf(p, kv[j * KS + d], acc[dd]);
+      }
+    }
+  }
+  if (w >= 0) {
+    for (int r = 0; r <= 2 * w; ++r) {
+      const int j = i0 + ri + r - w;
+      if (j < 0 || j >= T) continue;
+      const float p = S[ri * T + j];
+#pragma unroll
+      for (int dd = 0; dd < ND; ++dd) {
+        const int d = rj + 16 * dd;
+        if (d < dk) acc[dd] = fmaf(p, rel[(nrel + r) * dk + d], acc[dd]);
+      }
+    }
+  }
+  if (i0 + ri < T) {
+#pragma unroll
+    for (int dd = 0; dd < ND; ++dd) {
+      const int d = rj + 16 * dd;
+      if (d < dk) g.out[(rowb + i0 + ri) * C + hd * dk + d] = acc[dd];
+    }
+  }
+}
+
+// commons.fused_add_tanh_sigmoid_multiply with g = None (commons.py:102-109): [M, 2H] -> [M, H]
+__global__ void wn_gate_kernel(const float* xin, float* acts, int M, int H) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= (size_t)M * H) return;
+  const size_t m = i / H, c = i % H;
+  const float a = xin[m * 2 * H + c], s = xin[m * 2 * H + H + c];
+  acts[i] = mul_rn(tanhf(a), sigmoid_f(s));
+}
+// modules.WN.forward:201-208: not last: x = (x + rs[:, :H]) * mask; output += rs[:, H:]
+//                             last:     output = (output + rs) * mask   (the final `output * x_mask` folded in)
+__global__ void wn_update_kernel(float* x, float* output, const float* rs, const float* mask, int M, int H, int last, int first) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= (size_t)M * H) return;
+  const size_t m = i / H, c = i % H;
+  const float o = first ? 0.f : output[i];
+  if (last) {
+    output[i] = mul_rn(add_rn(o, rs[m * H + c]), mask[m]);
+  } else {
+    x[i] = mul_rn(add_rn(x[i], rs[m * 2 * H + c]), mask[m]);
+    output[i] = add_rn(o, rs[m * 2 * H + H + c]);
+  }
+}
+// modules.Flip (modules.py:374-381) + split: xf = flip(x); x0m = xf[:, :half] * mask
+__global__ void flip_split_kernel(const float* x, const float* mask, float* xf, float* x0m, int M, int I) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= (size_t)M * I) return;
+  const size_t m = i / I, c = i % I;
+  const float v = x[m * I + (I - 1 - c)];
+  xf[i] = v;
+  const int half = I / 2;
+  if ((int)c < half) x0m[m * half + c] = mul_rn(v, mask[m]);
+}
+// x0_ = pre_transformer(...) + x0 (models.py:509): enc [M, half] += xf[:, :half]
+__global__ void add_x0_kernel(float* enc, const float* xf, int M, int I) {
+  const int half = I / 2;
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= (size_t)M * half) return;
+  const size_t m = i / half, c = i % half;
+  enc[i] = add_rn(enc[i], xf[m * I + c]);
+}
+// x1 = (x1 - m) * exp(-0) * mask (models.py:529): xf[:, half:] updated in place; mm is post(h) * mask
+__global__ void couple_kernel(float* xf, const float* mm, const float* mask, int M, int I) {
+  const int half = I / 2;
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= (size_t)M * half) return;
+  const size_t m = i / half, c = i % half;
+  float* p = xf + m * I + half + c;
+  *p = mul_rn(mul_rn(sub_rn(*p, mm[i]), 1.0f), mask[m]);
+}
+__global__ void copy_f_kernel(const float* a, float* b, size_t n) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) b[i] = a[i];
+}
+// pack: rows of three [C, C] matrices stacked -> [3C, C]; conv weights via launch_conv_transpose
+
+inline dim3 grid1(size_t n) { return dim3((unsigned)((n + 255) / 256)); }
+
+// ---------------------------------------------------------------------------
+// host-side building blocks
+// ---------------------------------------------------------------------------
+void gemm_generic(const float* a, int lda, int K, const float* W, const float* bias, int M, int N, float* out, int ldo, int act,
+                  const float* row_mask, const float* resid, int taps, int T, hipStream_t st) {
+  GemmArgs g;
+  memset(&g, 0, sizeof(g));
+  g.M = M; g.N = N; g.bias = bias; g.out = out; g.ldo = ldo; g.act = act; g.row_mask = row_mask; g.resid = resid;
+  g.W = g.W_lo = W;
+  if (taps > 1) {
+    g.a = make_seg1(a, K, K); g.a_lo = g.a;
+    g.T = T; g.Cin = K; g.taps = taps; g.ldw = taps * K; g.K = taps * K;
+    launch_gemm(g, A_CONV, EPI_GENERIC, st);
+  } else {
+    g.a = make_seg1(a, lda, K); g.a_lo = g.a;
+    g.ldw = K; g.K = K;
+    launch_gemm(g, A_PLAIN, EPI_GENERIC, st);
+  }
+}
+
+struct StackWs {
+  float *x, *xm, *qkv, *att, *t, *f;  // [M,C] [M,C] [M,3C] [M,C] [M,C] [M,F]
+};
+size_t mha_lds_bytes(int T, int dk, int window) {
+  const int nrel = window >= 0 ? 2 * window + 1 : 0;
+  return ((size_t)kMhaRows * dk + (size_t)kMhaChunk * (dk + 1) + 2 * (size_t)nrel * dk + (size_t)kMhaRows * T) * sizeof(float);
+}
+constexpr size_t kMhaMaxLds = 150 * 1024;
+
+// attentions.Encoder.forward (attentions.py:76-93), eval mode.  Input: sw.x = sw.xm = x * mask.
+// Result: sw.xm (= x * mask of the last layer).
+int run_stack(ttsvits_handle* h, const StackBlob& sb, const StackDims& sd, const StackWs& sw, const float* mask, int B, int T,
+              hipStream_t st) {
+  const float* blob = h->blob;
+  const int M = B * T, C = sd.C, dk = C / sd.heads;
+  const size_t lds = mha_lds_bytes(T, dk, sd.window);
+  if (lds > kMhaMaxLds || dk > 256) return TTSDEC_ERR_DIMS;
+  if (hipFuncSetAttribute((const void*)mha_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+    return vits_fail(h, "hipFuncSetAttribute(mha_kernel)");
+  const float* xin = sw.xm;  // layer 0 attends over x * mask; later layers over the unmasked LayerNorm output
+  for (int i = 0; i < sd.layers; ++i) {
+    const float* xa = i == 0 ? sw.xm : sw.x;
+    gemm_generic(xa, C, C, blob + sb.wqkv[i], blob + sb.bqkv[i], M, 3 * C, sw.qkv, 3 * C, 0, nullptr, nullptr, 1, T, st);
+    MhaArgs a;
+    a.qkv = sw.qkv; a.mask = mask; a.out = sw.att; a.T = T; a.C = C; a.dk = dk; a.window = sd.window;
+    a.ek = sd.window >= 0 ? blob + sb.ek[i] : nullptr; a.ev = sd.window >= 0 ? blob + sb.ev[i] : nullptr;
+    a.qscale = sqrtf((float)dk);
+    hipLaunchKernelGGL(mha_kernel, dim3((T + kMhaRows - 1) / kMhaRows, sd.heads, B), dim3(kMhaThreads), lds, st, a);
+    // x = LayerNorm(x + conv_o(att))
+    gemm_generic(sw.att, C, C, blob + sb.wo[i], blob + sb.bo[i], M, C, sw.t, C, 0, nullptr, xa, 1, T, st);
+    hipLaunchKernelGGL(layernorm_rows_kernel, dim3((M + 3) / 4), dim3(256), 0, st, sw.t, blob + sb.g1[i], blob + sb.b1[i], mask, sw.x,
+                       sw.xm, M, C, 1e-5f);
+    // FFN (attentions.py:411-419): conv_2(relu(conv_1(x * mask)) * mask) * mask, then x = LayerNorm(x + y)
+    gemm_generic(sw.xm, C, C, blob + sb.w1[i], blob + sb.c1[i], M, sd.F, sw.f, sd.F, 1, mask, nullptr, sd.kernel, T, st);
+    gemm_generic(sw.f, sd.F, sd.F, blob + sb.w2[i], blob + sb.c2[i], M, C, sw.t, C, 0, mask, sw.x, sd.kernel, T, st);
+    hipLaunchKernelGGL(layernorm_rows_kernel, dim3((M + 3) / 4), dim3(256), 0, st, sw.t, blob + sb.g2[i], blob + sb.b2[i], mask, sw.x,
+                       sw.xm, M, C, 1e-5f);
+  }
+  (void)xin;
+  return TTSDEC_OK;
+}
+
+size_t stack_ws_floats(const StackDims& sd, size_t M) { return M * (size_t)(4 * sd.C + 3 * sd.C + sd.F) + 8 * kAlign; }
+StackWs carve_stack(float*& p, const StackDims& sd, size_t M) {
+  auto take = [&](size_t n) { float* r = p; p += up(n, kAlign); return r; };
+  StackWs w;
+  w.x = take(M * sd.C); w.xm = take(M * sd.C); w.qkv = take(M * 3 * sd.C); w.att = take(M * sd.C); w.t = take(M * sd.C);
+  w.f = take(M * sd.F);
+  return w;
+}
+
+int pack_stack(const float* const* src, int& k, float* b, const StackBlob& s, const StackDims& sd, hipStream_t st) {
+  const size_t C = sd.C, F = sd.F, dk = sd.C / sd.heads;
+  for (int i = 0; i < sd.layers; ++i) {
+    for (int j = 0; j < 3; ++j) {  // conv_q / conv_k / conv_v stacked on the output axis
+      launch_copy(src[k + 2 * j], b + s.wqkv[i] + j * C * C, C * C, st);
+      launch_copy(src[k + 2 * j + 1], b + s.bqkv[i] + j * C, C, st);
+    }
+    launch_copy(src[k + 6], b + s.wo[i], C * C, st);
+    launch_copy(src[k + 7], b + s.bo[i], C, st);
+    k += 8;
+    if (sd.window >= 0) {
+      launch_copy(src[k], b + s.ek[i], (2 * sd.window + 1) * dk, st);
+      launch_copy(src[k + 1], b + s.ev[i], (2 * sd.window + 1) * dk, st);
+      k += 2;
+    }
+    launch_copy(src[k], b + s.g1[i], C, st);
+    launch_copy(src[k + 1], b + s.b1[i], C, st);
+    if (src[k + 2]) launch_conv_transpose(src[k + 2], b + s.w1[i], (int)F, (int)C, sd.kernel, st);
+    launch_copy(src[k + 3], b + s.c1[i], F, st);
+    if (src[k + 4]) launch_conv_transpose(src[k + 4], b + s.w2[i], (int)C, (int)F, sd.kernel, st);
+    launch_copy(src[k + 5], b + s.c2[i], C, st);
+    launch_copy(src[k + 6], b + s.g2[i], C, st);
+    launch_copy(src[k + 7], b + s.b2[i], C, st);
+    k += 8;
+  }
+  return TTSDEC_OK;
+}
+
+bool dims_ok(const ttsvits_dims& d) {
+  const int v[] = {d.inter_channels, d.hidden_channels, d.filter_channels, d.flow_hidden};
+  for (int x : v)
+    if (x <= 0 || (x & 3)) return false;
+  if ((d.inter_channels / 2) & 3) return false;
+  if (d.n_vocab <= 0 || d.n_heads <= 0 || d.hidden_channels % d.n_heads) return false;
+  if (d.flow_tf_heads <= 0 || (d.inter_channels / 2) % d.flow_tf_heads) return false;
+  if (d.n_layers < 0 || d.n_layers > kMaxLayers || d.flow_tf_layers < 0 || d.flow_tf_layers > kMaxLayers) return false;
+  if (d.n_flows < 0 || d.n_flows > kMaxFlows || d.flow_wn_layers < 1 || d.flow_wn_layers > kMaxWn) return false;
+  if (!(d.kernel_size & 1) || !(d.flow_kernel & 1) || !(d.flow_tf_kernel & 1) || d.kernel_size < 1 || d.flow_kernel < 1 || d.flow_tf_kernel < 1)
+    return false;
+  if (d.window_size > 64 || d.hidden_channels > 1024 || d.inter_channels > 2048) return false;
+  return true;
+}
+
+}  // namespace
+
+extern "C" {
+
+int ttsvits_create(const ttsvits_dims* dims, ttsvits_handle** out) {
+  if (!dims || !out) return TTSDEC_ERR_INVALID_ARG;
+  *out = nullptr;
+  if (!dims_ok(*dims)) return TTSDEC_ERR_DIMS;
+  ttsvits_handle* h = new (std::nothrow) ttsvits_handle();
+  if (!h) return TTSDEC_ERR_INVALID_ARG;
+  h->d = *dims;
+  h->bl = make_layout(*dims);
+  h->blob = nullptr;
+  *out = h;
+  return TTSDEC_OK;
+}
+int ttsvits_destroy(ttsvits_handle* h) {
+  delete h;
+  return TTSDEC_OK;
+}
+const char* ttsvits_last_hip_error(const ttsvits_handle* h) { return h ? h->hip_err.c_str() : ""; }
+int ttsvits_num_weight_tensors(const ttsvits_handle* h) { return h ? n_text_tensors(h->d) + n_flow_tensors(h->d) : TTSDEC_ERR_INVALID_ARG; }
+size_t ttsvits_packed_bytes(const ttsvits_handle* h) { return h ? h->bl.total * sizeof(float) : 0; }
+
+int ttsvits_pack_weights(ttsvits_handle* h, const float* const* src, int n_src, void* blob, void* stream) {
+  if (!h || !src || !blob || n_src != ttsvits_num_weight_tensors(h)) return TTSDEC_ERR_INVALID_ARG;
+  if (reinterpret_cast<uintptr_t>(blob) & 255) return TTSDEC_ERR_WORKSPACE;
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  const ttsvits_dims& d = h->d;
+  const VitsBlob& L = h->bl;
+  float* b = static_cast<float*>(blob);
+  if (hipMemsetAsync(blob, 0, L.total * sizeof(float), st) != hipSuccess) return vits_fail(h, "memset");
+  const size_t H = d.hidden_channels, I = d.inter_channels, half = I / 2, Fh = d.flow_hidden;
+  int k = 0;
+  // (launch_copy / launch_conv_transpose skip NULL sources: a module that owns only the text encoder
+  // or only the flow packs what it has)
+  launch_copy(src[k++], b + L.emb, (size_t)d.n_vocab * H, st);
+  pack_stack(src, k, b, L.enc, enc_dims(d), st);
+  launch_copy(src[k++], b + L.proj_w, 2 * I * H, st);
+  launch_copy(src[k++], b + L.proj_b, 2 * I, st);
+  for (int f = 0; f < d.n_flows; ++f) {
+    const FlowBlob& fb = L.flow[f];
+    pack_stack(src, k, b, fb.tf, tf_dims(d), st);
+    launch_copy(src[k++], b + fb.pre_w, Fh * half, st);
+    launch_copy(src[k++], b + fb.pre_b, Fh, st);
+    for (int j = 0; j < d.flow_wn_layers; ++j) {
+      const size_t cr = j < d.flow_wn_layers - 1 ? 2 * Fh : Fh;
+      if (src[k]) launch_conv_transpose(src[k], b + fb.in_w[j], (int)(2 * Fh), (int)Fh, d.flow_kernel, st);
+      launch_copy(src[k + 1], b + fb.in_b[j], 2 * Fh, st);
+      launch_copy(src[k + 2], b + fb.rs_w[j], cr * Fh, st);
+      launch_copy(src[k + 3], b + fb.rs_b[j], cr, st);
+      k += 4;
+    }
+    launch_copy(src[k++], b + fb.post_w, half * Fh, st);
+    launch_copy(src[k++], b + fb.post_b, half, st);
+  }
+  const int rc = vits_fail(h, "pack_weights");
+  if (rc == TTSDEC_OK) h->blob = b;
+  return rc;
+}
+
+int ttsvits_bind_weights(ttsvits_handle* h, const void* blob) {
+  if (!h || !blob || (reinterpret_cast<uintptr_t>(blob) & 255)) return TTSDEC_ERR_INVALID_ARG;
+  h->blob = static_cast<const float*>(blob);
+  return TTSDEC_OK;
+}
+
+size_t ttsvits_text_encoder_workspace_bytes(const ttsvits_handle* h, int B, int T) {
+  if (!h || B <= 0 || T <= 0) return 0;
+  const size_t M = (size_t)B * T;
+  return (stack_ws_floats(enc_dims(h->d), M) + up(M, kAlign) + up(M * 2 * h->d.inter_channels, kAlign)) * sizeof(float);
+}
+
+int ttsvits_text_encoder(ttsvits_handle* h, const int64_t* ids, const int32_t* lengths, int B, int T, float* x, float* m, float* logs,
+                         void* workspace, size_t workspace_bytes, void* stream) {
+  if (!h || !ids || !lengths || !x || !m || !logs || !workspace || B <= 0 || T <= 0) return TTSDEC_ERR_INVALID_ARG;
+  if (!h->blob) return TTSDEC_ERR_NOT_BOUND;
+  if (workspace_bytes < ttsvits_text_encoder_workspace_bytes(h, B, T) || (reinterpret_cast<uintptr_t>(workspace) & 255))
+    return TTSDEC_ERR_WORKSPACE;
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  const ttsvits_dims& d = h->d;
+  const VitsBlob& L = h->bl;
+  const int M = B * T, H = d.hidden_channels, I = d.inter_channels;
+  float* p = static_cast<float*>(workspace);
+  const StackDims sd = enc_dims(d);
+  StackWs sw = carve_stack(p, sd, (size_t)M);
+  float* mask = p; p += up((size_t)M, kAlign);
+  float* stats = p;
+  // models.py:370-376
+  hipLaunchKernelGGL(embed_scale_kernel, grid1((size_t)M * H), dim3(256), 0, st, reinterpret_cast<const long long*>(ids), lengths,
+                     h->blob + L.emb, T, H, sqrtf((float)H), sw.xm, mask, M);
+  int rc = run_stack(h, L.enc, sd, sw, mask, B, T, st);
+  if (rc != TTSDEC_OK) return rc;
+  // models.py:377-379: stats = proj(x) * x_mask; m, logs = split(stats)
+  gemm_generic(sw.xm, H, H, h->blob + L.proj_w, h->blob + L.proj_b, M, 2 * I, stats, 2 * I, 0, mask, nullptr, 1, T, st);
+  if (hipMemcpyAsync(x, sw.xm, (size_t)M * H * sizeof(float), hipMemcpyDeviceToDevice, st) != hipSuccess) return vits_fail(h, "copy x");
+  if (hipMemcpy2DAsync(m, (size_t)I * sizeof(float), stats, (size_t)2 * I * sizeof(float), (size_t)I * sizeof(float), M,
+                       hipMemcpyDeviceToDevice, st) != hipSuccess)
+    return vits_fail(h, "copy m");
+  if (hipMemcpy2DAsync(logs, (size_t)I * sizeof(float), stats + I, (size_t)2 * I * sizeof(float), (size_t)I * sizeof(float), M,
+                       hipMemcpyDeviceToDevice, st) != hipSuccess)
+    return vits_fail(h, "copy logs");
+  return vits_fail(h, "text_encoder");
+}
+
+size_t ttsvits_flow_workspace_bytes(const ttsvits_handle* h, int B, int T) {
+  if (!h || B <= 0 || T <= 0) return 0;
+  const size_t M = (size_t)B * T, I = h->d.inter_channels, Fh = h->d.flow_hidden;
+  const size_t fl = up(M, kAlign) + 2 * up(M * I, kAlign) + up(M * (I / 2), kAlign) + 2 * up(M * Fh, kAlign) + up(M * Fh, kAlign) +
+                    2 * up(M * 2 * Fh, kAlign);
+  return (stack_ws_floats(tf_dims(h->d), M) + fl) * sizeof(float);
+}
+
+int ttsvits_flow_reverse(ttsvits_handle* h, const float* z, const int32_t* lengths, int B, int T, float* out, void* workspace,
+                         size_t workspace_bytes, void* stream) {
+  if (!h || !z || !lengths || !out || !workspace || B <= 0 || T <= 0) return TTSDEC_ERR_INVALID_ARG;
+  if (!h->blob) return TTSDEC_ERR_NOT_BOUND;
+  if (workspace_bytes < ttsvits_flow_workspace_bytes(h, B, T) || (reinterpret_cast<uintptr_t>(workspace) & 255)) return TTSDEC_ERR_WORKSPACE;
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  const ttsvits_dims& d = h->d;
+  const VitsBlob& L = h->bl;
+  const float* blob = h->blob;
+  const int M = B * T, I = d.inter_channels, half = I / 2, Fh = d.flow_hidden;
+  float* p = static_cast<float*>(workspace);
+  const StackDims sd = tf_dims(d);
+  StackWs sw = carve_stack(p, sd, (size_t)M);
+  auto take = [&](size_t n) { float* r = p; p += up(n, kAlign); return r; };
+  float* mask = take(M);
+  float* xa = take((size_t)M * I);   // current x (ping)
+  float* xb = take((size_t)M * I);   // flipped x (pong)
+  float* mm = take((size_t)M * half);
+  float* hx = take((size_t)M * Fh);   // WN running x
+  float* ho = take((size_t)M * Fh);   // WN output accumulator
+  float* acts = take((size_t)M * Fh);
+  float* xin = take((size_t)M * 2 * Fh);
+  float* rs = take((size_t)M * 2 * Fh);
+  hipLaunchKernelGGL(frame_mask_kernel, grid1(M), dim3(256), 0, st, lengths, T, mask, M);
+  const float* cur = z;
+  for (int f = d.n_flows - 1; f >= 0; --f) {  // models.py:807-809: reversed(flows) = Flip, layer_f, ...
+    const FlowBlob& fb = L.flow[f];
+    hipLaunchKernelGGL(flip_split_kernel, grid1((size_t)M * I), dim3(256), 0, st, cur, mask, xb, sw.xm, M, I);
+    // x0_ = pre_transformer(x0 * mask, mask) + x0                                   models.py:508-509
+    int rc = run_stack(h, fb.tf, sd, sw, mask, B, T, st);
+    if (rc != TTSDEC_OK) return rc;
+    hipLaunchKernelGGL(add_x0_kernel, grid1((size_t)M * half), dim3(256), 0, st, sw.xm, xb, M, I);
+    // h = pre(x0_) * mask                                                           :510
+    gemm_generic(sw.xm, half, half, blob + fb.pre_w, blob + fb.pre_b, M, Fh, hx, Fh, 0, mask, nullptr, 1, T, st);
+    // h = WN(h, mask)                                                               :511, modules.py:185-210
+    for (int j = 0; j < d.flow_wn_layers; ++j) {
+      const bool last = j == d.flow_wn_layers - 1;
+      gemm_generic(hx, Fh, Fh, blob + fb.in_w[j], blob + fb.in_b[j], M, 2 * Fh, xin, 2 * Fh, 0, nullptr, nullptr, d.flow_kernel, T, st);
+      hipLaunchKernelGGL(wn_gate_kernel, grid1((size_t)M * Fh), dim3(256), 0, st, xin, acts, M, Fh);
+      const int cr = last ? Fh : 2 * Fh;
+      gemm_generic(acts, Fh, Fh, blob + fb.rs_w[j], blob + fb.rs_b[j], M, cr, rs, cr, 0, nullptr, nullptr, 1, T, st);
+      hipLaunchKernelGGL(wn_update_kernel, grid1((size_t)M * Fh), dim3(256), 0, st, hx, ho, rs, mask, M, Fh, last ? 1 : 0, j == 0 ? 1 : 0);
+    }
+    // m = post(h) * mask ; x1 = (x1 - m) * mask                                     :517, 529
+    gemm_generic(ho, Fh, Fh, blob + fb.post_w, blob + fb.post_b, M, half, mm, half, 0, mask, nullptr, 1, T, st);
+    hipLaunchKernelGGL(couple_kernel, grid1((size_t)M * half), dim3(256), 0, st, xb, mm, mask, M, I);
+    float* t = xa; xa = xb; xb = t;  // the coupled tensor becomes the next layer's input
+    cur = xa;
+  }
+  hipLaunchKernelGGL(copy_f_kernel, grid1((size_t)M * I), dim3(256), 0, st, cur, out, (size_t)M * I);
+  return vits_fail(h, "flow_reverse");
+}
+
+}  // extern "C"
