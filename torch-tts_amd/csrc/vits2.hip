@@ -289,6 +289,166 @@ __global__ __launch_bounds__(kMhaThreads) void mha_kernel(MhaArgs g) {
   }
 }
 
+// The same attention on the matrix cores (exact fp32 32x32x2 MFMAs).  One workgroup = 32 query
+// frames of one (utterance, head); the 4 waves split the keys.
+//   pass 1: S[32, T] = Q K^T, 32 keys per MFMA tile; both operands go global -> registers directly
+//           (a lane holds a contiguous half of its row's dk values: the K index of an fp32 MFMA may
+//           be permuted freely as long as A and B agree); relative-key logits R = Q E_k^T the same way
+//   softmax over the rows of S in LDS
+//   pass 2: out[32, dk] = P V: P from LDS, V rows from global (lanes along d: coalesced), keys split
+//           over the waves, partial tiles reduced through LDS in wave order
+constexpr int kMhaMRows = 32, kMhaMThreads = 256;
+template <int DKH>  // dk / 2 (a multiple of 4)
+__global__ __launch_bounds__(kMhaMThreads) void mha_mfma_kernel(MhaArgs g) {
+  constexpr int DK = 2 * DKH, NDT = (DK + 31) / 32;
+  extern __shared__ __attribute__((aligned(16))) float sm[];
+  const int T = g.T, C = g.C, w = g.window;
+  const int ST = T | 1;                    // odd row stride: the 32 rows of a column hit 32 banks
+  float* S = sm;                           // [32][ST]   (aliased by the pass-2 reduction buffer)
+  float* R = S + kMhaMRows * ST;           // [32][33] relative-key logits
+  const int nrel = w >= 0 ? 2 * w + 1 : 0;
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, l32 = lane & 31, half = lane >> 5;
+  const int b = blockIdx.z, hd = blockIdx.y, i0 = blockIdx.x * kMhaMRows;
+  const size_t rowb = (size_t)b * T;
+  const float* base = g.qkv + rowb * 3 * C + hd * DK;
+  typedef __attribute__((address_space(1))) const f32x4 gf32x4;
+
+  // A fragments of Q (scaled): row i0 + l32, k in [half*DKH, +DKH)
+  f32x4 qa[DKH / 4];
+  {
+    const int i = i0 + l32 < T ? i0 + l32 : T - 1;
+    gf32x4* src = (gf32x4*)(base + (size_t)i * 3 * C + half * DKH);
+#pragma unroll
+    for (int j = 0; j < DKH / 4; ++j) {
+      f32x4 v = src[j];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) v[e] = div_rn(v[e], g.qscale);
+      qa[j] = v;
+    }
+  }
+  // relative-key logits: R[i][r] = q_i . E_k[r]   (wave 0; rows r >= nrel of the B operand are zero)
+  if (w >= 0 && wave == 0) {
+    f32x16 acc = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int j = 0; j < DKH / 4; ++j) {
+      f32x4 e4 = {0.f, 0.f, 0.f, 0.f};
+      if (l32 < nrel) e4 = *reinterpret_cast<const f32x4*>(g.ek + (size_t)l32 * DK + half * DKH + 4 * j);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(qa[j][e], e4[e], acc, 0, 0, 0);
+    }
+#pragma unroll
+    for (int r = 0; r < 16; ++r) R[((r & 3) + 8 * (r >> 2) + 4 * half) * 33 + l32] = acc[r];
+  }
+  __syncthreads();
+  // ---- pass 1: scores, 32 keys per tile, tiles round-robin over the waves ----
+  const int ntile = (T + 31) / 32;
+  for (int kt = wave; kt < ntile; kt += 4) {
+    const int j = kt * 32 + l32;
+    gf32x4* src = (gf32x4*)(base + (size_t)(j < T ? j : T - 1) * 3 * C + C + half * DKH);
+    f32x4 kb[DKH / 4];
+#pragma unroll
+    for (int q = 0; q < DKH / 4; ++q) kb[q] = src[q];
+    f32x16 acc = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int q = 0; q < DKH / 4; ++q)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(qa[q][e], kb[q][e], acc, 0, 0, 0);
+    if (j < T) {
+      const float mj = g.mask[rowb + j];
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int row = (r & 3) + 8 * (r >> 2) + 4 * half;
+        const int i = i0 + row;
+        float s = acc[r];
+        const int rr = j - i + w;
+        if (w >= 0 && rr >= 0 && rr <= 2 * w) s = add_rn(s, R[row * 33 + rr]);
+        const float mi = i < T ? g.mask[rowb + i] : 0.f;
+        if (mi * mj == 0.f) s = -1e4f;
+        S[row * ST + j] = s;
+      }
+    }
+  }
+  __syncthreads();
+  // ---- softmax: wave v owns rows 8v .. 8v+7 ----
+  for (int rr = 0; rr < 8; ++rr) {
+    float* row = S + (wave * 8 + rr) * ST;
+    float mx = -3.4e38f;
+    for (int j = lane; j < T; j += 64) mx = fmaxf(mx, row[j]);
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o));
+    float sum = 0.f;
+    for (int j = lane; j < T; j += 64) {
+      const float e = expf(row[j] - mx);
+      row[j] = e;
+      sum += e;
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) sum += __shfl_xor(sum, o);
+    for (int j = lane; j < T; j += 64) row[j] = div_rn(row[j], sum);
+  }
+  __syncthreads();
+  // ---- pass 2: out = P V; wave v takes the key pairs {v, v+4, v+8, ...} ----
+  f32x16 acc[NDT];
+#pragma unroll
+  for (int dt = 0; dt < NDT; ++dt) acc[dt] = f32x16{0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+  {
+    const float* vb = base + 2 * C;
+    const float* prow = S + l32 * ST;
+    const int npair = (T + 1) / 2;
+    for (int pi = wave; pi < npair; pi += 4) {
+      const int key = 2 * pi + half;
+      const bool ok = key < T;
+      const float p = ok ? prow[key] : 0.f;
+#pragma unroll
+      for (int dt = 0; dt < NDT; ++dt) {
+        const int d = dt * 32 + l32;
+        const float v = (ok && d < DK) ? vb[(size_t)key * 3 * C + d] : 0.f;
+        acc[dt] = __builtin_amdgcn_mfma_f32_32x32x2f32(p, v, acc[dt], 0, 0, 0);
+      }
+    }
+  }
+  // relative values need p[i, i + r - w]: read them before S is reused as the reduction buffer
+  const int oi = tid >> 3;  // output row of this thread in the final loop (32 rows x 8 threads)
+  float prel[32];
+#pragma unroll
+  for (int r = 0; r < 32; ++r) {
+    const int j = i0 + oi + r - w;
+    prel[r] = (w >= 0 && r < nrel && j >= 0 && j < T) ? S[oi * ST + j] : 0.f;
+  }
+  __syncthreads();
+  float* red = S;  // [4 waves][32][DK + 1]
+  constexpr int RS = DK + 1;
+#pragma unroll
+  for (int dt = 0; dt < NDT; ++dt) {
+    const int d = dt * 32 + l32;
+    if (d < DK) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) red[(wave * 32 + (r & 3) + 8 * (r >> 2) + 4 * half) * RS + d] = acc[dt][r];
+    }
+  }
+  __syncthreads();
+  if (i0 + oi < T) {
+    for (int d = tid & 7; d < DK; d += 8) {
+      float v = red[oi * RS + d];
+#pragma unroll
+      for (int q = 1; q < 4; ++q) v = add_rn(v, red[(q * 32 + oi) * RS + d]);
+      if (w >= 0) {
+        float a = 0.f;
+#pragma unroll
+        for (int r = 0; r < 32; ++r)
+          if (r < nrel) a = fmaf(prel[r], g.ev[(size_t)r * DK + d], a);
+        v = add_rn(v, a);
+      }
+      g.out[(rowb + i0 + oi) * C + hd * DK + d] = v;
+    }
+  }
+}
+size_t mha_mfma_lds_bytes(int T, int dk) {
+  const size_t s = (size_t)kMhaMRows * (T | 1) + 32 * 33;
+  const size_t red = (size_t)4 * 32 * (dk + 1);
+  return (s > red ? s : red + 32 * 33) * sizeof(float);
+}
+
 // commons.fused_add_tanh_sigmoid_multiply with g = None (commons.py:102-109): [M, 2H] -> [M, H]
 __global__ void wn_gate_kernel(const float* xin, float* acts, int M, int H) {
   const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -381,10 +541,18 @@ int run_stack(ttsvits_handle* h, const StackBlob& sb, const StackDims& sd, const
               hipStream_t st) {
   const float* blob = h->blob;
   const int M = B * T, C = sd.C, dk = C / sd.heads;
-  const size_t lds = mha_lds_bytes(T, dk, sd.window);
+  // matrix-core attention when the score tile fits LDS (T <= ~1150) and dk is one of the built sizes;
+  // the scalar kernel covers everything else
+  const size_t lds_m = mha_mfma_lds_bytes(T, dk);
+  const bool use_mfma = lds_m <= kMhaMaxLds && sd.window <= 15 && (dk == 96 || dk == 48 || dk == 16 || dk == 8);
+  const size_t lds = use_mfma ? lds_m : mha_lds_bytes(T, dk, sd.window);
   if (lds > kMhaMaxLds || dk > 256) return TTSDEC_ERR_DIMS;
-  if (hipFuncSetAttribute((const void*)mha_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
-    return vits_fail(h, "hipFuncSetAttribute(mha_kernel)");
+  const void* kfn = !use_mfma ? (const void*)mha_kernel
+                   : dk == 96 ? (const void*)mha_mfma_kernel<48>
+                   : dk == 48 ? (const void*)mha_mfma_kernel<24>
+                   : dk == 16 ? (const void*)mha_mfma_kernel<8> : (const void*)mha_mfma_kernel<4>;
+  if (hipFuncSetAttribute(kfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+    return vits_fail(h, "hipFuncSetAttribute(mha kernel)");
   const float* xin = sw.xm;  // layer 0 attends over x * mask; later layers over the unmasked LayerNorm output
   for (int i = 0; i < sd.layers; ++i) {
     const float* xa = i == 0 ? sw.xm : sw.x;
@@ -393,7 +561,15 @@ int run_stack(ttsvits_handle* h, const StackBlob& sb, const StackDims& sd, const
     a.qkv = sw.qkv; a.mask = mask; a.out = sw.att; a.T = T; a.C = C; a.dk = dk; a.window = sd.window;
     a.ek = sd.window >= 0 ? blob + sb.ek[i] : nullptr; a.ev = sd.window >= 0 ? blob + sb.ev[i] : nullptr;
     a.qscale = sqrtf((float)dk);
-    hipLaunchKernelGGL(mha_kernel, dim3((T + kMhaRows - 1) / kMhaRows, sd.heads, B), dim3(kMhaThreads), lds, st, a);
+    if (use_mfma) {
+      const dim3 grid((T + kMhaMRows - 1) / kMhaMRows, sd.heads, B), block(kMhaMThreads);
+      if (dk == 96) hipLaunchKernelGGL(mha_mfma_kernel<48>, grid, block, lds, st, a);
+      else if (dk == 48) hipLaunchKernelGGL(mha_mfma_kernel<24>, grid, block, lds, st, a);
+      else if (dk == 16) hipLaunchKernelGGL(mha_mfma_kernel<8>, grid, block, lds, st, a);
+      else hipLaunchKernelGGL(mha_mfma_kernel<4>, grid, block, lds, st, a);
+    } else {
+      hipLaunchKernelGGL(mha_kernel, dim3((T + kMhaRows - 1) / kMhaRows, sd.heads, B), dim3(kMhaThreads), lds, st, a);
+    }
     // x = LayerNorm(x + conv_o(att))
     gemm_generic(sw.att, C, C, blob + sb.wo[i], blob + sb.bo[i], M, C, sw.t, C, 0, nullptr, xa, 1, T, st);
     hipLaunchKernelGGL(layernorm_rows_kernel, dim3((M + 3) / 4), dim3(256), 0, st, sw.t, blob + sb.g1[i], blob + sb.b1[i], mask, sw.x,
