@@ -74,6 +74,115 @@ def step_bytes(B, L, d):
     return out
 
 
+FP32_MFMA_PEAK_TFLOPS = 157.3  # MI355X_MICROARCH.md: dense fp32 matrix peak
+
+
+def vits2_flops(Tx, Ty, d):
+    """Algorithmic FLOPs of one utterance through TextEncoder (Tx tokens) + reverse flow (Ty frames)."""
+    def stack(T, C, F, k, layers, heads):
+        per_frame = 2 * (4 * C * C + 2 * k * C * F)           # q,k,v,o 1x1 convs + the two FFN convs
+        attn = 2 * 2 * T * C                                   # QK^T and PV per frame (all heads)
+        return layers * T * (per_frame + attn)
+    H, I, Fh = d["hidden_channels"], d["inter_channels"], d["flow_hidden"]
+    te = stack(Tx, H, d["filter_channels"], d["kernel_size"], d["n_layers"], d["n_heads"]) + Tx * 2 * H * 2 * I
+    half = I // 2
+    per_flow = stack(Ty, half, half, 3, 2, 2) + Ty * 2 * (half * Fh + Fh * half)
+    for j in range(d["flow_wn_layers"]):
+        per_flow += Ty * 2 * (d["flow_kernel"] * Fh * 2 * Fh + Fh * (2 * Fh if j < d["flow_wn_layers"] - 1 else Fh))
+    return te, d["n_flows"] * per_flow
+
+
+def bench_vits2(args, T, dist, dev, world, rank):
+    """Second hot path: one step = TextEncoder over [B, 120] tokens + the reverse
+    flow over [B, 192, 600] latent frames.  Utterances are independent: ranks take equal shares, no collective."""
+    import warnings
+
+    warnings.filterwarnings("ignore", category=FutureWarning)
+    B = args.batch if args.batch != 256 else 64
+    Tx, Ty = args.mem_len, args.frames
+    D = dict(n_vocab=178, inter_channels=192, hidden_channels=192, filter_channels=768, n_heads=2, n_layers=6, kernel_size=3, window_size=4,
+             flow_hidden=192, flow_kernel=5, flow_wn_layers=4, n_flows=4)
+    torch.manual_seed(42)
+    te = T.vits2.TextEncoder(D["n_vocab"], D["inter_channels"], D["hidden_channels"], D["filter_channels"], D["n_heads"], D["n_layers"],
+                             D["kernel_size"], 0.1).to(dev).eval()
+    fl = T.vits2.ResidualCouplingTransformersBlock(D["inter_channels"], D["flow_hidden"], D["flow_kernel"], 1, D["flow_wn_layers"], n_flows=D["n_flows"],
+                                                   use_transformer_flows=True).to(dev).eval()
+    for m in fl.modules():  # the reference zero-initialises `post`; give it weight so the coupling does real work
+        if isinstance(m, T.vits2.ResidualCouplingTransformersLayer):
+            torch.nn.init.normal_(m.post.weight, 0.0, 0.05)
+    g = torch.Generator().manual_seed(1234 + rank)
+    ids = torch.randint(0, D["n_vocab"], (B, Tx), generator=g).to(dev)
+    xl = torch.full((B,), Tx, device=dev)
+    z = torch.randn(B, D["inter_channels"], Ty, generator=g).to(dev)
+    ym = torch.ones(B, 1, Ty, device=dev)
+
+    def one_step():
+        with torch.no_grad():
+            a = te(ids, xl)
+            return a, fl(z, ym, reverse=True)
+
+    def fence():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(max(1, args.warmup)):
+        one_step()
+    fence()
+    ev = [torch.cuda.Event(enable_timing=True) for _ in range(3)]
+    te_ms = fl_ms = 0.0
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        with torch.no_grad():
+            ev[0].record(); te(ids, xl); ev[1].record(); out = fl(z, ym, reverse=True); ev[2].record()
+        ev[2].synchronize()
+        te_ms += ev[0].elapsed_time(ev[1]); fl_ms += ev[1].elapsed_time(ev[2])
+    fence()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        tt = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        elapsed = float(tt.item())
+    assert bool(torch.isfinite(out).all())
+    Bg = B * world
+    f_te, f_fl = vits2_flops(Tx, Ty, D)
+    fl_s = fl_ms / args.steps * 1e-3
+    res = {
+        "metric": "mel-frames/s (whole node) + real-time-factor, LJSpeech 22.05kHz hop256",
+        "value": round(Bg * Ty * args.steps / elapsed, 1), "unit": "mel-frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": round(elapsed * 1e3 / args.steps, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": "f32", "data": "synthetic",
+        "config": {"workload": f"vits2 second hot path (BASELINE.json configs[4]): TextEncoder [B={B}/GPU, {Tx} tokens] + reverse flow "
+                               f"[B, 192, {Ty} frames], ModelConfig defaults", "global_batch": Bg, "parallelism": f"utterance-shard x{world}"},
+        "rtf": round((elapsed / args.steps) / (Ty * FRAME_SEC), 6),
+        "text_encoder_ms": round(te_ms / args.steps, 3), "flow_reverse_ms": round(fl_ms / args.steps, 3),
+        "roofline": {"bound": "mfma", "kernel": "flow_reverse (whole pass: GEMMs + attention)", "achieved": round(B * f_fl / fl_s / 1e12, 2),
+                     "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(B * f_fl / fl_s / 1e12 / FP32_MFMA_PEAK_TFLOPS, 4),
+                     "traffic": None, "alg_flops_per_utterance": {"text_encoder": f_te, "flow_reverse": f_fl}},
+    }
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        from oracle import vits2_oracle as V
+
+        d = V.Vits2Dims()
+        wts = {"enc_p." + k: v.detach().cpu() for k, v in te.state_dict().items()}
+        wts.update({"flow." + k: v.detach().cpu() for k, v in fl.state_dict().items()})
+        cores = max(1, min(16, os.cpu_count() or 1, torch.get_num_threads()))
+        torch.set_num_threads(cores)
+        bc = min(B, 4)
+        t1 = time.perf_counter()
+        with torch.no_grad():
+            V.text_encoder(ids[:bc].cpu(), xl[:bc].cpu(), wts, d)
+            V.flow_reverse(z[:bc].cpu(), ym[:bc].cpu(), wts, d)
+        ct = time.perf_counter() - t1
+        res["cpu_baseline"] = {"value": round(bc * Ty / ct, 1), "unit": "mel-frames/s", "cores": cores, "kind": "port",
+                               "sample": f"oracle (torch-CPU restatement of the reference blocks) on B={bc}: TextEncoder {Tx} tokens + reverse flow {Ty} frames, {cores} threads"}
+    if rank == 0:
+        print(json.dumps(res), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -87,6 +196,9 @@ def main():
                     help="arithmetic of the LSTM gate GEMMs (include/ttsdec.h TTSDEC_PREC_*)")
     ap.add_argument("--config", choices=sorted(CONFIGS), default="ljspeech",
                     help="model dims: ljspeech = BASELINE.json's config (default); rdh / sandra = the other shipped configs")
+    ap.add_argument("--workload", choices=["tacotron", "vits2"], default="tacotron",
+                    help="tacotron = the headline decoder path (default); vits2 = the second hot path of BASELINE.json configs[4] "
+                         "(TextEncoder on [B, 120] + reverse flow on [B, 192, 600], ModelConfig defaults; --batch defaults to 64)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-frames", type=int, default=0, help="decode frames for the CPU baseline sample (0 = auto)")
     args = ap.parse_args()
@@ -114,6 +226,9 @@ def main():
     import torch_tts_amd as T
     from torch_tts_amd import _lib
     from torch_tts_amd import distributed as D
+
+    if args.workload == "vits2":
+        return bench_vits2(args, T, dist, dev, world, rank)
 
     B, L, NF = args.batch, args.mem_len, args.frames
     Bg = B * world  # global batch
