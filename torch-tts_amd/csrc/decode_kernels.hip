@@ -100,27 +100,34 @@ __global__ __launch_bounds__(kGemmThreads) void gemm_rows_kernel(GemmArgs g) {
   const int m0 = blockIdx.y * BM;
   const int n0 = blockIdx.x * BN;
 
-  // Epilogue operands are requested BEFORE the K loop (their latency hides under it).
-  float pre_bias[EPT], pre_res[EPT], pre_rm[EPT];
-  uint8_t pre_mask[EPT];
-#pragma unroll
-  for (int j = 0; j < EPT; ++j) {
-    const int e = threadIdx.x + j * kGemmThreads;
-    const int m = m0 + e / BN, n = n0 + e % BN;
-    const bool ok = live && m < g.M && n < g.N;
-    pre_bias[j] = (ok && g.bias != nullptr) ? g.bias[n] : 0.f;
-    pre_mask[j] = 1;
-    pre_res[j] = 0.f;
-    if (EK == EPI_RELU_DROPOUT && ok && g.dropout_mode == TTSDEC_DROPOUT_MASKS) pre_mask[j] = g.masks[(size_t)m * g.N + n];
+  // Epilogue operands are requested BEFORE the K loop (their latency hides under it) - for the
+  // small tiles, where a thread owns <= 8 outputs; the 128x128 tiles fetch them in the epilogue.
+  constexpr bool kPre = EPT <= 8;
+  constexpr int NPRE = kPre ? EPT : 1;
+  auto load_epi = [&](int m, int n, bool ok, float& pb, float& pr, float& prm, uint8_t& pm) {
+    pb = (ok && g.bias != nullptr) ? g.bias[n] : 0.f;
+    pm = 1;
+    pr = 0.f;
+    prm = 1.0f;
+    if (EK == EPI_RELU_DROPOUT && ok && g.dropout_mode == TTSDEC_DROPOUT_MASKS) pm = g.masks[(size_t)m * g.N + n];
     if ((EK == EPI_BN_ISRU || EK == EPI_BN_LRELU || EK == EPI_BN_ISRLU) && ok) {
-      pre_bias[j] = g.alpha[n];
-      pre_res[j] = g.beta[n];
+      pb = g.alpha[n];
+      pr = g.beta[n];
     }
-    if (EK == EPI_RESIDUAL && ok) pre_res[j] = g.resid[(size_t)m * g.ldo + n];
-    pre_rm[j] = 1.0f;
+    if (EK == EPI_RESIDUAL && ok) pr = g.resid[(size_t)m * g.ldo + n];
     if (EK == EPI_GENERIC && ok) {
-      if (g.resid != nullptr) pre_res[j] = g.resid[(size_t)m * g.ldo + n];
-      if (g.row_mask != nullptr) pre_rm[j] = g.row_mask[m];
+      if (g.resid != nullptr) pr = g.resid[(size_t)m * g.ldo + n];
+      if (g.row_mask != nullptr) prm = g.row_mask[m];
+    }
+  };
+  float pre_bias[NPRE], pre_res[NPRE], pre_rm[NPRE];
+  uint8_t pre_mask[NPRE];
+  if constexpr (kPre) {
+#pragma unroll
+    for (int j = 0; j < EPT; ++j) {
+      const int e = threadIdx.x + j * kGemmThreads;
+      const int m = m0 + e / BN, n = n0 + e % BN;
+      load_epi(m, n, live && m < g.M && n < g.N, pre_bias[j], pre_res[j], pre_rm[j], pre_mask[j]);
     }
   }
 
@@ -162,7 +169,11 @@ __global__ __launch_bounds__(kGemmThreads) void gemm_rows_kernel(GemmArgs g) {
     const int m = m0 + row, n = n0 + col;
     if (m >= g.M || n >= g.N) continue;
     float v = smem[row * LDO + col];
-    if (EK != EPI_BN_ISRU && EK != EPI_BN_LRELU && EK != EPI_BN_ISRLU && g.bias != nullptr) v = add_rn(v, pre_bias[j]);
+    float pb, pr, prm;
+    uint8_t pm;
+    if constexpr (kPre) { pb = pre_bias[j]; pr = pre_res[j]; prm = pre_rm[j]; pm = pre_mask[j]; }
+    else load_epi(m, n, true, pb, pr, prm, pm);
+    if (EK != EPI_BN_ISRU && EK != EPI_BN_LRELU && EK != EPI_BN_ISRLU && g.bias != nullptr) v = add_rn(v, pb);
     auto store16 = [&](float val) {  // 16-bit copies for a following 16-bit GEMM
       const size_t o = (size_t)m * g.ldo + n;
       if (g.out_kind == 1) split_f16(val, g.out_h[o], g.out_l[o]);
@@ -175,7 +186,7 @@ __global__ __launch_bounds__(kGemmThreads) void gemm_rows_kernel(GemmArgs g) {
       // modules.py:39-40: relu then dropout(p, always): kept units scaled by 1/(1-p)
       v = v > 0.f ? v : 0.f;
       if (g.dropout_mode == TTSDEC_DROPOUT_MASKS) {
-        v = pre_mask[j] ? mul_rn(v, g.keep_scale) : 0.f;
+        v = pm ? mul_rn(v, g.keep_scale) : 0.f;
       } else if (g.dropout_mode == TTSDEC_DROPOUT_PHILOX) {
         v = philox_keep(g.seed, (uint32_t)g.t, (uint32_t)g.layer, (uint32_t)m, (uint32_t)n) ? mul_rn(v, g.keep_scale) : 0.f;
       }
@@ -197,29 +208,29 @@ __global__ __launch_bounds__(kGemmThreads) void gemm_rows_kernel(GemmArgs g) {
       }
     } else if (EK == EPI_BN_ISRU) {
       // modules.py:181 isru(BatchNorm1d(conv(x))) with eval-mode BN as x*alpha + beta
-      v = isru(add_rn(mul_rn(v, pre_bias[j]), pre_res[j]));
+      v = isru(add_rn(mul_rn(v, pb), pr));
       if (g.out != nullptr) g.out[(size_t)m * g.ldo + n] = v;
       store16(v);
     } else if (EK == EPI_BN_ISRLU) {
       // encoder.py:49-57 ISRLU(BatchNorm1d(conv(x))): x >= 0 ? x : x / sqrt(1 + x*x)  (activations.py:13-14)
-      v = add_rn(mul_rn(v, pre_bias[j]), pre_res[j]);
+      v = add_rn(mul_rn(v, pb), pr);
       v = v >= 0.f ? v : isru(v);
       if (g.out != nullptr) g.out[(size_t)m * g.ldo + n] = v;
       store16(v);
     } else if (EK == EPI_BN_LRELU) {
       // modules.py:196-198 LeakyReLU(BatchNorm1d(conv(x))), default negative_slope 0.01
-      v = add_rn(mul_rn(v, pre_bias[j]), pre_res[j]);
+      v = add_rn(mul_rn(v, pb), pr);
       v = v > 0.f ? v : mul_rn(v, 0.01f);
       if (g.out != nullptr) g.out[(size_t)m * g.ldo + n] = v;
       store16(v);
     } else if (EK == EPI_GENERIC) {
       if (g.act == 1) v = v > 0.f ? v : 0.f;
-      if (g.row_mask != nullptr) v = mul_rn(v, pre_rm[j]);
-      if (g.resid != nullptr) v = add_rn(pre_res[j], v);
+      if (g.row_mask != nullptr) v = mul_rn(v, prm);
+      if (g.resid != nullptr) v = add_rn(pr, v);
       g.out[(size_t)m * g.ldo + n] = v;
     } else if (EK == EPI_RESIDUAL) {
       // modules.py:184 x + fc_out(...)  /  modules.py:215 x + layer(x)
-      v = add_rn(pre_res[j], v);
+      v = add_rn(pr, v);
       g.out[(size_t)m * g.ldo + n] = v;
       store16(v);
     }
@@ -231,6 +242,15 @@ static void launch_gemm_cfg(const GemmArgs& a, hipStream_t st) {
   // Pick the tile so the grid covers the 256 CUs when it can; small M uses 32x32 tiles
   // with the four MFMA waves splitting K.
   const long tiles_big = (long)((a.M + 63) / 64) * ((a.N + 63) / 64);
+  if constexpr (PREC != PREC_F32) {
+    // large 16-bit GEMMs (Postnet convs): 128x128 tiles, half-depth stages (see TileCfg)
+    if (a.N >= 128 && a.M >= 2048) {
+      using Cfg = TileCfg<2, 2, 1, 4, PREC, 0, 2, 2, 1>;
+      dim3 grid((a.N + Cfg::BN - 1) / Cfg::BN, (a.M + Cfg::BM - 1) / Cfg::BM);
+      hipLaunchKernelGGL((gemm_rows_kernel<Cfg, AK, EK>), grid, dim3(kGemmThreads), 0, st, a);
+      return;
+    }
+  }
   if (PREC != PREC_F32 || (a.M >= 64 && tiles_big >= 512)) {
     // 64x64 tiles; ring: fp32 4 x 16 KiB, bf16 5 x 16 KiB, split-fp16 4 x 32 KiB
     using Cfg = TileCfg<2, 2, 1, (PREC == PREC_BF16 ? 5 : 4), PREC>;

@@ -43,18 +43,28 @@
 namespace ttsdec {
 
 
-template <int WM, int WN, int WK, int S, int PREC = PREC_F32, int AUXB = 0>
+// TM x TN > 1 ("big" tiles, 16-bit modes only): every MFMA wave owns TM x TN 32x32 accumulators, so a
+// 2x2 arrangement of waves covers 128x128 outputs and each byte staged through LDS feeds twice the
+// MFMAs of the 64x64 tile (the large GEMMs are bound by the per-CU ingest rate, not by the matrix
+// pipe).  HK = 1 halves the K depth of a stage (64-byte rows) so that four such stages still fit LDS.
+// Big tiles read their fragments single-buffered, right after the barrier that publishes the tile.
+template <int WM, int WN, int WK, int S, int PREC = PREC_F32, int AUXB = 0, int TM = 1, int TN = 1, int HK = 0>
 struct TileCfg {
   static constexpr int kAuxB = AUXB;  // cache-policy bits of the B (weight) operand's LDS-DMA: 2 = nt (streamed once)
   static constexpr int NMW = WM * WN * WK;  // active MFMA waves (of the 4 in the workgroup)
+  static constexpr int kWM = WM, kWN = WN, kWK = WK, kTM = TM, kTN = TN;
+  static constexpr bool kBig = TM * TN > 1;
   static_assert(NMW == 4 || NMW == 2, "2 or 4 active MFMA waves per workgroup");
-  static_assert(S >= 3, "ring needs at least 3 stages (fragment reads run one tile ahead of the MFMAs)");
+  static_assert(kBig || S >= 3, "ring needs at least 3 stages (fragment reads run one tile ahead of the MFMAs)");
+  static_assert(!kBig || (PREC != PREC_F32 && WK == 1 && NMW == 4 && S >= 2), "big tiles: 16-bit modes, no intra-workgroup split-K");
+  static_assert(!HK || WK == 1, "half-depth stages have no K slices");
   static constexpr int kPrec = PREC;
   static constexpr int EB = (PREC == PREC_F32) ? 4 : 2;      // element bytes
   static constexpr int NP = (PREC == PREC_F16S) ? 2 : 1;     // planes per operand
-  static constexpr int BM = 32 * WM;
-  static constexpr int BN = 32 * WN;
-  static constexpr int ROWB = 128 * WK;                      // bytes per tile row per plane
+  static constexpr int BM = 32 * WM * TM;
+  static constexpr int BN = 32 * WN * TN;
+  static constexpr int ROWB = HK ? 64 : 128 * WK;            // bytes per tile row per plane
+  static constexpr int NS16 = HK ? 2 : 4;                    // k16 steps of a 16-bit tile (per K slice)
   static constexpr int KT = ROWB / EB;                       // K elements per tile
   static constexpr int C16 = ROWB / 16;                      // 16-byte columns per tile row
   static constexpr int ROWS_PER_INST = 64 / C16;             // tile rows one wave instruction covers
@@ -71,10 +81,14 @@ struct TileCfg {
   static constexpr int kLdsBytes = kRingBytes > kOutBytes ? kRingBytes : kOutBytes;
   static constexpr int kLdsFloats = kLdsBytes / 4;
   // loads left in flight when the tile whose fragments are read NEXT (one ahead of the MFMAs) has landed
-  static constexpr int kWaitCnt = (S - 3) * NLOADS;
+  static constexpr int kWaitCnt = (kBig ? S - 2 : S - 3) * NLOADS;
   static_assert((S - 2) * NLOADS <= 63, "vmcnt field");
   static_assert(kLdsBytes <= 160 * 1024, "LDS per workgroup");
-  __device__ static __forceinline__ int swz(int row) { return ROWB == 128 ? ((row >> 1) & 7) : (row & 15); }
+  // 16-byte column swizzle: rows are packed 256/ROWB to an LDS bank row; the 16 lanes of a ds_read_b128
+  // group (16 consecutive rows, same column) must land in 16 distinct 16-byte slots
+  __device__ static __forceinline__ int swz(int row) {
+    return ROWB == 64 ? ((row >> 2) & 3) : (ROWB == 128 ? ((row >> 1) & 7) : (row & 15));
+  }
 };
 
 typedef __attribute__((address_space(3))) void lds_void;
@@ -116,7 +130,7 @@ __device__ __forceinline__ void gemm_tile(const LoaderA& la, const LoaderB& lb, 
   constexpr int BM = Cfg::BM, BN = Cfg::BN, KT = Cfg::KT, C16 = Cfg::C16, RPI = Cfg::ROWS_PER_INST;
   constexpr int NA = Cfg::NA, NB = Cfg::NB, NP = Cfg::NP, EB = Cfg::EB, ROWB = Cfg::ROWB;
   constexpr int LDO = Cfg::LDO, S = Cfg::STAGES;
-  constexpr int WN_ = BN / 32, WK_ = ROWB / 128;
+  constexpr int WN_ = Cfg::kWN, WK_ = Cfg::kWK;
   constexpr int EPC = 16 / EB;  // elements per 16-byte column
   char* lds = reinterpret_cast<char*>(smem);
   const int tid = threadIdx.x;
@@ -249,13 +263,15 @@ __device__ __forceinline__ void gemm_tile(const LoaderA& la, const LoaderB& lb, 
 #pragma unroll
     for (int t = 0; t < S - 1; ++t) issue_tile();
     const int nk_run = live ? nk : 0;
-    if (live) {
+    if (live && !Cfg::kBig) {
       wait_vmcnt<(S - 2) * Cfg::NLOADS>();  // tile 0 landed
       __builtin_amdgcn_s_barrier();         // B0
     }
     for (int t = 0; t < nk_run; ++t) {
-      wait_vmcnt<Cfg::kWaitCnt>();        // this wave's part of tile t+1 has landed
-      __builtin_amdgcn_s_barrier();       // B(t+1): the MFMA waves have issued tile t-1's MFMAs, its stage is free
+      // small tiles: this wave's part of tile t+1 has landed (fragments are read one tile ahead);
+      // big tiles: tile t has landed (fragments are read right after this barrier)
+      wait_vmcnt<Cfg::kWaitCnt>();
+      __builtin_amdgcn_s_barrier();       // the MFMA waves are done reading the stage tile t-1 occupied
       if (dbg != 3) issue_tile();         // tile t+S-1 into that stage (dbg 3: measurement ablation)
     }
     wait_vmcnt<0>();  // trailing zero-block loads must land before the ring is reused
@@ -269,6 +285,78 @@ __device__ __forceinline__ void gemm_tile(const LoaderA& la, const LoaderB& lb, 
         __builtin_amdgcn_s_barrier();
         for (int t = 0; t < nk; ++t) __builtin_amdgcn_s_barrier();
       }
+    } else if constexpr (Cfg::kBig) {
+      // TM x TN accumulators per wave, 16-bit planes; fragments single-buffered
+      constexpr int TM = Cfg::kTM, TN = Cfg::kTN, NS = Cfg::NS16;
+      f32x16 accb[TM][TN], accb2[TM][TN];
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+          for (int e = 0; e < 16; ++e) { accb[i][j][e] = 0.f; accb2[i][j][e] = 0.f; }
+      int aoff[TM][NS], boff[TN][NS];
+#pragma unroll
+      for (int s = 0; s < NS; ++s) {
+        const int c16 = s * 2 + half;
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+          const int r = (wm * TM + i) * 32 + l32;
+          aoff[i][s] = r * ROWB + ((c16 ^ Cfg::swz(r)) << 4);
+        }
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+          const int r = (wn * TN + j) * 32 + l32;
+          boff[j][s] = NP * Cfg::kPlaneABytes + r * ROWB + ((c16 ^ Cfg::swz(r)) << 4);
+        }
+      }
+      const int nk_run = live ? nk : 0;
+      for (int t = 0; t < nk_run; ++t) {
+        __builtin_amdgcn_s_barrier();  // tile t is in LDS
+        const char* st = lds + rstage * Cfg::kStageBytes;
+        rstage = (rstage + 1 == S) ? 0 : rstage + 1;
+        f16x8 ah[TM][NS], al[TM][NS], bh[TN][NS], bl[TN][NS];
+#pragma unroll
+        for (int s = 0; s < NS; ++s) {
+#pragma unroll
+          for (int i = 0; i < TM; ++i) {
+            ah[i][s] = *reinterpret_cast<const f16x8*>(st + aoff[i][s]);
+            if constexpr (NP == 2) al[i][s] = *reinterpret_cast<const f16x8*>(st + Cfg::kPlaneABytes + aoff[i][s]);
+          }
+#pragma unroll
+          for (int j = 0; j < TN; ++j) {
+            bh[j][s] = *reinterpret_cast<const f16x8*>(st + boff[j][s]);
+            if constexpr (NP == 2) bl[j][s] = *reinterpret_cast<const f16x8*>(st + Cfg::kPlaneBBytes + boff[j][s]);
+          }
+        }
+#pragma unroll
+        for (int s = 0; s < NS; ++s)
+#pragma unroll
+          for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int j = 0; j < TN; ++j) {
+              if constexpr (Cfg::kPrec == PREC_F16S) {
+                accb[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[i][s], bh[j][s], accb[i][j], 0, 0, 0);
+                accb2[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[i][s], bl[j][s], accb2[i][j], 0, 0, 0);
+                accb2[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[i][s], bh[j][s], accb2[i][j], 0, 0, 0);
+              } else {
+                accb[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, ah[i][s]),
+                                                                     __builtin_bit_cast(bf16x8, bh[j][s]), accb[i][j], 0, 0, 0);
+              }
+            }
+      }
+      __syncthreads();  // every wave is done with the ring: the out tile may overwrite it
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            float v = accb[i][j][r];
+            if constexpr (Cfg::kPrec == PREC_F16S) v = fmaf(accb2[i][j][r], 1.0f / kSplitScale, v);
+            const int row = (wm * TM + i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+            smem[row * LDO + (wn * TN + j) * 32 + l32] = v;
+          }
     } else if constexpr (Cfg::kPrec == PREC_F32) {
       int aoff[4], boff[4];  // byte offsets inside a stage
 #pragma unroll
@@ -375,11 +463,11 @@ __device__ __forceinline__ void gemm_tile(const LoaderA& la, const LoaderB& lb, 
       }
     }
   }
-  __syncthreads();
+  if (!(Cfg::kBig && !is_loader)) __syncthreads();  // (big-tile MFMA waves crossed this barrier before their stores)
 
   // accumulators -> LDS out tile (aliases the ring).
   // C/D map of the 32x32 MFMA: col = lane & 31, row = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5).
-  if (!is_loader && wave < Cfg::NMW) {
+  if (!Cfg::kBig && !is_loader && wave < Cfg::NMW) {
     float* out = smem + wk * BM * LDO;
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
