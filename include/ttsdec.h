@@ -299,7 +299,7 @@ int ttsenc_forward(ttsenc_handle* h, const int64_t* ids, const int32_t* lengths,
  *       over ResidualCouplingTransformersLayer.forward, models.py:506-531 (mean-only), with
  *       modules.WN.forward modules.py:185-210, commons.fused_add_tanh_sigmoid_multiply commons.py:102-109
  *       and modules.Flip modules.py:374-381.
- * Eval mode, no speaker conditioning (g = None), exact fp32.  Activations at this boundary are
+ * Eval mode, no speaker conditioning (g = None), split-fp16 GEMMs (fp32-class accuracy: hi+lo fp16 planes, fp32 accumulate), fp32 elsewhere.  Activations at this boundary are
  * CHANNEL-LAST: [B, T, C] (the reference's [B, C, T] transposed).
  * ------------------------------------------------------------------------------------- */
 typedef struct ttsvits_dims {

@@ -276,8 +276,8 @@ void launch_gemm(const GemmArgs& a, AKind ak, EpiKind ek, hipStream_t st) {
   if (ak == A_CONV && ek == EPI_BN_LRELU) return launch_gemm_prec<A_CONV, EPI_BN_LRELU>(a, st);
   if (ak == A_CONV && ek == EPI_BN_ISRLU) return launch_gemm_prec<A_CONV, EPI_BN_ISRLU>(a, st);
   if (ak == A_CONV && ek == EPI_RESIDUAL) return launch_gemm_prec<A_CONV, EPI_RESIDUAL>(a, st);
-  if (ak == A_CONV && ek == EPI_GENERIC) return launch_gemm_cfg<A_CONV, EPI_GENERIC, PREC_F32>(a, st);
-  if (ek == EPI_GENERIC) return launch_gemm_cfg<A_PLAIN, EPI_GENERIC, PREC_F32>(a, st);
+  if (ak == A_CONV && ek == EPI_GENERIC) return launch_gemm_prec<A_CONV, EPI_GENERIC>(a, st);
+  if (ek == EPI_GENERIC) return launch_gemm_prec<A_PLAIN, EPI_GENERIC>(a, st);
   switch (ek) {
     case EPI_PLAIN: return launch_gemm_cfg<A_PLAIN, EPI_PLAIN, PREC_F32>(a, st);
     case EPI_RELU_DROPOUT: return launch_gemm_cfg<A_PLAIN, EPI_RELU_DROPOUT, PREC_F32>(a, st);

@@ -5,7 +5,8 @@
 // channel-last activations, bias / ReLU / frame mask / residual in the epilogue) plus four small
 // kernels of its own: channel LayerNorm, relative-position multi-head attention, the WN gate and the
 // coupling update.  Activations are channel-last [B*T, C] (one row per frame) throughout - the
-// reference's [B, C, T] is transposed once at the boundary by the host module.  Exact fp32.
+// reference's [B, C, T] is transposed once at the boundary by the host module.  GEMMs run in the
+// split-fp16 mode of the GEMM core (fp32-class accuracy, gemm_tile.h); everything else is fp32.
 #include <math.h>
 #include <string.h>
 
@@ -62,30 +63,32 @@ VitsBlob make_layout(const ttsvits_dims& d) {
   memset(&L, 0, sizeof(L));
   size_t off = 0;
   auto take = [&](size_t n) { const size_t o = off; off = up(off + n, kAlign); return o; };
+  // a GEMM weight of n elements occupies 2n floats: fp32 | fp16 hi plane | fp16 lo plane (w_hi / w_lo below)
+  auto take_w = [&](size_t n) { return take(2 * n); };
   auto stack = [&](StackBlob& s, const StackDims& sd) {
     const size_t C = sd.C, F = sd.F, k = sd.kernel, dk = sd.C / sd.heads;
     for (int i = 0; i < sd.layers; ++i) {
-      s.wqkv[i] = take(3 * C * C); s.bqkv[i] = take(3 * C); s.wo[i] = take(C * C); s.bo[i] = take(C);
+      s.wqkv[i] = take_w(3 * C * C); s.bqkv[i] = take(3 * C); s.wo[i] = take_w(C * C); s.bo[i] = take(C);
       if (sd.window >= 0) { s.ek[i] = take((2 * sd.window + 1) * dk); s.ev[i] = take((2 * sd.window + 1) * dk); }
       s.g1[i] = take(C); s.b1[i] = take(C);
-      s.w1[i] = take(F * k * C); s.c1[i] = take(F); s.w2[i] = take(C * k * F); s.c2[i] = take(C);
+      s.w1[i] = take_w(F * k * C); s.c1[i] = take(F); s.w2[i] = take_w(C * k * F); s.c2[i] = take(C);
       s.g2[i] = take(C); s.b2[i] = take(C);
     }
   };
   const size_t H = d.hidden_channels, I = d.inter_channels, half = I / 2, Fh = d.flow_hidden;
   L.emb = take((size_t)d.n_vocab * H);
   stack(L.enc, enc_dims(d));
-  L.proj_w = take(2 * I * H); L.proj_b = take(2 * I);
+  L.proj_w = take_w(2 * I * H); L.proj_b = take(2 * I);
   for (int f = 0; f < d.n_flows; ++f) {
     FlowBlob& fb = L.flow[f];
     stack(fb.tf, tf_dims(d));
-    fb.pre_w = take(Fh * half); fb.pre_b = take(Fh);
+    fb.pre_w = take_w(Fh * half); fb.pre_b = take(Fh);
     for (int j = 0; j < d.flow_wn_layers; ++j) {
       const size_t cr = j < d.flow_wn_layers - 1 ? 2 * Fh : Fh;
-      fb.in_w[j] = take(2 * Fh * d.flow_kernel * Fh); fb.in_b[j] = take(2 * Fh);
-      fb.rs_w[j] = take(cr * Fh); fb.rs_b[j] = take(cr);
+      fb.in_w[j] = take_w(2 * Fh * d.flow_kernel * Fh); fb.in_b[j] = take(2 * Fh);
+      fb.rs_w[j] = take_w(cr * Fh); fb.rs_b[j] = take(cr);
     }
-    fb.post_w = take(half * Fh); fb.post_b = take(half);
+    fb.post_w = take_w(half * Fh); fb.post_b = take(half);
   }
   L.total = off;
   return L;
@@ -305,7 +308,7 @@ __global__ __launch_bounds__(kMhaMThreads) void mha_mfma_kernel(MhaArgs g) {
   const int T = g.T, C = g.C, w = g.window;
   const int ST = T | 1;                    // odd row stride: the 32 rows of a column hit 32 banks
   float* S = sm;                           // [32][ST]   (aliased by the pass-2 reduction buffer)
-  float* R = S + kMhaMRows * ST;           // [32][33] relative-key logits
+  float* R = S + kMhaMRows * ST;           // [32][33] relative-key logits (windowed attention only)
   const int nrel = w >= 0 ? 2 * w + 1 : 0;
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, l32 = lane & 31, half = lane >> 5;
   const int b = blockIdx.z, hd = blockIdx.y, i0 = blockIdx.x * kMhaMRows;
@@ -340,14 +343,17 @@ __global__ __launch_bounds__(kMhaMThreads) void mha_mfma_kernel(MhaArgs g) {
     for (int r = 0; r < 16; ++r) R[((r & 3) + 8 * (r >> 2) + 4 * half) * 33 + l32] = acc[r];
   }
   __syncthreads();
-  // ---- pass 1: scores, 32 keys per tile, tiles round-robin over the waves ----
+  // ---- pass 1: scores, 32 keys per tile, tiles round-robin over the waves; the next tile's K
+  // fragments are requested before the current tile's MFMAs ----
   const int ntile = (T + 31) / 32;
-  for (int kt = wave; kt < ntile; kt += 4) {
+  auto load_k = [&](int kt, f32x4 (&kb)[DKH / 4]) {
     const int j = kt * 32 + l32;
     gf32x4* src = (gf32x4*)(base + (size_t)(j < T ? j : T - 1) * 3 * C + C + half * DKH);
-    f32x4 kb[DKH / 4];
 #pragma unroll
     for (int q = 0; q < DKH / 4; ++q) kb[q] = src[q];
+  };
+  auto score_tile = [&](int kt, const f32x4 (&kb)[DKH / 4]) {
+    const int j = kt * 32 + l32;
     f32x16 acc = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int q = 0; q < DKH / 4; ++q)
@@ -365,6 +371,18 @@ __global__ __launch_bounds__(kMhaMThreads) void mha_mfma_kernel(MhaArgs g) {
         const float mi = i < T ? g.mask[rowb + i] : 0.f;
         if (mi * mj == 0.f) s = -1e4f;
         S[row * ST + j] = s;
+      }
+    }
+  };
+  {
+    f32x4 kb0[DKH / 4], kb1[DKH / 4];
+    if (wave < ntile) load_k(wave, kb0);
+    for (int kt = wave; kt < ntile; kt += 8) {
+      if (kt + 4 < ntile) load_k(kt + 4, kb1);
+      score_tile(kt, kb0);
+      if (kt + 4 < ntile) {
+        if (kt + 8 < ntile) load_k(kt + 8, kb0);
+        score_tile(kt + 4, kb1);
       }
     }
   }
@@ -395,16 +413,24 @@ __global__ __launch_bounds__(kMhaMThreads) void mha_mfma_kernel(MhaArgs g) {
     const float* vb = base + 2 * C;
     const float* prow = S + l32 * ST;
     const int npair = (T + 1) / 2;
-    for (int pi = wave; pi < npair; pi += 4) {
-      const int key = 2 * pi + half;
-      const bool ok = key < T;
-      const float p = ok ? prow[key] : 0.f;
+    constexpr int G = 8;  // key pairs whose V values are requested together (latency paid once per group)
+    for (int p0 = wave * G; p0 < npair; p0 += 4 * G) {
+      float pv[G], vv[G][NDT];
 #pragma unroll
-      for (int dt = 0; dt < NDT; ++dt) {
-        const int d = dt * 32 + l32;
-        const float v = (ok && d < DK) ? vb[(size_t)key * 3 * C + d] : 0.f;
-        acc[dt] = __builtin_amdgcn_mfma_f32_32x32x2f32(p, v, acc[dt], 0, 0, 0);
+      for (int u = 0; u < G; ++u) {
+        const int key = 2 * (p0 + u) + half;
+        const bool ok = key < T;
+        pv[u] = ok ? prow[key] : 0.f;
+#pragma unroll
+        for (int dt = 0; dt < NDT; ++dt) {
+          const int d = dt * 32 + l32;
+          vv[u][dt] = (ok && d < DK) ? vb[(size_t)key * 3 * C + d] : 0.f;
+        }
       }
+#pragma unroll
+      for (int u = 0; u < G; ++u)
+#pragma unroll
+        for (int dt = 0; dt < NDT; ++dt) acc[dt] = __builtin_amdgcn_mfma_f32_32x32x2f32(pv[u], vv[u][dt], acc[dt], 0, 0, 0);
     }
   }
   // relative values need p[i, i + r - w]: read them before S is reused as the reduction buffer
@@ -443,10 +469,11 @@ __global__ __launch_bounds__(kMhaMThreads) void mha_mfma_kernel(MhaArgs g) {
     }
   }
 }
-size_t mha_mfma_lds_bytes(int T, int dk) {
-  const size_t s = (size_t)kMhaMRows * (T | 1) + 32 * 33;
+size_t mha_mfma_lds_bytes(int T, int dk, int window) {
+  const size_t rel = window >= 0 ? 32 * 33 : 0;
+  const size_t s = (size_t)kMhaMRows * (T | 1) + rel;
   const size_t red = (size_t)4 * 32 * (dk + 1);
-  return (s > red ? s : red + 32 * 33) * sizeof(float);
+  return (s > red ? s : red) * sizeof(float);
 }
 
 // commons.fused_add_tanh_sigmoid_multiply with g = None (commons.py:102-109): [M, 2H] -> [M, H]
@@ -509,18 +536,36 @@ inline dim3 grid1(size_t n) { return dim3((unsigned)((n + 255) / 256)); }
 // ---------------------------------------------------------------------------
 // host-side building blocks
 // ---------------------------------------------------------------------------
-void gemm_generic(const float* a, int lda, int K, const float* W, const float* bias, int M, int N, float* out, int ldo, int act,
-                  const float* row_mask, const float* resid, int taps, int T, hipStream_t st) {
+// One GEMM of the path.  W points at the packed weight (fp32 | hi | lo, see make_layout) of n_w elements.
+// Split-fp16 arithmetic (3 f16 MFMA products, fp32 accumulate - the same accuracy class as fp32, see
+// gemm_tile.h): the A operand's planes are produced by one elementwise pass into `planes`.
+struct GemmCtx {
+  f16* planes;  // scratch for the A operand's hi / lo planes: 2 * max(M * K) halfs
+  bool split;   // false: exact fp32 MFMAs
+};
+void gemm_generic(const GemmCtx& cx, const float* a, int lda, int K, const float* W, size_t n_w, const float* bias, int M, int N, float* out,
+                  int ldo, int act, const float* row_mask, const float* resid, int taps, int T, hipStream_t st) {
   GemmArgs g;
   memset(&g, 0, sizeof(g));
   g.M = M; g.N = N; g.bias = bias; g.out = out; g.ldo = ldo; g.act = act; g.row_mask = row_mask; g.resid = resid;
+  const void *a0 = a, *a1 = a;
   g.W = g.W_lo = W;
+  const bool split = cx.split && lda == K && !(K & 7);
+  if (split) {
+    f16* ph = cx.planes;
+    f16* pl = cx.planes + (size_t)M * K;
+    launch_split(a, ph, pl, (size_t)M * K, st);
+    a0 = ph; a1 = pl;
+    g.prec = PREC_F16S;
+    g.W = reinterpret_cast<const f16*>(W + n_w);
+    g.W_lo = reinterpret_cast<const f16*>(W + n_w) + n_w;
+  }
   if (taps > 1) {
-    g.a = make_seg1(a, K, K); g.a_lo = g.a;
+    g.a = make_seg1(a0, K, K); g.a_lo = make_seg1(a1, K, K);
     g.T = T; g.Cin = K; g.taps = taps; g.ldw = taps * K; g.K = taps * K;
     launch_gemm(g, A_CONV, EPI_GENERIC, st);
   } else {
-    g.a = make_seg1(a, lda, K); g.a_lo = g.a;
+    g.a = make_seg1(a0, lda, K); g.a_lo = make_seg1(a1, lda, K);
     g.ldw = K; g.K = K;
     launch_gemm(g, A_PLAIN, EPI_GENERIC, st);
   }
@@ -528,6 +573,7 @@ void gemm_generic(const float* a, int lda, int K, const float* W, const float* b
 
 struct StackWs {
   float *x, *xm, *qkv, *att, *t, *f;  // [M,C] [M,C] [M,3C] [M,C] [M,C] [M,F]
+  GemmCtx cx;
 };
 size_t mha_lds_bytes(int T, int dk, int window) {
   const int nrel = window >= 0 ? 2 * window + 1 : 0;
@@ -543,7 +589,7 @@ int run_stack(ttsvits_handle* h, const StackBlob& sb, const StackDims& sd, const
   const int M = B * T, C = sd.C, dk = C / sd.heads;
   // matrix-core attention when the score tile fits LDS (T <= ~1150) and dk is one of the built sizes;
   // the scalar kernel covers everything else
-  const size_t lds_m = mha_mfma_lds_bytes(T, dk);
+  const size_t lds_m = mha_mfma_lds_bytes(T, dk, sd.window);
   const bool use_mfma = lds_m <= kMhaMaxLds && sd.window <= 15 && (dk == 96 || dk == 48 || dk == 16 || dk == 8);
   const size_t lds = use_mfma ? lds_m : mha_lds_bytes(T, dk, sd.window);
   if (lds > kMhaMaxLds || dk > 256) return TTSDEC_ERR_DIMS;
@@ -556,7 +602,7 @@ int run_stack(ttsvits_handle* h, const StackBlob& sb, const StackDims& sd, const
   const float* xin = sw.xm;  // layer 0 attends over x * mask; later layers over the unmasked LayerNorm output
   for (int i = 0; i < sd.layers; ++i) {
     const float* xa = i == 0 ? sw.xm : sw.x;
-    gemm_generic(xa, C, C, blob + sb.wqkv[i], blob + sb.bqkv[i], M, 3 * C, sw.qkv, 3 * C, 0, nullptr, nullptr, 1, T, st);
+    gemm_generic(sw.cx, xa, C, C, blob + sb.wqkv[i], (size_t)3 * C * C, blob + sb.bqkv[i], M, 3 * C, sw.qkv, 3 * C, 0, nullptr, nullptr, 1, T, st);
     MhaArgs a;
     a.qkv = sw.qkv; a.mask = mask; a.out = sw.att; a.T = T; a.C = C; a.dk = dk; a.window = sd.window;
     a.ek = sd.window >= 0 ? blob + sb.ek[i] : nullptr; a.ev = sd.window >= 0 ? blob + sb.ev[i] : nullptr;
@@ -571,12 +617,12 @@ int run_stack(ttsvits_handle* h, const StackBlob& sb, const StackDims& sd, const
       hipLaunchKernelGGL(mha_kernel, dim3((T + kMhaRows - 1) / kMhaRows, sd.heads, B), dim3(kMhaThreads), lds, st, a);
     }
     // x = LayerNorm(x + conv_o(att))
-    gemm_generic(sw.att, C, C, blob + sb.wo[i], blob + sb.bo[i], M, C, sw.t, C, 0, nullptr, xa, 1, T, st);
+    gemm_generic(sw.cx, sw.att, C, C, blob + sb.wo[i], (size_t)C * C, blob + sb.bo[i], M, C, sw.t, C, 0, nullptr, xa, 1, T, st);
     hipLaunchKernelGGL(layernorm_rows_kernel, dim3((M + 3) / 4), dim3(256), 0, st, sw.t, blob + sb.g1[i], blob + sb.b1[i], mask, sw.x,
                        sw.xm, M, C, 1e-5f);
     // FFN (attentions.py:411-419): conv_2(relu(conv_1(x * mask)) * mask) * mask, then x = LayerNorm(x + y)
-    gemm_generic(sw.xm, C, C, blob + sb.w1[i], blob + sb.c1[i], M, sd.F, sw.f, sd.F, 1, mask, nullptr, sd.kernel, T, st);
-    gemm_generic(sw.f, sd.F, sd.F, blob + sb.w2[i], blob + sb.c2[i], M, C, sw.t, C, 0, mask, sw.x, sd.kernel, T, st);
+    gemm_generic(sw.cx, sw.xm, C, C, blob + sb.w1[i], (size_t)sd.F * sd.kernel * C, blob + sb.c1[i], M, sd.F, sw.f, sd.F, 1, mask, nullptr, sd.kernel, T, st);
+    gemm_generic(sw.cx, sw.f, sd.F, sd.F, blob + sb.w2[i], (size_t)C * sd.kernel * sd.F, blob + sb.c2[i], M, C, sw.t, C, 0, mask, sw.x, sd.kernel, T, st);
     hipLaunchKernelGGL(layernorm_rows_kernel, dim3((M + 3) / 4), dim3(256), 0, st, sw.t, blob + sb.g2[i], blob + sb.b2[i], mask, sw.x,
                        sw.xm, M, C, 1e-5f);
   }
@@ -584,13 +630,23 @@ int run_stack(ttsvits_handle* h, const StackBlob& sb, const StackDims& sd, const
   return TTSDEC_OK;
 }
 
-size_t stack_ws_floats(const StackDims& sd, size_t M) { return M * (size_t)(4 * sd.C + 3 * sd.C + sd.F) + 8 * kAlign; }
+size_t stack_ws_floats(const StackDims& sd, size_t M) {
+  return M * (size_t)(4 * sd.C + 3 * sd.C + sd.F + (sd.C > sd.F ? sd.C : sd.F)) + 9 * kAlign;
+}
 StackWs carve_stack(float*& p, const StackDims& sd, size_t M) {
   auto take = [&](size_t n) { float* r = p; p += up(n, kAlign); return r; };
   StackWs w;
   w.x = take(M * sd.C); w.xm = take(M * sd.C); w.qkv = take(M * 3 * sd.C); w.att = take(M * sd.C); w.t = take(M * sd.C);
   w.f = take(M * sd.F);
+  w.cx.planes = reinterpret_cast<f16*>(take(M * (sd.C > sd.F ? sd.C : sd.F)));  // hi + lo planes of one A operand
+  w.cx.split = true;
   return w;
+}
+
+// fp32 weight at float offset `off` (n elements) -> its fp16 hi / lo planes right behind it
+void pack_planes(float* b, size_t off, size_t n, hipStream_t st) {
+  f16* hi = reinterpret_cast<f16*>(b + off + n);
+  launch_split(b + off, hi, hi + n, n, st);
 }
 
 int pack_stack(const float* const* src, int& k, float* b, const StackBlob& s, const StackDims& sd, hipStream_t st) {
@@ -602,6 +658,8 @@ int pack_stack(const float* const* src, int& k, float* b, const StackBlob& s, co
     }
     launch_copy(src[k + 6], b + s.wo[i], C * C, st);
     launch_copy(src[k + 7], b + s.bo[i], C, st);
+    pack_planes(b, s.wqkv[i], 3 * C * C, st);
+    pack_planes(b, s.wo[i], C * C, st);
     k += 8;
     if (sd.window >= 0) {
       launch_copy(src[k], b + s.ek[i], (2 * sd.window + 1) * dk, st);
@@ -616,6 +674,8 @@ int pack_stack(const float* const* src, int& k, float* b, const StackBlob& s, co
     launch_copy(src[k + 5], b + s.c2[i], C, st);
     launch_copy(src[k + 6], b + s.g2[i], C, st);
     launch_copy(src[k + 7], b + s.b2[i], C, st);
+    pack_planes(b, s.w1[i], F * sd.kernel * C, st);
+    pack_planes(b, s.w2[i], C * sd.kernel * F, st);
     k += 8;
   }
   return TTSDEC_OK;
@@ -676,21 +736,26 @@ int ttsvits_pack_weights(ttsvits_handle* h, const float* const* src, int n_src, 
   pack_stack(src, k, b, L.enc, enc_dims(d), st);
   launch_copy(src[k++], b + L.proj_w, 2 * I * H, st);
   launch_copy(src[k++], b + L.proj_b, 2 * I, st);
+  pack_planes(b, L.proj_w, 2 * I * H, st);
   for (int f = 0; f < d.n_flows; ++f) {
     const FlowBlob& fb = L.flow[f];
     pack_stack(src, k, b, fb.tf, tf_dims(d), st);
     launch_copy(src[k++], b + fb.pre_w, Fh * half, st);
     launch_copy(src[k++], b + fb.pre_b, Fh, st);
+    pack_planes(b, fb.pre_w, Fh * half, st);
     for (int j = 0; j < d.flow_wn_layers; ++j) {
       const size_t cr = j < d.flow_wn_layers - 1 ? 2 * Fh : Fh;
       if (src[k]) launch_conv_transpose(src[k], b + fb.in_w[j], (int)(2 * Fh), (int)Fh, d.flow_kernel, st);
       launch_copy(src[k + 1], b + fb.in_b[j], 2 * Fh, st);
       launch_copy(src[k + 2], b + fb.rs_w[j], cr * Fh, st);
       launch_copy(src[k + 3], b + fb.rs_b[j], cr, st);
+      pack_planes(b, fb.in_w[j], 2 * Fh * d.flow_kernel * Fh, st);
+      pack_planes(b, fb.rs_w[j], cr * Fh, st);
       k += 4;
     }
     launch_copy(src[k++], b + fb.post_w, half * Fh, st);
     launch_copy(src[k++], b + fb.post_b, half, st);
+    pack_planes(b, fb.post_w, half * Fh, st);
   }
   const int rc = vits_fail(h, "pack_weights");
   if (rc == TTSDEC_OK) h->blob = b;
@@ -730,7 +795,7 @@ int ttsvits_text_encoder(ttsvits_handle* h, const int64_t* ids, const int32_t* l
   int rc = run_stack(h, L.enc, sd, sw, mask, B, T, st);
   if (rc != TTSDEC_OK) return rc;
   // models.py:377-379: stats = proj(x) * x_mask; m, logs = split(stats)
-  gemm_generic(sw.xm, H, H, h->blob + L.proj_w, h->blob + L.proj_b, M, 2 * I, stats, 2 * I, 0, mask, nullptr, 1, T, st);
+  gemm_generic(sw.cx, sw.xm, H, H, h->blob + L.proj_w, (size_t)2 * I * H, h->blob + L.proj_b, M, 2 * I, stats, 2 * I, 0, mask, nullptr, 1, T, st);
   if (hipMemcpyAsync(x, sw.xm, (size_t)M * H * sizeof(float), hipMemcpyDeviceToDevice, st) != hipSuccess) return vits_fail(h, "copy x");
   if (hipMemcpy2DAsync(m, (size_t)I * sizeof(float), stats, (size_t)2 * I * sizeof(float), (size_t)I * sizeof(float), M,
                        hipMemcpyDeviceToDevice, st) != hipSuccess)
@@ -745,7 +810,7 @@ size_t ttsvits_flow_workspace_bytes(const ttsvits_handle* h, int B, int T) {
   if (!h || B <= 0 || T <= 0) return 0;
   const size_t M = (size_t)B * T, I = h->d.inter_channels, Fh = h->d.flow_hidden;
   const size_t fl = up(M, kAlign) + 2 * up(M * I, kAlign) + up(M * (I / 2), kAlign) + 2 * up(M * Fh, kAlign) + up(M * Fh, kAlign) +
-                    2 * up(M * 2 * Fh, kAlign);
+                    2 * up(M * 2 * Fh, kAlign) + up(M * (Fh > I / 2 ? Fh : I / 2), kAlign);
   return (stack_ws_floats(tf_dims(h->d), M) + fl) * sizeof(float);
 }
 
@@ -772,6 +837,9 @@ int ttsvits_flow_reverse(ttsvits_handle* h, const float* z, const int32_t* lengt
   float* acts = take((size_t)M * Fh);
   float* xin = take((size_t)M * 2 * Fh);
   float* rs = take((size_t)M * 2 * Fh);
+  GemmCtx fcx;
+  fcx.planes = reinterpret_cast<f16*>(take((size_t)M * (Fh > half ? Fh : half)));
+  fcx.split = true;
   hipLaunchKernelGGL(frame_mask_kernel, grid1(M), dim3(256), 0, st, lengths, T, mask, M);
   const float* cur = z;
   for (int f = d.n_flows - 1; f >= 0; --f) {  // models.py:807-809: reversed(flows) = Flip, layer_f, ...
@@ -782,18 +850,18 @@ int ttsvits_flow_reverse(ttsvits_handle* h, const float* z, const int32_t* lengt
     if (rc != TTSDEC_OK) return rc;
     hipLaunchKernelGGL(add_x0_kernel, grid1((size_t)M * half), dim3(256), 0, st, sw.xm, xb, M, I);
     // h = pre(x0_) * mask                                                           :510
-    gemm_generic(sw.xm, half, half, blob + fb.pre_w, blob + fb.pre_b, M, Fh, hx, Fh, 0, mask, nullptr, 1, T, st);
+    gemm_generic(fcx, sw.xm, half, half, blob + fb.pre_w, (size_t)Fh * half, blob + fb.pre_b, M, Fh, hx, Fh, 0, mask, nullptr, 1, T, st);
     // h = WN(h, mask)                                                               :511, modules.py:185-210
     for (int j = 0; j < d.flow_wn_layers; ++j) {
       const bool last = j == d.flow_wn_layers - 1;
-      gemm_generic(hx, Fh, Fh, blob + fb.in_w[j], blob + fb.in_b[j], M, 2 * Fh, xin, 2 * Fh, 0, nullptr, nullptr, d.flow_kernel, T, st);
+      gemm_generic(fcx, hx, Fh, Fh, blob + fb.in_w[j], (size_t)2 * Fh * d.flow_kernel * Fh, blob + fb.in_b[j], M, 2 * Fh, xin, 2 * Fh, 0, nullptr, nullptr, d.flow_kernel, T, st);
       hipLaunchKernelGGL(wn_gate_kernel, grid1((size_t)M * Fh), dim3(256), 0, st, xin, acts, M, Fh);
       const int cr = last ? Fh : 2 * Fh;
-      gemm_generic(acts, Fh, Fh, blob + fb.rs_w[j], blob + fb.rs_b[j], M, cr, rs, cr, 0, nullptr, nullptr, 1, T, st);
+      gemm_generic(fcx, acts, Fh, Fh, blob + fb.rs_w[j], (size_t)cr * Fh, blob + fb.rs_b[j], M, cr, rs, cr, 0, nullptr, nullptr, 1, T, st);
       hipLaunchKernelGGL(wn_update_kernel, grid1((size_t)M * Fh), dim3(256), 0, st, hx, ho, rs, mask, M, Fh, last ? 1 : 0, j == 0 ? 1 : 0);
     }
     // m = post(h) * mask ; x1 = (x1 - m) * mask                                     :517, 529
-    gemm_generic(ho, Fh, Fh, blob + fb.post_w, blob + fb.post_b, M, half, mm, half, 0, mask, nullptr, 1, T, st);
+    gemm_generic(fcx, ho, Fh, Fh, blob + fb.post_w, (size_t)half * Fh, blob + fb.post_b, M, half, mm, half, 0, mask, nullptr, 1, T, st);
     hipLaunchKernelGGL(couple_kernel, grid1((size_t)M * half), dim3(256), 0, st, xb, mm, mask, M, I);
     float* t = xa; xa = xb; xb = t;  // the coupled tensor becomes the next layer's input
     cur = xa;
