@@ -248,7 +248,7 @@ int ttsdec_profile_step(ttsdec_handle* h, const float* memory, int B, int L, int
 /* ---------------------------------------------------------------------------------------
  * Text encoder: Encoder2.forward in eval mode, tacotron/encoder.py:27-82
  * with the packed bidirectional LSTM of tacotron/modules/rnn.py:112-127.  Produces the `memory`
- * the decoder consumes.  Runs once per batch; exact fp32.
+ * the decoder consumes.  Runs once per batch; split-fp16 GEMMs for the convs and the input projection (fp32-class accuracy), exact fp32 recurrence.
  * ------------------------------------------------------------------------------------- */
 typedef struct ttsenc_dims {
   int32_t alphabet_size; /* 1 + len(text.alphabet) (+ phonemes), tacotron.py:189-191 */

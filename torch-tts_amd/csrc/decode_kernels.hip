@@ -307,7 +307,7 @@ struct LoaderWLstm {
 };
 
 template <class Cfg>
-__global__ __launch_bounds__(kGemmThreads) void lstm_kernel(LstmArgs g) {
+__device__ __forceinline__ void lstm_body(LstmArgs g) {
   const bool live = g.ctrl == nullptr || step_now(g.ctrl, g.slot).live;
   __shared__ __attribute__((aligned(16))) float smem[Cfg::kLdsFloats];
   constexpr int BM = Cfg::BM, BN = Cfg::BN, LDO = Cfg::LDO, BU = BN / 4, EB = Cfg::EB;
@@ -396,6 +396,42 @@ __global__ __launch_bounds__(kGemmThreads) void lstm_kernel(LstmArgs g) {
     if (g.h_out_h != nullptr) split_f16(h, g.h_out_h[idx], g.h_out_l[idx]);
     if (g.seq_out != nullptr) g.seq_out[((size_t)m * g.seq_Lout + seq_pos) * g.seq_out_ld + g.seq_out_off + unit] = h;
     g.c[idx] = add_rn(mul_rn(g.pz, c_prev), mul_rn(q, c_new));
+  }
+}
+
+template <class Cfg>
+__global__ __launch_bounds__(kGemmThreads) void lstm_kernel(LstmArgs g) {
+  lstm_body<Cfg>(g);
+}
+// two independent cells in one launch (blockIdx.z picks one): the two directions of a BiLSTM step
+struct LstmPair {
+  LstmArgs d[2];
+};
+template <class Cfg>
+__global__ __launch_bounds__(kGemmThreads) void lstm_pair_kernel(LstmPair p) {
+  lstm_body<Cfg>(blockIdx.z ? p.d[1] : p.d[0]);
+}
+
+void launch_lstm_pair(const LstmArgs& a0, const LstmArgs& a1, hipStream_t st) {
+  // same shape, exact fp32 (Encoder2's recurrence); anything else goes out as two launches
+  if (a0.M <= 0) return;
+  if (a0.prec != 0 || a1.prec != 0 || a0.M != a1.M || a0.H != a1.H || a0.K != a1.K) {
+    launch_lstm(a0, st);
+    launch_lstm(a1, st);
+    return;
+  }
+  LstmPair p;
+  p.d[0] = a0;
+  p.d[1] = a1;
+  if (a0.M >= 192) {
+    using Cfg = TileCfg<2, 2, 1, 6>;
+    hipLaunchKernelGGL((lstm_pair_kernel<Cfg>), dim3((a0.H + 15) / 16, (a0.M + 63) / 64, 2), dim3(kGemmThreads), 0, st, p);
+  } else if (a0.M >= 96) {
+    using Cfg = TileCfg<2, 1, 2, 4>;
+    hipLaunchKernelGGL((lstm_pair_kernel<Cfg>), dim3((a0.H + 7) / 8, (a0.M + 63) / 64, 2), dim3(kGemmThreads), 0, st, p);
+  } else {
+    using Cfg = TileCfg<1, 1, 4, 4>;
+    hipLaunchKernelGGL((lstm_pair_kernel<Cfg>), dim3((a0.H + 7) / 8, (a0.M + 31) / 32, 2), dim3(kGemmThreads), 0, st, p);
   }
 }
 

@@ -4,7 +4,7 @@
 //   embedding gather -> 3 x implicit-GEMM conv (k=5) + BN + ISRLU -> cat[conv, emb]
 //   -> one GEMM for the input projections of both LSTM directions over all time steps
 //   -> L sequential steps of the LSTM kernel in packed-sequence mode (forward and reverse).
-// Exact fp32 throughout.
+// Convs and the input projection: split-fp16 GEMMs (fp32-class accuracy); the recurrence: exact fp32.
 #include <string.h>
 
 #include <new>
@@ -22,7 +22,7 @@ struct EncBlob {  // offsets in floats
   size_t emb, conv_w[3], alpha[3], beta[3], w_ih, w_hh[2], h0, c0, total;
 };
 struct EncWs {  // offsets in bytes
-  size_t x, act[2], cat, gx, h[2][2], c[2], total;
+  size_t x, act[2], cat, gx, h[2][2], c[2], planes, total;
 };
 }  // namespace
 
@@ -41,8 +41,9 @@ EncBlob make_layout(const ttsenc_dims& d) {
   auto take = [&](size_t n) { const size_t o = off; off = up(off + n, kAlign); return o; };
   const size_t E = d.d_emb, H = d.d_out / 2, k = d.conv_kernel;
   L.emb = take((size_t)d.alphabet_size * E);
-  for (int i = 0; i < 3; ++i) { L.conv_w[i] = take(E * k * E); L.alpha[i] = take(E); L.beta[i] = take(E); }
-  L.w_ih = take(8 * H * 2 * E);  // [fwd i,f,g,o ; rev i,f,g,o] x [conv | emb]
+  // (GEMM weights of n elements take 2n floats: fp32 | fp16 hi plane | fp16 lo plane)
+  for (int i = 0; i < 3; ++i) { L.conv_w[i] = take(2 * E * k * E); L.alpha[i] = take(E); L.beta[i] = take(E); }
+  L.w_ih = take(2 * 8 * H * 2 * E);  // [fwd i,f,g,o ; rev i,f,g,o] x [conv | emb]
   L.w_hh[0] = take(4 * H * H);
   L.w_hh[1] = take(4 * H * H);
   L.h0 = take(2 * H);
@@ -65,6 +66,7 @@ EncWs make_ws(const ttsenc_dims& d, int B, int Lm) {
     W.h[dir][1] = take((size_t)B * H);
     W.c[dir] = take((size_t)B * H);
   }
+  W.planes = take(M * 2 * E);  // hi + lo fp16 planes of one GEMM's A operand
   W.total = off;
   return W;
 }
@@ -130,6 +132,15 @@ int ttsenc_pack_weights(ttsenc_handle* h, const float* const* src, int n_src, vo
   // both directions' input weights stacked on the output axis: one GEMM gives every gate pre-activation
   launch_copy(src[TTSENC_W_IH_FWD], b + L.w_ih, 4 * H * 2 * E, st);
   launch_copy(src[TTSENC_W_IH_REV], b + L.w_ih + 4 * H * 2 * E, 4 * H * 2 * E, st);
+  {
+    // split-fp16 planes of the conv and input-projection weights (used when d_emb is a multiple of 8)
+    auto planes = [&](size_t off, size_t n) {
+      f16* hi = reinterpret_cast<f16*>(b + off + n);
+      launch_split(b + off, hi, hi + n, n, st);
+    };
+    for (int i = 0; i < 3; ++i) planes(L.conv_w[i], E * d.conv_kernel * E);
+    planes(L.w_ih, 8 * H * 2 * E);
+  }
   launch_copy(src[TTSENC_W_HH_FWD], b + L.w_hh[0], 4 * H * H, st);
   launch_copy(src[TTSENC_W_HH_REV], b + L.w_hh[1], 4 * H * H, st);
   launch_copy(src[TTSENC_W_H0], b + L.h0, 2 * H, st);
@@ -164,6 +175,10 @@ int ttsenc_forward(ttsenc_handle* h, const int64_t* ids, const int32_t* lengths,
   // encoder.py:69: embedding (row 0 of the table is the zero padding vector); also the right half of the cat
   launch_embed(reinterpret_cast<const long long*>(ids), blob + bl.emb, M, E, x, E, cat + E, 2 * E, st);
   // encoder.py:70: three conv blocks over the padded sequence; the last writes the left half of the cat
+  // The convs and the input projection run in the GEMM core's split-fp16 mode (fp32-class accuracy,
+  // gemm_tile.h): one elementwise pass makes the hi / lo planes of each A operand.
+  const bool split = !(E & 7);
+  f16* ph = reinterpret_cast<f16*>(ws + W.planes);
   const float* in = x;
   for (int i = 0; i < 3; ++i) {
     GemmArgs g;
@@ -171,6 +186,14 @@ int ttsenc_forward(ttsenc_handle* h, const int64_t* ids, const int32_t* lengths,
     g.a = make_seg1(in, E, E); g.a_lo = g.a;
     g.T = L; g.Cin = E; g.taps = d.conv_kernel;
     g.W = g.W_lo = blob + bl.conv_w[i]; g.ldw = d.conv_kernel * E; g.K = d.conv_kernel * E;
+    if (split) {
+      const size_t n = (size_t)M * E, nw = (size_t)E * d.conv_kernel * E;
+      launch_split(in, ph, ph + n, n, st);
+      g.a = make_seg1(ph, E, E); g.a_lo = make_seg1(ph + n, E, E);
+      g.prec = PREC_F16S;
+      g.W = reinterpret_cast<const f16*>(blob + bl.conv_w[i] + nw);
+      g.W_lo = reinterpret_cast<const f16*>(blob + bl.conv_w[i] + nw) + nw;
+    }
     g.M = M; g.N = E;
     g.alpha = blob + bl.alpha[i]; g.beta = blob + bl.beta[i];
     if (i < 2) { g.out = F(W.act[i]); g.ldo = E; in = g.out; }
@@ -183,7 +206,17 @@ int ttsenc_forward(ttsenc_handle* h, const int64_t* ids, const int32_t* lengths,
     memset(&g, 0, sizeof(g));
     g.a = make_seg1(cat, 2 * E, 2 * E); g.a_lo = g.a;
     g.W = g.W_lo = blob + bl.w_ih; g.ldw = 2 * E; g.K = 2 * E; g.M = M; g.N = 8 * H; g.out = gx; g.ldo = 8 * H;
-    launch_gemm(g, A_PLAIN, EPI_PLAIN, st);
+    if (split) {
+      const size_t n = (size_t)M * 2 * E, nw = (size_t)8 * H * 2 * E;
+      launch_split(cat, ph, ph + n, n, st);
+      g.a = make_seg1(ph, 2 * E, 2 * E); g.a_lo = make_seg1(ph + n, 2 * E, 2 * E);
+      g.prec = PREC_F16S;
+      g.W = reinterpret_cast<const f16*>(blob + bl.w_ih + nw);
+      g.W_lo = reinterpret_cast<const f16*>(blob + bl.w_ih + nw) + nw;
+      launch_gemm(g, A_PLAIN, EPI_GENERIC, st);  // (the precision-aware plain epilogue: no bias / mask / residual here)
+    } else {
+      launch_gemm(g, A_PLAIN, EPI_PLAIN, st);
+    }
   }
   // initial state (rnn.py:117-118: rnn_h0 / rnn_c0 chunked over the two directions), zero-padded output
   for (int dir = 0; dir < 2; ++dir) {
@@ -195,8 +228,9 @@ int ttsenc_forward(ttsenc_handle* h, const int64_t* ids, const int32_t* lengths,
   // walks each utterance from its own last token (packed-sequence semantics, rnn.py:113-126)
   for (int t = 0; t < L_out; ++t) {
     const int p = t & 1;
+    LstmArgs dirs[2];
     for (int dir = 0; dir < 2; ++dir) {
-      LstmArgs a;
+      LstmArgs& a = dirs[dir];
       memset(&a, 0, sizeof(a));
       a.a = make_seg1(F(W.h[dir][p]), H, H); a.a_lo = a.a;
       a.w = make_seg1(blob + bl.w_hh[dir], H, H); a.w_lo = a.w;
@@ -205,8 +239,8 @@ int ttsenc_forward(ttsenc_handle* h, const int64_t* ids, const int32_t* lengths,
       a.seq_lens = lengths; a.seq_t = t; a.seq_L = L; a.seq_Lout = L_out; a.seq_reverse = dir;
       a.gx = gx; a.gx_ld = 8 * H; a.gx_off = dir * 4 * H;
       a.seq_out = memory; a.seq_out_ld = 2 * H; a.seq_out_off = dir * H;
-      launch_lstm(a, st);
     }
+    launch_lstm_pair(dirs[0], dirs[1], st);  // both directions of step t in one launch
   }
   return enc_fail(h, "encoder forward");
 }

@@ -105,6 +105,7 @@ struct LstmArgs {
   int dbg;  // measurement ablations (ttsdec_profile_step only): 1 = every load reads the zero block
 };
 void launch_lstm(const LstmArgs& a, hipStream_t st);
+void launch_lstm_pair(const LstmArgs& a0, const LstmArgs& a1, hipStream_t st);  // two same-shape fp32 cells, one launch
 
 // ---- stepwise monotonic attention + context ----
 struct AttnArgs {
