@@ -47,7 +47,7 @@ constexpr int kGraphSlots = 30;  // decode steps per captured graph (even: buffe
 // Split-K factors of the two small GEMMs of a step (their consumers add the slabs in order):
 // at B=256 the query projection then launches 256 workgroups instead of 128 and the mel/stop
 // projection 96 instead of 24, each with a proportionally shorter K loop.
-constexpr int kQuerySplit = 2;
+constexpr int kQuerySplit = 4;  // (upper bound: 2 slices for K = 1024, 4 for the Taco2 cell's K = 2048)
 constexpr int kProjSplit = 4;
 
 struct ttsdec_handle {
@@ -82,10 +82,14 @@ inline int proj_ldp(const ttsdec_dims& d) { return (proj_n(d) + 3) & ~3; }
 // The fused frame kernel (frame_kernel.hip) covers the shipped PreNet shapes; other dims keep the
 // three-launch form (proj with its own epilogue, prenet0, prenet1).
 inline bool use_frame(const ttsdec_dims& d) { return frame_supported(d.d_mel, d.r, pre_hidden(d), d.d_pre); }
+inline int split_of(int K, int want);
+inline int query_split(const ttsdec_dims& d);
 inline int split_of(int K, int want) {  // split-K factor: slices must be whole 128-element K tiles
   while (want > 1 && (K % want || (K / want) % 128)) --want;
   return want;
 }
+
+inline int query_split(const ttsdec_dims& d) { return split_of(query_k(d), query_k(d) >= 2048 ? kQuerySplit : 2); }
 
 BlobLayout make_blob_layout(const ttsdec_dims& d) {
   BlobLayout L;
@@ -389,7 +393,7 @@ void launch_node(const ttsdec_handle* h, const StepBufs& sb, const StepIo& io, N
       if (is_taco2(d)) g.a = make_seg2(sb.h_att[1 - p], Ha, Ha, sb.h_dec[1 - p], Hd, Hd);
       else g.a = make_seg1(sb.h_att[1 - p], Ha, Ha);
       g.W = blob + bl.wq; g.ldw = query_ld(d); g.K = query_k(d); g.M = B; g.N = D; g.out = sb.q; g.ldo = D;
-      g.ksplit = split_of(g.K, kQuerySplit); g.kchunk = g.K / g.ksplit; g.split_stride = (size_t)B * D;
+      g.ksplit = query_split(d); g.kchunk = g.K / g.ksplit; g.split_stride = (size_t)B * D;
       g.ctrl = ctrl; g.slot = io.slot; g.t = io.t;
       launch_gemm(g, A_PLAIN, EPI_PLAIN, st);
       break;
@@ -398,7 +402,7 @@ void launch_node(const ttsdec_handle* h, const StepBufs& sb, const StepIo& io, N
       AttnArgs a;
       memset(&a, 0, sizeof(a));
       if (prec) { a.ctx_h = sb.ctx_h; a.ctx_l = sb.ctx_l; }
-      a.memory = io.memory; a.q = sb.q; a.q_parts = split_of(query_k(d), kQuerySplit); a.q_stride = (size_t)B * D;
+      a.memory = io.memory; a.q = sb.q; a.q_parts = query_split(d); a.q_stride = (size_t)B * D;
       a.w_prev = sb.w[p]; a.w_new = sb.w[1 - p]; a.w_out = io.w; a.ctx = sb.ctx;
       a.B = B; a.L = io.L; a.D = D; a.t_rel = io.t_rel; a.t_stride = io.t_stride; a.ctrl = ctrl; a.slot = io.slot;
       launch_attn(a, st);

@@ -95,16 +95,32 @@ __global__ __launch_bounds__(kFrameThreads) void frame_kernel(FrameArgs g) {
   // thread -> (row = tid / 16, columns (tid % 16) + 16 i)
   const int nm = g.r * g.d_mel, NJ = nm + g.r;
   const int frow = tid >> 4, fm = m0 + frow;
+  // (every load below is unconditional - out-of-range lanes read element 0 and slabs past n_parts are
+  // discarded after the fact - so the compiler issues them all back to back instead of one dependent
+  // load per branch)
+  constexpr int kMaxParts = 4;
   float pv[kFrameMaxNI];
+  if (g.parts != nullptr) {
+    float pz[kFrameMaxNI][kMaxParts], pbias[kFrameMaxNI];
 #pragma unroll
-  for (int i = 0; i < kFrameMaxNI; ++i) {
-    const int n = (tid & 15) + 16 * i;
-    pv[i] = 0.f;
-    if (g.parts != nullptr && fm < g.M && n < NJ) {
-      float v = g.parts[(size_t)fm * g.ldp + n];
-      for (int z = 1; z < g.n_parts; ++z) v = add_rn(v, g.parts[z * g.part_stride + (size_t)fm * g.ldp + n]);
-      pv[i] = add_rn(v, g.proj_bias[n]);
+    for (int i = 0; i < kFrameMaxNI; ++i) {
+      const int n = (tid & 15) + 16 * i;
+      const bool ok = fm < g.M && n < NJ;
+      const size_t idx = ok ? (size_t)fm * g.ldp + n : 0;
+#pragma unroll
+      for (int z = 0; z < kMaxParts; ++z) pz[i][z] = g.parts[z * g.part_stride + idx];
+      pbias[i] = g.proj_bias[ok ? n : 0];
     }
+#pragma unroll
+    for (int i = 0; i < kFrameMaxNI; ++i) {
+      float v = pz[i][0];
+#pragma unroll
+      for (int z = 1; z < kMaxParts; ++z) v = add_rn(v, z < g.n_parts ? pz[i][z] : 0.f);
+      pv[i] = add_rn(v, pbias[i]);
+    }
+  } else {
+#pragma unroll
+    for (int i = 0; i < kFrameMaxNI; ++i) pv[i] = 0.f;
   }
 
   // ---- "now" ----
