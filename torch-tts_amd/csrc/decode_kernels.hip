@@ -97,8 +97,22 @@ __global__ __launch_bounds__(kGemmThreads) void gemm_rows_kernel(GemmArgs g) {
   __shared__ __attribute__((aligned(16))) float smem[Cfg::kLdsFloats];
   constexpr int BM = Cfg::BM, BN = Cfg::BN, LDO = Cfg::LDO;
   constexpr int EPT = BM * BN / kGemmThreads;  // output elements per thread
-  const int m0 = blockIdx.y * BM;
-  const int n0 = blockIdx.x * BN;
+  // XCD-aware tile order for the large GEMMs: workgroups are dealt round-robin over the 8 XCDs by
+  // linear id, so with the natural order the column tiles that share one row tile's A operand land on
+  // different XCDs and each L2 fetches that A tile again.  Remap so that all column tiles of a row tile
+  // run on the same XCD: id -> (xcd = id % 8, slot = id / 8) -> row tile (slot / nx) * 8 + xcd.
+  int bx = blockIdx.x, by = blockIdx.y;
+  if (AK == A_CONV || Cfg::kBig) {
+    const int nx = gridDim.x, ny = gridDim.y;
+    const int id = by * nx + bx, full = (ny / 8) * 8;
+    if (id < full * nx) {
+      const int xcd = id & 7, slot = id >> 3;
+      by = (slot / nx) * 8 + xcd;
+      bx = slot % nx;
+    }
+  }
+  const int m0 = by * BM;
+  const int n0 = bx * BN;
 
   // Epilogue operands are requested BEFORE the K loop (their latency hides under it) - for the
   // small tiles, where a thread owns <= 8 outputs; the 128x128 tiles fetch them in the epilogue.
