@@ -743,3 +743,37 @@ def test_frame_kernel_stop_teacher_and_chunks(H, prec, r, d_pre):
     H.assert_close(y.cpu(), oy, RTOL, ATOL, "y chunks")
     H.assert_close(s.cpu(), os_, RTOL, ATOL, "s chunks")
     H.assert_close(w.cpu(), ow, RTOL, ATOL, "w chunks")
+
+
+@pytest.mark.parametrize("prec", ["f32", "split_f16"])
+def test_frame_kernel_cell_step_at_ljspeech_prenet_dims(H, prec):
+    """Taco2ProdDecoderCell.forward (ttsdec_cell_step) where the PreNet runs in the frame kernel
+    (input frame handed in directly, nothing to finish) - against the oracle's single step."""
+    dims = O.DecoderDims(d_mel=80, r=1, d_pre=256, d_ctx=64, h_att=128, h_dec=192)
+    wts = O.random_decoder_weights(dims, seed=31, nonzero_init_state=True)
+    dec = H.make_decoder(dims, wts)
+    dec.precision = prec
+    cell = dec.decoder_cell
+    cell.dropout_source = "reference_rng"
+    B, L = 35, 19
+    mem = O.synthetic_memory(B, L, dims.d_ctx, lengths=[19] * 30 + [1, 4, 9, 13, 19], seed=8)
+    g = torch.Generator().manual_seed(17)
+    x = torch.randn(B, 1, dims.d_mel, generator=g)
+    w = torch.rand(B, L, generator=g)
+    w = w / w.sum(1, keepdim=True)
+    ctx = torch.randn(B, dims.d_ctx, generator=g) * 0.3
+    ha, ca = torch.randn(B, dims.h_att, generator=g) * 0.3, torch.randn(B, dims.h_att, generator=g) * 0.3
+    hd, cd = torch.randn(B, dims.h_dec, generator=g) * 0.3, torch.randn(B, dims.h_dec, generator=g) * 0.3
+    torch.manual_seed(5)
+    m0, m1 = O.draw_prenet_masks(B, dims.d_pre, dims.d_pre)
+    ox, (ow, octx, (oha, oca), (ohd, ocd)) = O.decoder_cell_step(x[:, -1], (w, ctx, (ha, ca), (hd, cd)), mem, wts, dims, torch.stack([m0, m1]))
+    dev = "cuda:0"
+    with torch.no_grad():
+        torch.manual_seed(5)
+        xd, cx, (w2, ctx2, ((ha2, ca2), (hd2, cd2))) = cell(
+            x.to(dev), (w.to(dev), ctx.to(dev), ((ha.to(dev), ca.to(dev)), (hd.to(dev), cd.to(dev)))), mem.to(dev), None
+        )
+    H.assert_close(xd.cpu(), ox, RTOL, ATOL, "x_dec")
+    H.assert_close(w2.cpu(), ow, RTOL, ATOL, "w")
+    H.assert_close(ha2.cpu(), oha, RTOL, ATOL, "h_att")
+    H.assert_close(cd2.cpu(), ocd, RTOL, ATOL, "c_dec")
