@@ -1,8 +1,12 @@
 // Decode-step kernels for gfx950 (MI355X).  One decode step of the reference
-// (tacotron/decoder.py:47-58 around tacotron/decoder_cell.py:180-195) is the launch
-// sequence  prenet0 -> prenet1 -> lstm(att) -> query -> attention+context -> lstm(dec) -> proj.
+// (tacotron/decoder.py:47-58 around tacotron/decoder_cell.py:180-195) is the launch sequence
+//   frame (frame_kernel.hip: finish proj(t-1), PreNet) -> lstm(att) -> query -> attention+context
+//   -> lstm(dec) -> proj                         [dims the frame kernel does not cover: prenet0 ->
+//   prenet1 -> ... -> proj with its own epilogue]
 // Kernel boundaries are the all-to-all seams of the step (every output row needs a whole
-// hidden vector produced by all workgroups of the previous phase).
+// hidden vector produced by all workgroups of the previous phase).  This file holds the row
+// GEMM (PreNet / query / projection / Postnet / Encoder2 / VITS2 GEMMs), the LSTM cell, the
+// attention kernel and the small bookkeeping / packing kernels.
 #include "gemm_tile.h"
 #include "kernels.h"
 
