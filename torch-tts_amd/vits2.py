@@ -114,10 +114,15 @@ class VitsEngine:
     def num_weight_tensors(self) -> int:
         return int(self._lib.ttsvits_num_weight_tensors(self._h))
 
-    def ensure_packed(self, tensors: List[Optional[torch.Tensor]]) -> None:
-        fp = weights_fingerprint([t for t in tensors if t is not None])
+    def ensure_packed(self, tensors, key_tensors=None) -> None:
+        """tensors: the list the C ABI expects, or a callable producing it (called only when a repack is
+        needed); key_tensors: the parameters whose identity / version decide that (default: the list itself -
+        derived tensors such as weight-normed weights are new objects on every call and must not be the key)."""
+        fp = weights_fingerprint([t for t in (key_tensors if key_tensors is not None else tensors) if t is not None])
         if self.blob is not None and fp == self._fingerprint:
             return
+        if callable(tensors):
+            tensors = tensors()
         n = len(tensors)
         assert n == self.num_weight_tensors(), (n, self.num_weight_tensors())
         arr = (C.c_void_p * n)()
@@ -305,10 +310,14 @@ class ResidualCouplingTransformersBlock(nn.Module):
         if torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters()):
             raise NotImplementedError("the HIP flow is inference-only: call under torch.no_grad()")
         eng = self._engines.get(self._dims(), x.device)
-        tensors: List[Optional[torch.Tensor]] = [None] * 3  # emb, proj.weight, proj.bias of the (absent) text encoder
-        for i in range(self.n_flows):
-            tensors += self.flows[2 * i].weight_tensors()
-        eng.ensure_packed(tensors)
+
+        def tensors() -> List[Optional[torch.Tensor]]:
+            ts: List[Optional[torch.Tensor]] = [None] * 3  # emb, proj.weight, proj.bias of the (absent) text encoder
+            for i in range(self.n_flows):
+                ts += self.flows[2 * i].weight_tensors()  # (materialises the weight-normed conv weights)
+            return ts
+
+        eng.ensure_packed(tensors, key_tensors=list(self.parameters()))
         lengths = x_mask[:, 0, :].sum(dim=1).round().to(torch.int32)  # sequence_mask is a prefix mask
         out = eng.flow_reverse(x.transpose(1, 2), lengths)
         return out.transpose(1, 2)
