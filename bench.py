@@ -366,7 +366,8 @@ def main():
         "higher_is_better": True,
         "scaling": "weak",
         "vs_baseline": None,
-        "dtype": "f32" if args.precision == "f32" else "f32 via split-fp16 (hi+lo fp16 planes, 3 f16 MFMA products, fp32 accumulate) for the LSTM GEMMs; f32 elsewhere",
+        "dtype": ("f32" if args.precision == "f32" else "f32 via split-fp16 (hi+lo fp16 planes, 3 f16 MFMA products, fp32 accumulate) for the LSTM and PreNet GEMMs; f32 elsewhere")
+                 + {"f32": "; Postnet f32", "split_f16": "; Postnet split-fp16", "bf16": "; Postnet bf16"}[args.postnet],
         "data": "synthetic",
         "config": {
             "workload": f"{args.config} dims, batch={B}/GPU (global {Bg}), L={L}, {NF} decode frames + Postnet({args.postnet}); "
