@@ -132,6 +132,16 @@ with torch.no_grad():
     out["unit/enc_nowin_in"] = x0.numpy()
     out["unit/enc_nowin_out"] = layers[0][0](x0 * y_mask, y_mask).numpy()
 
+# sequences shorter than the relative-position window (attentions.py:304-318 slices the tables instead of padding)
+with torch.no_grad():
+    for Ts in (1, 3):
+        ids_s = torch.randint(0, D["n_vocab"], (2, Ts))
+        len_s = torch.tensor([Ts, max(1, Ts - 1)])
+        xs = torch.transpose(emb(ids_s) * math.sqrt(H), 1, -1)
+        ms = torch.unsqueeze(commons.sequence_mask(len_s, Ts), 1).to(xs.dtype)
+        out[f"short{Ts}/ids"] = ids_s.numpy(); out[f"short{Ts}/lengths"] = len_s.numpy()
+        out[f"short{Ts}/x"] = enc(xs * ms, ms).numpy()
+
 np.savez_compressed(os.path.join(HERE, "vits2_small.npz"), **out)
 json.dump({"dims": D, "reference": "kgoba/torch-tts @ 2024_10_08, vits2/{attentions,modules,commons}.py imported on CPU",
            "glue": "TextEncoder.forward and the reverse coupling layer are composed in make_golden_vits2.py from the reference blocks "

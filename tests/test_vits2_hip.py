@@ -114,3 +114,28 @@ def test_vits_modules_refuse_what_is_outside_the_path():
         fl(x, torch.ones(1, 1, 8, device="cuda"), reverse=False)
     with pytest.raises(NotImplementedError):
         T.vits2.ResidualCouplingTransformersBlock(192, 192, 5, 1, 4, use_transformer_flows=False)
+
+
+def test_text_encoder_sequences_shorter_than_the_window(gv):
+    c = gv["c"]
+    te = _text_encoder(gv["d"], gv["wts"])
+    for Ts in (1, 3):
+        with torch.no_grad():
+            x, _, _, _ = te(c[f"short{Ts}/ids"].cuda(), c[f"short{Ts}/lengths"].cuda())
+        _close(x, c[f"short{Ts}/x"], f"x T={Ts}")
+
+
+def test_flow_reverse_long_sequence_uses_the_scalar_attention_fallback():
+    """T = 1300 frames does not fit the matrix-core attention's score tile in LDS: the scalar kernel runs."""
+    d = V.Vits2Dims(n_flows=1)
+    wts = V.random_vits2_weights(d, seed=9)
+    g = torch.Generator().manual_seed(4)
+    B, T = 1, 1300
+    z = torch.randn(B, d.inter_channels, T, generator=g)
+    lens = torch.tensor([T - 37])
+    ymask = V.sequence_mask(lens, T).unsqueeze(1).float()
+    ref = V.flow_reverse(z, ymask, wts, d)
+    fl = _flow({**d.__dict__}, wts)
+    with torch.no_grad():
+        out = fl(z.cuda(), ymask.cuda(), reverse=True)
+    _close(out, ref, "flow out (T=1300)", rtol=2e-4, atol=2e-4)

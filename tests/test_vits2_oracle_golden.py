@@ -70,3 +70,11 @@ def test_random_weights_cover_every_key_the_functions_read():
     z = torch.randn(2, 8, 12)
     out = V.flow_reverse(z, V.sequence_mask(torch.tensor([12, 5]), 12).unsqueeze(1).float(), w, d)
     assert out.shape == z.shape and bool(torch.isfinite(out).all())
+
+
+def test_sequences_shorter_than_the_window(gv):
+    """T < window + 1: the reference slices its relative-position tables (attentions.py:304-318)."""
+    c, d = gv["c"], gv["dims"]
+    for Ts in (1, 3):
+        x, _, _, _ = V.text_encoder(c[f"short{Ts}/ids"], c[f"short{Ts}/lengths"], gv["wts"], d)
+        close(x, c[f"short{Ts}/x"])
