@@ -352,6 +352,12 @@ __global__ __launch_bounds__(kMhaMThreads) void mha_mfma_kernel(MhaArgs g) {
 #pragma unroll
     for (int q = 0; q < DKH / 4; ++q) kb[q] = src[q];
   };
+  float mrow[16];  // frame mask of the 16 query rows this lane's accumulator registers belong to
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    const int i = i0 + (r & 3) + 8 * (r >> 2) + 4 * half;
+    mrow[r] = i < T ? g.mask[rowb + i] : 0.f;
+  }
   auto score_tile = [&](int kt, const f32x4 (&kb)[DKH / 4]) {
     const int j = kt * 32 + l32;
     f32x16 acc = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
@@ -368,8 +374,7 @@ __global__ __launch_bounds__(kMhaMThreads) void mha_mfma_kernel(MhaArgs g) {
         float s = acc[r];
         const int rr = j - i + w;
         if (w >= 0 && rr >= 0 && rr <= 2 * w) s = add_rn(s, R[row * 33 + rr]);
-        const float mi = i < T ? g.mask[rowb + i] : 0.f;
-        if (mi * mj == 0.f) s = -1e4f;
+        if (mrow[r] * mj == 0.f) s = -1e4f;
         S[row * ST + j] = s;
       }
     }
@@ -387,7 +392,9 @@ __global__ __launch_bounds__(kMhaMThreads) void mha_mfma_kernel(MhaArgs g) {
     }
   }
   __syncthreads();
-  // ---- softmax: wave v owns rows 8v .. 8v+7 ----
+  // ---- softmax numerators: wave v owns rows 8v .. 8v+7.  S keeps e = exp(s - max); the division by the
+  // row sum is applied once to the 32 x dk output instead of to the 32 x T scores ----
+  float* rinv = S + kMhaMRows * ST + (w >= 0 ? 32 * 33 : 0);  // [32] 1 / row sum
   for (int rr = 0; rr < 8; ++rr) {
     float* row = S + (wave * 8 + rr) * ST;
     float mx = -3.4e38f;
@@ -396,13 +403,13 @@ __global__ __launch_bounds__(kMhaMThreads) void mha_mfma_kernel(MhaArgs g) {
     for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o));
     float sum = 0.f;
     for (int j = lane; j < T; j += 64) {
-      const float e = expf(row[j] - mx);
+      const float e = __expf(row[j] - mx);
       row[j] = e;
       sum += e;
     }
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) sum += __shfl_xor(sum, o);
-    for (int j = lane; j < T; j += 64) row[j] = div_rn(row[j], sum);
+    if (lane == 0) rinv[wave * 8 + rr] = 1.0f / sum;
   }
   __syncthreads();
   // ---- pass 2: out = P V; wave v takes the key pairs {v, v+4, v+8, ...} ----
@@ -433,8 +440,9 @@ __global__ __launch_bounds__(kMhaMThreads) void mha_mfma_kernel(MhaArgs g) {
         for (int dt = 0; dt < NDT; ++dt) acc[dt] = __builtin_amdgcn_mfma_f32_32x32x2f32(pv[u], vv[u][dt], acc[dt], 0, 0, 0);
     }
   }
-  // relative values need p[i, i + r - w]: read them before S is reused as the reduction buffer
+  // relative values need p[i, i + r - w]: read them (and the row's 1/sum) before S is reused as the reduction buffer
   const int oi = tid >> 3;  // output row of this thread in the final loop (32 rows x 8 threads)
+  const float ri = rinv[oi];
   float prel[32];
 #pragma unroll
   for (int r = 0; r < 32; ++r) {
@@ -465,12 +473,12 @@ __global__ __launch_bounds__(kMhaMThreads) void mha_mfma_kernel(MhaArgs g) {
           if (r < nrel) a = fmaf(prel[r], g.ev[(size_t)r * DK + d], a);
         v = add_rn(v, a);
       }
-      g.out[(rowb + i0 + oi) * C + hd * DK + d] = v;
+      g.out[(rowb + i0 + oi) * C + hd * DK + d] = v * ri;
     }
   }
 }
 size_t mha_mfma_lds_bytes(int T, int dk, int window) {
-  const size_t rel = window >= 0 ? 32 * 33 : 0;
+  const size_t rel = (window >= 0 ? 32 * 33 : 0) + 32;  // relative-key logits, 1 / row sums
   const size_t s = (size_t)kMhaMRows * (T | 1) + rel;
   const size_t red = (size_t)4 * 32 * (dk + 1);
   return (s > red ? s : red) * sizeof(float);
