@@ -199,6 +199,9 @@ def main():
     ap.add_argument("--workload", choices=["tacotron", "vits2"], default="tacotron",
                     help="tacotron = the headline decoder path (default); vits2 = the second hot path of BASELINE.json configs[4] "
                          "(TextEncoder on [B, 120] + reverse flow on [B, 192, 600], ModelConfig defaults; --batch defaults to 64)")
+    ap.add_argument("--dropout", choices=["philox", "masks"], default="philox",
+                    help="PreNet dropout source: philox = drawn on the device (default, SURVEY 8d 'mode 2'); masks = injected keep-masks "
+                         "resident in HBM ('mode 1': what the parity runs use)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-frames", type=int, default=0, help="decode frames for the CPU baseline sample (0 = auto)")
     args = ap.parse_args()
@@ -275,9 +278,17 @@ def main():
     t_out = torch.zeros(2, dtype=torch.int32, device=dev)
     prec = {"f32": _lib.POSTNET_F32, "bf16": _lib.POSTNET_BF16, "split_f16": _lib.POSTNET_SPLIT_F16}[args.postnet]
 
+    dmode, dmasks = _lib.DROPOUT_PHILOX, None
+    if args.dropout == "masks":  # [NS, 2, B, d_pre] uint8 keep-masks (p = 0.5), generated outside the timed region
+        dd = CFG["model"]["decoder"]
+        ph = 128 if dd["type"] == "tacotron2" else dd["dim_pre"]
+        gm = torch.Generator(device=dev).manual_seed(123 + rank)
+        dmasks = torch.randint(0, 2, (NS, B * (ph + dd["dim_pre"])), generator=gm, device=dev, dtype=torch.uint8)
+        dmode = _lib.DROPOUT_MASKS
+
     def one_step():
-        eng.decode(mem, t_begin=0, n_steps=NS, stop_threshold=-2.0, check_stop=True, dropout_mode=_lib.DROPOUT_PHILOX,
-                   masks=None, seed=123, teacher=None, teacher_flags=None, y=y, s=s, w=w, t_out=t_out)
+        eng.decode(mem, t_begin=0, n_steps=NS, stop_threshold=-2.0, check_stop=True, dropout_mode=dmode,
+                   masks=dmasks, seed=123, teacher=None, teacher_flags=None, y=y, s=s, w=w, t_out=t_out)
         return peng.postnet(y, prec)
 
     def fence():
@@ -294,8 +305,8 @@ def main():
     dec_ms = 0.0
     for _ in range(args.steps):
         ev0.record()
-        eng.decode(mem, t_begin=0, n_steps=NS, stop_threshold=-2.0, check_stop=True, dropout_mode=_lib.DROPOUT_PHILOX,
-                   masks=None, seed=123, teacher=None, teacher_flags=None, y=y, s=s, w=w, t_out=t_out)
+        eng.decode(mem, t_begin=0, n_steps=NS, stop_threshold=-2.0, check_stop=True, dropout_mode=dmode,
+                   masks=dmasks, seed=123, teacher=None, teacher_flags=None, y=y, s=s, w=w, t_out=t_out)
         ev1.record()
         y_post = peng.postnet(y, prec)
         ev2.record()
@@ -372,7 +383,7 @@ def main():
         "config": {
             "workload": f"{args.config} dims, batch={B}/GPU (global {Bg}), L={L}, {NF} decode frames + Postnet({args.postnet}); "
                         "BASELINE.json configs[2] per GPU, configs[3] at 8 GPUs",
-            "global_batch": Bg, "mem_len": L, "frames": NF, "dropout": "philox", "parallelism": f"utterance-shard x{world}",
+            "global_batch": Bg, "mem_len": L, "frames": NF, "dropout": args.dropout, "parallelism": f"utterance-shard x{world}",
             "lstm_precision": eng.precision(),
         },
         "rtf": round((elapsed / args.steps) / (NF * FRAME_SEC), 6),
