@@ -428,6 +428,7 @@ void launch_node(const ttsdec_handle* h, const StepBufs& sb, const StepIo& io, N
       if (prec) { a.h_out_h = sb.h_dec_h[1 - p]; a.h_out_l = sb.h_dec_l[1 - p]; }
       a.bsum = blob + bl.dec_b; a.h_prev = sb.h_dec[p]; a.c = sb.c_dec; a.h_out = sb.h_dec[1 - p];
       a.M = B; a.H = Hd; a.K = Ha + D + Hd; a.pz = d.p_zoneout; a.ctrl = ctrl; a.slot = io.slot; a.dbg = io.dbg;
+      a.tag = 1;
       launch_lstm(a, st);
       break;
     }

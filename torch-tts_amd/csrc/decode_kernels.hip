@@ -417,9 +417,16 @@ __device__ __forceinline__ void lstm_body(LstmArgs g) {
   }
 }
 
-template <class Cfg>
+// TAG only names the instantiation (0 = attention LSTM / generic, 1 = decoder LSTM) so that profilers
+// list the two cells of a decode step as separate kernels.
+template <class Cfg, int TAG = 0>
 __global__ __launch_bounds__(kGemmThreads) void lstm_kernel(LstmArgs g) {
   lstm_body<Cfg>(g);
+}
+template <class Cfg>
+static void launch_lstm_tagged(const LstmArgs& a, dim3 grid, hipStream_t st) {
+  if (a.tag == 1) hipLaunchKernelGGL((lstm_kernel<Cfg, 1>), grid, dim3(kGemmThreads), 0, st, a);
+  else hipLaunchKernelGGL((lstm_kernel<Cfg, 0>), grid, dim3(kGemmThreads), 0, st, a);
 }
 // two independent cells in one launch (blockIdx.z picks one): the two directions of a BiLSTM step
 struct LstmPair {
@@ -459,32 +466,32 @@ void launch_lstm(const LstmArgs& a, hipStream_t st) {
     if (a.M >= 192) {
       using Cfg = TileCfg<2, 2, 1, 4, PREC_F16S>;  // 64 rows x 16 units, 32 KiB stages (64 k each); S=5 and nt weight loads measured slower
       dim3 grid((a.H + 15) / 16, (a.M + 63) / 64);
-      hipLaunchKernelGGL((lstm_kernel<Cfg>), grid, dim3(kGemmThreads), 0, st, a);
+      launch_lstm_tagged<Cfg>(a, grid, st);
     } else if (a.M >= 96) {
       using Cfg = TileCfg<2, 1, 2, 3, PREC_F16S>;  // 64 rows x 8 units, 48 KiB stages (128 k each)
       dim3 grid((a.H + 7) / 8, (a.M + 63) / 64);
-      hipLaunchKernelGGL((lstm_kernel<Cfg>), grid, dim3(kGemmThreads), 0, st, a);
+      launch_lstm_tagged<Cfg>(a, grid, st);
     } else {
       // small batches: 32 rows x 8 units on two MFMA waves, so B = 64 still launches 256 workgroups
       // (the kernel is bound by streaming its weight rows, which this halves per workgroup)
       using Cfg = TileCfg<1, 1, 2, 4, PREC_F16S>;  // 32 KiB stages (128 k each)
       dim3 grid((a.H + 7) / 8, (a.M + 31) / 32);
-      hipLaunchKernelGGL((lstm_kernel<Cfg>), grid, dim3(kGemmThreads), 0, st, a);
+      launch_lstm_tagged<Cfg>(a, grid, st);
     }
     return;
   }
   if (a.M >= 192) {
     using Cfg = TileCfg<2, 2, 1, 6>;  // 64 rows x 16 units, 16 KiB stages
     dim3 grid((a.H + 15) / 16, (a.M + 63) / 64);
-    hipLaunchKernelGGL((lstm_kernel<Cfg>), grid, dim3(kGemmThreads), 0, st, a);
+    launch_lstm_tagged<Cfg>(a, grid, st);
   } else if (a.M >= 96) {
     using Cfg = TileCfg<2, 1, 2, 4>;  // 64 rows x 8 units, 24 KiB stages
     dim3 grid((a.H + 7) / 8, (a.M + 63) / 64);
-    hipLaunchKernelGGL((lstm_kernel<Cfg>), grid, dim3(kGemmThreads), 0, st, a);
+    launch_lstm_tagged<Cfg>(a, grid, st);
   } else {
     using Cfg = TileCfg<1, 1, 4, 4>;  // 32 rows x 8 units, 32 KiB stages
     dim3 grid((a.H + 7) / 8, (a.M + 31) / 32);
-    hipLaunchKernelGGL((lstm_kernel<Cfg>), grid, dim3(kGemmThreads), 0, st, a);
+    launch_lstm_tagged<Cfg>(a, grid, st);
   }
 }
 

@@ -103,6 +103,7 @@ struct LstmArgs {
   Ctrl* ctrl;
   int slot;
   int dbg;  // measurement ablations (ttsdec_profile_step only): 1 = every load reads the zero block
+  int tag;  // 1 = the decoder LSTM of a decode step (separate kernel symbol for profilers), else 0
 };
 void launch_lstm(const LstmArgs& a, hipStream_t st);
 void launch_lstm_pair(const LstmArgs& a0, const LstmArgs& a1, hipStream_t st);  // two same-shape fp32 cells, one launch
