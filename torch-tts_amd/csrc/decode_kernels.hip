@@ -246,6 +246,7 @@ __global__ __launch_bounds__(kGemmThreads) void gemm_rows_kernel(GemmArgs g) {
       if (g.row_mask != nullptr) v = mul_rn(v, prm);
       if (g.resid != nullptr) v = add_rn(pr, v);
       g.out[(size_t)m * g.ldo + n] = v;
+      store16(v);
     } else if (EK == EPI_RESIDUAL) {
       // modules.py:184 x + fc_out(...)  /  modules.py:215 x + layer(x)
       v = add_rn(pr, v);

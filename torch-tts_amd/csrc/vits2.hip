@@ -109,14 +109,18 @@ int vits_fail(ttsvits_handle* h, const char* where) {
 // kernels
 // ===========================================================================
 // TextEncoder.forward, models.py:370-376: x = emb(ids) * sqrt(H), masked; also the per-frame mask
+// (every producer below can also emit the split-fp16 planes of its output - hi at p, lo at p + M*C - so
+// the GEMM that consumes it needs no separate conversion pass)
 __global__ void embed_scale_kernel(const long long* ids, const int* lengths, const float* table, int T, int H, float scale, float* x,
-                                   float* mask, int M) {
+                                   f16* xp, float* mask, int M) {
   const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= (size_t)M * H) return;
   const int m = (int)(i / H), c = (int)(i % H);
   const int b = m / T, t = m - b * T;
   const float mk = t < lengths[b] ? 1.0f : 0.0f;
-  x[i] = mul_rn(mul_rn(table[(size_t)ids[m] * H + c], scale), mk);
+  const float v = mul_rn(mul_rn(table[(size_t)ids[m] * H + c], scale), mk);
+  x[i] = v;
+  if (xp) split_f16(v, xp[i], xp[(size_t)M * H + i]);
   if (c == 0) mask[m] = mk;
 }
 __global__ void frame_mask_kernel(const int* lengths, int T, float* mask, int M) {
@@ -127,7 +131,7 @@ __global__ void frame_mask_kernel(const int* lengths, int T, float* mask, int M)
 // modules.LayerNorm (modules.py:24-27) over the channels of one frame; one wave per row.
 // out = LN(in) ; out_m = LN(in) * mask  (either may be nullptr)
 __global__ __launch_bounds__(256) void layernorm_rows_kernel(const float* in, const float* gamma, const float* beta, const float* mask,
-                                                             float* out, float* out_m, int M, int C, float eps) {
+                                                             float* out, float* out_m, f16* out_p, f16* outm_p, int M, int C, float eps) {
   const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
   if (row >= M) return;
   const float* x = in + (size_t)row * C;
@@ -158,8 +162,11 @@ __global__ __launch_bounds__(256) void layernorm_rows_kernel(const float* in, co
     const int c = lane + 64 * j;
     if (c < C) {
       const float y = add_rn(mul_rn(mul_rn(v[j] - mean, rstd), gamma[c]), beta[c]);
-      if (out) out[(size_t)row * C + c] = y;
-      if (out_m) out_m[(size_t)row * C + c] = mul_rn(y, mk);
+      const size_t o = (size_t)row * C + c, n = (size_t)M * C;
+      if (out) out[o] = y;
+      if (out_m) out_m[o] = mul_rn(y, mk);
+      if (out_p) split_f16(y, out_p[o], out_p[n + o]);
+      if (outm_p) split_f16(mul_rn(y, mk), outm_p[o], outm_p[n + o]);
     }
   }
 }
@@ -175,6 +182,8 @@ struct MhaArgs {
   const float* mask;  // [B*T]
   const float *ek, *ev;  // [2w+1, dk] or nullptr
   float* out;            // [B*T, C]
+  f16* out_p;            // optional split-fp16 planes of out (hi, then lo n_out halfs later)
+  size_t n_out;          // B*T*C
   int T, C, dk, window;
   float qscale;  // sqrt(dk): q is DIVIDED by it, as the reference does
 };
@@ -287,7 +296,11 @@ __global__ __launch_bounds__(kMhaThreads) void mha_kernel(MhaArgs g) {
 #pragma unroll
     for (int dd = 0; dd < ND; ++dd) {
       const int d = rj + 16 * dd;
-      if (d < dk) g.out[(rowb + i0 + ri) * C + hd * dk + d] = acc[dd];
+      if (d < dk) {
+        const size_t o = (rowb + i0 + ri) * C + hd * dk + d;
+        g.out[o] = acc[dd];
+        if (g.out_p) split_f16(acc[dd], g.out_p[o], g.out_p[g.n_out + o]);
+      }
     }
   }
 }
@@ -473,7 +486,9 @@ __global__ __launch_bounds__(kMhaMThreads) void mha_mfma_kernel(MhaArgs g) {
           if (r < nrel) a = fmaf(prel[r], g.ev[(size_t)r * DK + d], a);
         v = add_rn(v, a);
       }
-      g.out[(rowb + i0 + oi) * C + hd * DK + d] = v * ri;
+      const size_t o = (rowb + i0 + oi) * C + hd * DK + d;
+      g.out[o] = v * ri;
+      if (g.out_p) split_f16(v * ri, g.out_p[o], g.out_p[g.n_out + o]);
     }
   }
 }
@@ -485,44 +500,59 @@ size_t mha_mfma_lds_bytes(int T, int dk, int window) {
 }
 
 // commons.fused_add_tanh_sigmoid_multiply with g = None (commons.py:102-109): [M, 2H] -> [M, H]
-__global__ void wn_gate_kernel(const float* xin, float* acts, int M, int H) {
+__global__ void wn_gate_kernel(const float* xin, float* acts, f16* acts_p, int M, int H) {
   const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= (size_t)M * H) return;
   const size_t m = i / H, c = i % H;
   const float a = xin[m * 2 * H + c], s = xin[m * 2 * H + H + c];
-  acts[i] = mul_rn(tanhf(a), sigmoid_f(s));
+  const float v = mul_rn(tanhf(a), sigmoid_f(s));
+  acts[i] = v;
+  if (acts_p) split_f16(v, acts_p[i], acts_p[(size_t)M * H + i]);
 }
 // modules.WN.forward:201-208: not last: x = (x + rs[:, :H]) * mask; output += rs[:, H:]
 //                             last:     output = (output + rs) * mask   (the final `output * x_mask` folded in)
-__global__ void wn_update_kernel(float* x, float* output, const float* rs, const float* mask, int M, int H, int last, int first) {
+__global__ void wn_update_kernel(float* x, float* output, const float* rs, const float* mask, f16* x_p, f16* out_p, int M, int H, int last,
+                                 int first) {
   const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= (size_t)M * H) return;
   const size_t m = i / H, c = i % H;
   const float o = first ? 0.f : output[i];
+  const size_t n = (size_t)M * H;
   if (last) {
-    output[i] = mul_rn(add_rn(o, rs[m * H + c]), mask[m]);
+    const float v = mul_rn(add_rn(o, rs[m * H + c]), mask[m]);
+    output[i] = v;
+    if (out_p) split_f16(v, out_p[i], out_p[n + i]);
   } else {
-    x[i] = mul_rn(add_rn(x[i], rs[m * 2 * H + c]), mask[m]);
+    const float v = mul_rn(add_rn(x[i], rs[m * 2 * H + c]), mask[m]);
+    x[i] = v;
+    if (x_p) split_f16(v, x_p[i], x_p[n + i]);
     output[i] = add_rn(o, rs[m * 2 * H + H + c]);
   }
 }
 // modules.Flip (modules.py:374-381) + split: xf = flip(x); x0m = xf[:, :half] * mask
-__global__ void flip_split_kernel(const float* x, const float* mask, float* xf, float* x0m, int M, int I) {
+__global__ void flip_split_kernel(const float* x, const float* mask, float* xf, float* x0m, f16* x0m_p, int M, int I) {
   const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= (size_t)M * I) return;
   const size_t m = i / I, c = i % I;
   const float v = x[m * I + (I - 1 - c)];
   xf[i] = v;
   const int half = I / 2;
-  if ((int)c < half) x0m[m * half + c] = mul_rn(v, mask[m]);
+  if ((int)c < half) {
+    const float vm = mul_rn(v, mask[m]);
+    const size_t o = m * half + c;
+    x0m[o] = vm;
+    if (x0m_p) split_f16(vm, x0m_p[o], x0m_p[(size_t)M * half + o]);
+  }
 }
 // x0_ = pre_transformer(...) + x0 (models.py:509): enc [M, half] += xf[:, :half]
-__global__ void add_x0_kernel(float* enc, const float* xf, int M, int I) {
+__global__ void add_x0_kernel(float* enc, f16* enc_p, const float* xf, int M, int I) {
   const int half = I / 2;
   const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= (size_t)M * half) return;
   const size_t m = i / half, c = i % half;
-  enc[i] = add_rn(enc[i], xf[m * I + c]);
+  const float v = add_rn(enc[i], xf[m * I + c]);
+  enc[i] = v;
+  if (enc_p) split_f16(v, enc_p[i], enc_p[(size_t)M * half + i]);
 }
 // x1 = (x1 - m) * exp(-0) * mask (models.py:529): xf[:, half:] updated in place; mm is post(h) * mask
 __global__ void couple_kernel(float* xf, const float* mm, const float* mask, int M, int I) {
@@ -551,19 +581,25 @@ struct GemmCtx {
   f16* planes;  // scratch for the A operand's hi / lo planes: 2 * max(M * K) halfs
   bool split;   // false: exact fp32 MFMAs
 };
-void gemm_generic(const GemmCtx& cx, const float* a, int lda, int K, const float* W, size_t n_w, const float* bias, int M, int N, float* out,
-                  int ldo, int act, const float* row_mask, const float* resid, int taps, int T, hipStream_t st) {
+// a_pl: the A operand's planes if its producer already wrote them (else they are made here);
+// out_pl: where to put the planes of the result for the next GEMM (needs ldo == N), or nullptr.
+void gemm_generic(const GemmCtx& cx, const float* a, const f16* a_pl, int lda, int K, const float* W, size_t n_w, const float* bias, int M,
+                  int N, float* out, f16* out_pl, int ldo, int act, const float* row_mask, const float* resid, int taps, int T,
+                  hipStream_t st) {
   GemmArgs g;
   memset(&g, 0, sizeof(g));
   g.M = M; g.N = N; g.bias = bias; g.out = out; g.ldo = ldo; g.act = act; g.row_mask = row_mask; g.resid = resid;
   const void *a0 = a, *a1 = a;
   g.W = g.W_lo = W;
   const bool split = cx.split && lda == K && !(K & 7);
+  if (out_pl != nullptr && ldo == N) { g.out_kind = 1; g.out_h = out_pl; g.out_l = out_pl + (size_t)M * N; }
   if (split) {
-    f16* ph = cx.planes;
-    f16* pl = cx.planes + (size_t)M * K;
-    launch_split(a, ph, pl, (size_t)M * K, st);
-    a0 = ph; a1 = pl;
+    const f16* ph = a_pl;
+    if (ph == nullptr) {
+      launch_split(a, cx.planes, cx.planes + (size_t)M * K, (size_t)M * K, st);
+      ph = cx.planes;
+    }
+    a0 = ph; a1 = ph + (size_t)M * K;
     g.prec = PREC_F16S;
     g.W = reinterpret_cast<const f16*>(W + n_w);
     g.W_lo = reinterpret_cast<const f16*>(W + n_w) + n_w;
@@ -581,6 +617,7 @@ void gemm_generic(const GemmCtx& cx, const float* a, int lda, int K, const float
 
 struct StackWs {
   float *x, *xm, *qkv, *att, *t, *f;  // [M,C] [M,C] [M,3C] [M,C] [M,C] [M,F]
+  f16 *x_p, *xm_p, *att_p, *f_p;      // split-fp16 planes of x, xm, att, f (written by their producers)
   GemmCtx cx;
 };
 size_t mha_lds_bytes(int T, int dk, int window) {
@@ -610,9 +647,12 @@ int run_stack(ttsvits_handle* h, const StackBlob& sb, const StackDims& sd, const
   const float* xin = sw.xm;  // layer 0 attends over x * mask; later layers over the unmasked LayerNorm output
   for (int i = 0; i < sd.layers; ++i) {
     const float* xa = i == 0 ? sw.xm : sw.x;
-    gemm_generic(sw.cx, xa, C, C, blob + sb.wqkv[i], (size_t)3 * C * C, blob + sb.bqkv[i], M, 3 * C, sw.qkv, 3 * C, 0, nullptr, nullptr, 1, T, st);
+    const f16* xa_p = i == 0 ? sw.xm_p : sw.x_p;
+    gemm_generic(sw.cx, xa, xa_p, C, C, blob + sb.wqkv[i], (size_t)3 * C * C, blob + sb.bqkv[i], M, 3 * C, sw.qkv, nullptr, 3 * C, 0, nullptr,
+                 nullptr, 1, T, st);
     MhaArgs a;
-    a.qkv = sw.qkv; a.mask = mask; a.out = sw.att; a.T = T; a.C = C; a.dk = dk; a.window = sd.window;
+    a.qkv = sw.qkv; a.mask = mask; a.out = sw.att; a.out_p = sw.att_p; a.n_out = (size_t)M * C;
+    a.T = T; a.C = C; a.dk = dk; a.window = sd.window;
     a.ek = sd.window >= 0 ? blob + sb.ek[i] : nullptr; a.ev = sd.window >= 0 ? blob + sb.ev[i] : nullptr;
     a.qscale = sqrtf((float)dk);
     if (use_mfma) {
@@ -625,28 +665,32 @@ int run_stack(ttsvits_handle* h, const StackBlob& sb, const StackDims& sd, const
       hipLaunchKernelGGL(mha_kernel, dim3((T + kMhaRows - 1) / kMhaRows, sd.heads, B), dim3(kMhaThreads), lds, st, a);
     }
     // x = LayerNorm(x + conv_o(att))
-    gemm_generic(sw.cx, sw.att, C, C, blob + sb.wo[i], (size_t)C * C, blob + sb.bo[i], M, C, sw.t, C, 0, nullptr, xa, 1, T, st);
+    gemm_generic(sw.cx, sw.att, sw.att_p, C, C, blob + sb.wo[i], (size_t)C * C, blob + sb.bo[i], M, C, sw.t, nullptr, C, 0, nullptr, xa, 1, T, st);
     hipLaunchKernelGGL(layernorm_rows_kernel, dim3((M + 3) / 4), dim3(256), 0, st, sw.t, blob + sb.g1[i], blob + sb.b1[i], mask, sw.x,
-                       sw.xm, M, C, 1e-5f);
+                       sw.xm, sw.x_p, sw.xm_p, M, C, 1e-5f);
     // FFN (attentions.py:411-419): conv_2(relu(conv_1(x * mask)) * mask) * mask, then x = LayerNorm(x + y)
-    gemm_generic(sw.cx, sw.xm, C, C, blob + sb.w1[i], (size_t)sd.F * sd.kernel * C, blob + sb.c1[i], M, sd.F, sw.f, sd.F, 1, mask, nullptr, sd.kernel, T, st);
-    gemm_generic(sw.cx, sw.f, sd.F, sd.F, blob + sb.w2[i], (size_t)C * sd.kernel * sd.F, blob + sb.c2[i], M, C, sw.t, C, 0, mask, sw.x, sd.kernel, T, st);
+    gemm_generic(sw.cx, sw.xm, sw.xm_p, C, C, blob + sb.w1[i], (size_t)sd.F * sd.kernel * C, blob + sb.c1[i], M, sd.F, sw.f, sw.f_p, sd.F, 1, mask,
+                 nullptr, sd.kernel, T, st);
+    gemm_generic(sw.cx, sw.f, sw.f_p, sd.F, sd.F, blob + sb.w2[i], (size_t)C * sd.kernel * sd.F, blob + sb.c2[i], M, C, sw.t, nullptr, C, 0, mask,
+                 sw.x, sd.kernel, T, st);
     hipLaunchKernelGGL(layernorm_rows_kernel, dim3((M + 3) / 4), dim3(256), 0, st, sw.t, blob + sb.g2[i], blob + sb.b2[i], mask, sw.x,
-                       sw.xm, M, C, 1e-5f);
+                       sw.xm, sw.x_p, sw.xm_p, M, C, 1e-5f);
   }
   (void)xin;
   return TTSDEC_OK;
 }
 
 size_t stack_ws_floats(const StackDims& sd, size_t M) {
-  return M * (size_t)(4 * sd.C + 3 * sd.C + sd.F + (sd.C > sd.F ? sd.C : sd.F)) + 9 * kAlign;
+  return M * (size_t)(4 * sd.C + 3 * sd.C + sd.F + (sd.C > sd.F ? sd.C : sd.F) + 3 * sd.C + sd.F) + 13 * kAlign;
 }
 StackWs carve_stack(float*& p, const StackDims& sd, size_t M) {
   auto take = [&](size_t n) { float* r = p; p += up(n, kAlign); return r; };
   StackWs w;
   w.x = take(M * sd.C); w.xm = take(M * sd.C); w.qkv = take(M * 3 * sd.C); w.att = take(M * sd.C); w.t = take(M * sd.C);
   w.f = take(M * sd.F);
-  w.cx.planes = reinterpret_cast<f16*>(take(M * (sd.C > sd.F ? sd.C : sd.F)));  // hi + lo planes of one A operand
+  w.cx.planes = reinterpret_cast<f16*>(take(M * (sd.C > sd.F ? sd.C : sd.F)));  // hi + lo planes of one A operand (fallback)
+  w.x_p = reinterpret_cast<f16*>(take(M * sd.C)); w.xm_p = reinterpret_cast<f16*>(take(M * sd.C));
+  w.att_p = reinterpret_cast<f16*>(take(M * sd.C)); w.f_p = reinterpret_cast<f16*>(take(M * sd.F));
   w.cx.split = true;
   return w;
 }
@@ -799,11 +843,12 @@ int ttsvits_text_encoder(ttsvits_handle* h, const int64_t* ids, const int32_t* l
   float* stats = p;
   // models.py:370-376
   hipLaunchKernelGGL(embed_scale_kernel, grid1((size_t)M * H), dim3(256), 0, st, reinterpret_cast<const long long*>(ids), lengths,
-                     h->blob + L.emb, T, H, sqrtf((float)H), sw.xm, mask, M);
+                     h->blob + L.emb, T, H, sqrtf((float)H), sw.xm, sw.xm_p, mask, M);
   int rc = run_stack(h, L.enc, sd, sw, mask, B, T, st);
   if (rc != TTSDEC_OK) return rc;
   // models.py:377-379: stats = proj(x) * x_mask; m, logs = split(stats)
-  gemm_generic(sw.cx, sw.xm, H, H, h->blob + L.proj_w, (size_t)2 * I * H, h->blob + L.proj_b, M, 2 * I, stats, 2 * I, 0, mask, nullptr, 1, T, st);
+  gemm_generic(sw.cx, sw.xm, sw.xm_p, H, H, h->blob + L.proj_w, (size_t)2 * I * H, h->blob + L.proj_b, M, 2 * I, stats, nullptr, 2 * I, 0, mask,
+               nullptr, 1, T, st);
   if (hipMemcpyAsync(x, sw.xm, (size_t)M * H * sizeof(float), hipMemcpyDeviceToDevice, st) != hipSuccess) return vits_fail(h, "copy x");
   if (hipMemcpy2DAsync(m, (size_t)I * sizeof(float), stats, (size_t)2 * I * sizeof(float), (size_t)I * sizeof(float), M,
                        hipMemcpyDeviceToDevice, st) != hipSuccess)
@@ -818,7 +863,7 @@ size_t ttsvits_flow_workspace_bytes(const ttsvits_handle* h, int B, int T) {
   if (!h || B <= 0 || T <= 0) return 0;
   const size_t M = (size_t)B * T, I = h->d.inter_channels, Fh = h->d.flow_hidden;
   const size_t fl = up(M, kAlign) + 2 * up(M * I, kAlign) + up(M * (I / 2), kAlign) + 2 * up(M * Fh, kAlign) + up(M * Fh, kAlign) +
-                    2 * up(M * 2 * Fh, kAlign) + up(M * (Fh > I / 2 ? Fh : I / 2), kAlign);
+                    2 * up(M * 2 * Fh, kAlign) + up(M * (Fh > I / 2 ? Fh : I / 2), kAlign) + 3 * up(M * Fh, kAlign);
   return (stack_ws_floats(tf_dims(h->d), M) + fl) * sizeof(float);
 }
 
@@ -848,28 +893,32 @@ int ttsvits_flow_reverse(ttsvits_handle* h, const float* z, const int32_t* lengt
   GemmCtx fcx;
   fcx.planes = reinterpret_cast<f16*>(take((size_t)M * (Fh > half ? Fh : half)));
   fcx.split = true;
+  f16* hx_p = reinterpret_cast<f16*>(take((size_t)M * Fh));  // planes of hx / acts / ho, written by their producers
+  f16* acts_p = reinterpret_cast<f16*>(take((size_t)M * Fh));
+  f16* ho_p = reinterpret_cast<f16*>(take((size_t)M * Fh));
   hipLaunchKernelGGL(frame_mask_kernel, grid1(M), dim3(256), 0, st, lengths, T, mask, M);
   const float* cur = z;
   for (int f = d.n_flows - 1; f >= 0; --f) {  // models.py:807-809: reversed(flows) = Flip, layer_f, ...
     const FlowBlob& fb = L.flow[f];
-    hipLaunchKernelGGL(flip_split_kernel, grid1((size_t)M * I), dim3(256), 0, st, cur, mask, xb, sw.xm, M, I);
+    hipLaunchKernelGGL(flip_split_kernel, grid1((size_t)M * I), dim3(256), 0, st, cur, mask, xb, sw.xm, sw.xm_p, M, I);
     // x0_ = pre_transformer(x0 * mask, mask) + x0                                   models.py:508-509
     int rc = run_stack(h, fb.tf, sd, sw, mask, B, T, st);
     if (rc != TTSDEC_OK) return rc;
-    hipLaunchKernelGGL(add_x0_kernel, grid1((size_t)M * half), dim3(256), 0, st, sw.xm, xb, M, I);
+    hipLaunchKernelGGL(add_x0_kernel, grid1((size_t)M * half), dim3(256), 0, st, sw.xm, sw.xm_p, xb, M, I);
     // h = pre(x0_) * mask                                                           :510
-    gemm_generic(fcx, sw.xm, half, half, blob + fb.pre_w, (size_t)Fh * half, blob + fb.pre_b, M, Fh, hx, Fh, 0, mask, nullptr, 1, T, st);
+    gemm_generic(fcx, sw.xm, sw.xm_p, half, half, blob + fb.pre_w, (size_t)Fh * half, blob + fb.pre_b, M, Fh, hx, hx_p, Fh, 0, mask, nullptr, 1, T, st);
     // h = WN(h, mask)                                                               :511, modules.py:185-210
     for (int j = 0; j < d.flow_wn_layers; ++j) {
       const bool last = j == d.flow_wn_layers - 1;
-      gemm_generic(fcx, hx, Fh, Fh, blob + fb.in_w[j], (size_t)2 * Fh * d.flow_kernel * Fh, blob + fb.in_b[j], M, 2 * Fh, xin, 2 * Fh, 0, nullptr, nullptr, d.flow_kernel, T, st);
-      hipLaunchKernelGGL(wn_gate_kernel, grid1((size_t)M * Fh), dim3(256), 0, st, xin, acts, M, Fh);
+      gemm_generic(fcx, hx, hx_p, Fh, Fh, blob + fb.in_w[j], (size_t)2 * Fh * d.flow_kernel * Fh, blob + fb.in_b[j], M, 2 * Fh, xin, nullptr, 2 * Fh, 0,
+                   nullptr, nullptr, d.flow_kernel, T, st);
+      hipLaunchKernelGGL(wn_gate_kernel, grid1((size_t)M * Fh), dim3(256), 0, st, xin, acts, acts_p, M, Fh);
       const int cr = last ? Fh : 2 * Fh;
-      gemm_generic(fcx, acts, Fh, Fh, blob + fb.rs_w[j], (size_t)cr * Fh, blob + fb.rs_b[j], M, cr, rs, cr, 0, nullptr, nullptr, 1, T, st);
-      hipLaunchKernelGGL(wn_update_kernel, grid1((size_t)M * Fh), dim3(256), 0, st, hx, ho, rs, mask, M, Fh, last ? 1 : 0, j == 0 ? 1 : 0);
+      gemm_generic(fcx, acts, acts_p, Fh, Fh, blob + fb.rs_w[j], (size_t)cr * Fh, blob + fb.rs_b[j], M, cr, rs, nullptr, cr, 0, nullptr, nullptr, 1, T, st);
+      hipLaunchKernelGGL(wn_update_kernel, grid1((size_t)M * Fh), dim3(256), 0, st, hx, ho, rs, mask, hx_p, ho_p, M, Fh, last ? 1 : 0, j == 0 ? 1 : 0);
     }
     // m = post(h) * mask ; x1 = (x1 - m) * mask                                     :517, 529
-    gemm_generic(fcx, ho, Fh, Fh, blob + fb.post_w, (size_t)half * Fh, blob + fb.post_b, M, half, mm, half, 0, mask, nullptr, 1, T, st);
+    gemm_generic(fcx, ho, ho_p, Fh, Fh, blob + fb.post_w, (size_t)half * Fh, blob + fb.post_b, M, half, mm, nullptr, half, 0, mask, nullptr, 1, T, st);
     hipLaunchKernelGGL(couple_kernel, grid1((size_t)M * half), dim3(256), 0, st, xb, mm, mask, M, I);
     float* t = xa; xa = xb; xb = t;  // the coupled tensor becomes the next layer's input
     cur = xa;
