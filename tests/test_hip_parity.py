@@ -496,14 +496,15 @@ def test_postnet_ljspeech_dims_vs_oracle(H):
     H.assert_close(out, ref, RTOL, ATOL, "postnet")
 
 
+@pytest.mark.parametrize("B,T", [(5, 131), (7, 301)])  # 655 rows: 64x64 tiles; 2107 rows: the 128x128 tiles, ragged last tile
 @pytest.mark.parametrize("mode,rtol,atol", [("split_f16", RTOL, ATOL), ("bf16", 3e-2, 3e-2)])
-def test_postnet_low_precision_modes_vs_oracle(H, mode, rtol, atol):
+def test_postnet_low_precision_modes_vs_oracle(H, mode, rtol, atol, B, T):
     """Postnet on 16-bit MFMA operands.  split_f16 must meet the exact path's bar; bf16
     (BASELINE.json configs[2]: 'Postnet conv1d on MFMA bf16, mel tolerance vs CPU reported')
     carries 8 significand bits per operand - its measured error is printed and bounded."""
     pw = O.random_postnet_weights(80, 512, 3, seed=9)
     g = torch.Generator().manual_seed(2)
-    y = torch.randn(5, 131, 80, generator=g)
+    y = torch.randn(B, T, 80, generator=g)
     ref = O.mel_postnet(y, pw, 3)
     pn = H.make_postnet(80, 512, 3, pw)
     pn.precision = mode
