@@ -124,7 +124,9 @@ enum {
 enum {
   TTSDEC_DROPOUT_OFF = 0,   /* no dropout (not reference behaviour; for analysis)              */
   TTSDEC_DROPOUT_MASKS = 1, /* keep-masks injected: uint8 [steps, 2, B, d_pre], 1 = keep       */
-  TTSDEC_DROPOUT_PHILOX = 2 /* on-device Philox4x32-10 keyed by (seed; step, layer, b, unit)   */
+  TTSDEC_DROPOUT_PHILOX = 2 /* on-device Philox4x32-10 keyed by (seed; step, layer, b, unit): one keep BIT per
+                             * unit, i.e. keep probability exactly 1/2 - valid only for p_dropout == 0.5 (the
+                             * reference's value, modules.py:25); other p: TTSDEC_ERR_INVALID_ARG, use MASKS   */
 };
 
 /* Arithmetic of the two LSTM gate GEMMs (95 % of the step's FLOPs). */
@@ -169,10 +171,17 @@ size_t ttsdec_packed_bytes(const ttsdec_handle* h);
  * pairs, stacks fc_mel/fc_stop, transposes conv weights to [C_out][tap][C_in],
  * turns BatchNorm running stats into per-channel (alpha, beta).  The blob is
  * position-independent: it can be broadcast to other GPUs (RCCL) and bound there.
+ * Range guard of the split-fp16 planes: the call also reduces max |w| over the matrices that have
+ * planes into the blob header and reads it back - the ONE place this library synchronises `stream`.
+ * A weight with |w| >= 65504 (or NaN) has no split-fp16 form: the handle then stays on exact fp32
+ * for the affected GEMMs whatever ttsdec_set_precision / the postnet precision ask
+ * (ttsdec_get_precision reports the mode in effect).
  * Replaces: nn.Module parameter storage / load_state_dict (train_util.py:23-45). */
 int ttsdec_pack_weights(ttsdec_handle* h, const float* const* src /*host array of device ptrs; NULL entry = skip*/, int n_src,
                         void* blob, void* stream);
-/* Binds a packed blob (from ttsdec_pack_weights here or on another rank). */
+/* Binds a packed blob (from ttsdec_pack_weights here or on another rank).  The blob must be complete
+ * (e.g. the broadcast that fills it finished): its header (the range guard's maxima) is read back here
+ * with a synchronous copy. */
 int ttsdec_bind_weights(ttsdec_handle* h, const void* blob);
 
 /* Decoder workspace (recurrent state + scratch) for a batch of B utterances with
@@ -207,7 +216,12 @@ size_t ttsdec_workspace_bytes(const ttsdec_handle* h, int B, int L);
  *                 outputs of this call, step t stored at row (t - t_begin)
  *   T_out         device int32[2]: [0] = total number of steps produced so far
  *                 (= stop step + 1 if the rule fired, else t_begin+n_steps),
- *                 [1] = 1 if the stop rule has fired.
+ *                 [1] = bit 0: the stop rule has fired; bit 1 (split-fp16 mode only): an activation
+ *                 entering a 16-bit GEMM (input / teacher frame, PreNet output, context) had
+ *                 |x| > 65504, the fp16 range - it was SATURATED, never inf/NaN, so outputs stay
+ *                 finite but those rows are not fp32-accurate: rerun with TTSDEC_PREC_F32.
+ *                 (Activation bound of the split mode: |x| <= 65504; h is bounded by 1, the context
+ *                 by max |memory|.)
  */
 int ttsdec_decode(ttsdec_handle* h, const float* memory, int B, int L, int t_begin, int n_steps, int t_stride,
                   float stop_threshold, int check_stop, int dropout_mode, const uint8_t* masks, uint64_t seed,

@@ -11,6 +11,20 @@
 
 using namespace ttsdec;
 
+namespace ttsdec {
+int current_device_or_minus1() {
+  int ndev = 0, dev = -1;
+  if (hipGetDeviceCount(&ndev) == hipSuccess && ndev > 0 && hipGetDevice(&dev) == hipSuccess) return dev;
+  (void)hipGetLastError();
+  return -1;
+}
+bool device_is_current(int device) {
+  if (device < 0) return false;
+  int cur = -1;
+  return hipGetDevice(&cur) == hipSuccess && cur == device;
+}
+}  // namespace ttsdec
+
 namespace {
 
 constexpr int kMaxPostnetLayers = 8;
@@ -31,6 +45,7 @@ struct BlobLayout {  // offsets in floats
   // MelPostnet2: per layer three Conv1dFix weights (+ 16-bit planes) and two folded BatchNorms
   size_t p2_w[kMaxPostnetLayers][3], p2_wb[kMaxPostnetLayers][3], p2_wh[kMaxPostnetLayers][3], p2_wl[kMaxPostnetLayers][3];
   size_t p2_alpha[kMaxPostnetLayers][2], p2_beta[kMaxPostnetLayers][2];
+  size_t wmax;  // [0] max |w| over the decoder matrices that have split-fp16 planes, [1] the same over the Postnet's
   size_t total;
 };
 
@@ -66,6 +81,9 @@ struct ttsdec_handle {
   const void* g_ws;
   const void* g_blob;
   int g_B, g_L, g_prec;
+  // max |w| read back from the blob header (pack / bind): a weight at or beyond the fp16 range has no
+  // split-fp16 form, so the affected GEMMs stay on exact fp32 (ttsdec_get_precision reports it)
+  float wmax_dec, wmax_post;
 };
 
 namespace {
@@ -100,6 +118,7 @@ BlobLayout make_blob_layout(const ttsdec_dims& d) {
     off = align_up(off + n, kAlignFloats);
     return o;
   };
+  L.wmax = take(2);
   const size_t Ha = d.h_att, Hd = d.h_dec, D = d.d_ctx, P = d.d_pre, Mel = d.d_mel, R = d.r, Ph = pre_hidden(d);
   L.pre0_w = take(Ph * Mel);
   L.pre0_b = take(Ph);
@@ -197,7 +216,7 @@ int check_dims(const ttsdec_dims& d) {
   const int v[] = {d.d_mel, d.d_pre, d.d_ctx, d.h_att, d.h_dec};
   for (int x : v)
     if (x <= 0 || (x & 3)) return TTSDEC_ERR_DIMS;
-  if (d.r < 1 || d.d_ctx > 4096) return TTSDEC_ERR_DIMS;
+  if (d.r < 1 || d.d_ctx > 1024) return TTSDEC_ERR_DIMS;  // attn_kernel<4> covers d_ctx/4 <= 256 float4 columns
   if (d.d_pre_hidden < 0 || (d.d_pre_hidden & 3)) return TTSDEC_ERR_DIMS;
   if (d.cell_type != TTSDEC_CELL_TACO2PROD && d.cell_type != TTSDEC_CELL_TACO2) return TTSDEC_ERR_DIMS;
   if (d.postnet_type != TTSDEC_POSTNET_TYPE_MEL && d.postnet_type != TTSDEC_POSTNET_TYPE_MEL2) return TTSDEC_ERR_DIMS;
@@ -222,12 +241,7 @@ int hip_fail(ttsdec_handle* h, hipError_t e, const char* where) {
     if (_e != hipSuccess) return hip_fail(h, _e, #expr); \
   } while (0)
 
-int check_device(ttsdec_handle* h) {
-  if (h->device < 0) return TTSDEC_ERR_DEVICE;
-  int cur = -1;
-  if (hipGetDevice(&cur) != hipSuccess || cur != h->device) return TTSDEC_ERR_DEVICE;
-  return TTSDEC_OK;
-}
+int check_device(ttsdec_handle* h) { return device_is_current(h->device) ? TTSDEC_OK : TTSDEC_ERR_DEVICE; }
 
 int check_launch(ttsdec_handle* h, const char* where) {
   hipError_t e = hipGetLastError();
@@ -294,7 +308,21 @@ struct StepOrder {
 bool split_ok(const ttsdec_dims& d) { return !((d.d_pre | d.d_ctx | d.h_att | d.h_dec) & 7); }
 // launch order of one step: the Prod cell attends between its two LSTMs, the Taco2 cell after both
 const StepOrder& step_order(const ttsdec_dims& d);
-int lstm_prec(const ttsdec_handle* h) { return (h->precision == TTSDEC_PREC_SPLIT_F16 && split_ok(h->d)) ? 1 : 0; }
+int lstm_prec(const ttsdec_handle* h) {
+  return (h->precision == TTSDEC_PREC_SPLIT_F16 && split_ok(h->d) && h->wmax_dec < kSplitMax) ? 1 : 0;
+}
+
+// reads the two weight maxima back from the blob header (one small synchronous copy)
+int read_wmax(ttsdec_handle* h, hipStream_t st) {
+  float v[2] = {0.f, 0.f};
+  if (hipStreamSynchronize(st) != hipSuccess) return hip_fail(h, hipGetLastError(), "wmax sync");
+  hipError_t e = hipMemcpy(v, h->blob + h->bl.wmax, sizeof(v), hipMemcpyDeviceToHost);
+  if (e != hipSuccess) return hip_fail(h, e, "wmax readback");
+  // (a NaN maximum compares false below, i.e. also keeps the GEMMs on fp32)
+  h->wmax_dec = v[0] == v[0] ? v[0] : INFINITY;
+  h->wmax_post = v[1] == v[1] ? v[1] : INFINITY;
+  return TTSDEC_OK;
+}
 
 void launch_node(const ttsdec_handle* h, const StepBufs& sb, const StepIo& io, Node node, hipStream_t st) {
   const ttsdec_dims& d = h->d;
@@ -558,6 +586,7 @@ int ttsdec_create(const ttsdec_dims* dims, ttsdec_handle** out) {
   h->gexec = nullptr;
   h->graph = nullptr;
   h->g_ws = h->g_blob = nullptr;
+  h->wmax_dec = h->wmax_post = 0.f;
   // Measurement switch: TTSDEC_NO_GRAPH=1 launches every step kernel from the host instead of
   // replaying the captured graph.  (A two-stream schedule that ran the LSTMs' early K segments
   // beside the small critical-path kernels was built and measured SLOWER on MI355X - 126 vs 96 us
@@ -565,13 +594,7 @@ int ttsdec_create(const ttsdec_dims* dims, ttsdec_handle** out) {
   // queue behind them - and was removed; see DESIGN.md.)
   const char* e2 = getenv("TTSDEC_NO_GRAPH");
   h->use_graph = !(e2 && atoi(e2));
-  int ndev = 0, dev = -1;
-  if (hipGetDeviceCount(&ndev) == hipSuccess && ndev > 0 && hipGetDevice(&dev) == hipSuccess) {
-    h->device = dev;
-  } else {
-    h->device = -1;
-    (void)hipGetLastError();
-  }
+  h->device = current_device_or_minus1();
   *out = h;
   return TTSDEC_OK;
 }
@@ -689,17 +712,42 @@ int ttsdec_pack_weights(ttsdec_handle* h, const float* const* src, int n_src, vo
     launch_split(fc, hp(L.fc_wh), hp(L.fc_wl), n, st);
     launch_to_bf16(fc, b + L.fc_wb, n, st);
   }
+  // range guard of the split-fp16 planes: max |w| of every matrix that has them
+  {
+    float* wm = b + L.wmax;
+    launch_absmax(src[TTSDEC_W_PRE0_W], Ph * Mel, wm, st);
+    launch_absmax(src[TTSDEC_W_PRE1_W], P * Ph, wm, st);
+    launch_absmax(src[TTSDEC_W_ATT_IH], 4 * Ha * (P + D), wm, st);
+    launch_absmax(src[TTSDEC_W_ATT_HH], 4 * Ha * Ha, wm, st);
+    launch_absmax(src[TTSDEC_W_DEC_IH], 4 * Hd * (Ha + D), wm, st);
+    launch_absmax(src[TTSDEC_W_DEC_HH], 4 * Hd * Hd, wm, st);
+    if (d.postnet_type == TTSDEC_POSTNET_TYPE_MEL2) {
+      const size_t Hh = d.postnet_hidden, k = d.postnet_kernel;
+      const size_t n3[3] = {Hh * Mel * k, Hh * Hh * k, Mel * Hh * k};
+      for (int i = 0; i < d.postnet_layers; ++i)
+        for (int c = 0; c < 3; ++c) launch_absmax(b + L.p2_w[i][c], n3[c], wm + 1, st);
+    } else {
+      size_t ci = Mel;
+      for (int i = 0; i < d.postnet_layers; ++i) {
+        launch_absmax(b + L.conv_w[i], (size_t)d.postnet_hidden * d.postnet_kernel * ci, wm + 1, st);
+        ci = d.postnet_hidden;
+      }
+      if (d.postnet_layers > 0) launch_absmax(b + L.fc_w, Mel * (size_t)d.postnet_hidden, wm + 1, st);
+    }
+  }
   rc = check_launch(h, "pack_weights");
   if (rc != TTSDEC_OK) return rc;
   h->blob = b;
-  return TTSDEC_OK;
+  return read_wmax(h, st);
 }
 
 int ttsdec_bind_weights(ttsdec_handle* h, const void* blob) {
   if (!h || !blob) return TTSDEC_ERR_INVALID_ARG;
   if (reinterpret_cast<uintptr_t>(blob) & 255) return TTSDEC_ERR_WORKSPACE;
+  const int rc = check_device(h);
+  if (rc != TTSDEC_OK) return rc;
   h->blob = static_cast<const float*>(blob);
-  return TTSDEC_OK;
+  return read_wmax(h, nullptr);  // (synchronises the null stream: the blob must be complete, e.g. the broadcast done)
 }
 
 size_t ttsdec_workspace_bytes(const ttsdec_handle* h, int B, int L) {
@@ -715,6 +763,7 @@ int ttsdec_decode(ttsdec_handle* h, const float* memory, int B, int L, int t_beg
   if (B <= 0 || L <= 0 || t_begin < 0 || n_steps < 0 || t_stride < n_steps) return TTSDEC_ERR_INVALID_ARG;
   if (dropout_mode < TTSDEC_DROPOUT_OFF || dropout_mode > TTSDEC_DROPOUT_PHILOX) return TTSDEC_ERR_INVALID_ARG;
   if (dropout_mode == TTSDEC_DROPOUT_MASKS && !masks) return TTSDEC_ERR_INVALID_ARG;
+  if (dropout_mode == TTSDEC_DROPOUT_PHILOX && h->d.p_dropout != 0.5f) return TTSDEC_ERR_INVALID_ARG;  // one keep BIT per unit
   if (teacher && (!teacher_flags || teacher_T < (t_begin + n_steps - 1) * h->d.r)) return TTSDEC_ERR_INVALID_ARG;
   if (!h->blob) return TTSDEC_ERR_NOT_BOUND;
   int rc = check_device(h);
@@ -794,7 +843,7 @@ int ttsdec_postnet(ttsdec_handle* h, const float* y, int B, int T, int precision
   int prec = PREC_F32;
   if (!((d.d_mel | d.postnet_hidden) & 7)) {
     if (precision == TTSDEC_POSTNET_BF16) prec = PREC_BF16;
-    if (precision == TTSDEC_POSTNET_SPLIT_F16) prec = PREC_F16S;
+    if (precision == TTSDEC_POSTNET_SPLIT_F16 && h->wmax_post < kSplitMax) prec = PREC_F16S;
   }
   const size_t M = (size_t)B * T;
   const size_t act_bytes = align_up(M * d.postnet_hidden * sizeof(float), 256);
@@ -932,6 +981,7 @@ int ttsdec_cell_step(ttsdec_handle* h, const float* x, const float* memory, int 
     return TTSDEC_ERR_INVALID_ARG;
   if (B <= 0 || L <= 0 || step < 0) return TTSDEC_ERR_INVALID_ARG;
   if (dropout_mode == TTSDEC_DROPOUT_MASKS && !masks) return TTSDEC_ERR_INVALID_ARG;
+  if (dropout_mode == TTSDEC_DROPOUT_PHILOX && h->d.p_dropout != 0.5f) return TTSDEC_ERR_INVALID_ARG;
   if (!h->blob) return TTSDEC_ERR_NOT_BOUND;
   int rc = check_device(h);
   if (rc != TTSDEC_OK) return rc;
@@ -1019,6 +1069,7 @@ int ttsdec_profile_step(ttsdec_handle* h, const float* memory, int B, int L, int
   if (n_kernels) *n_kernels = order.n;
   if (n_out < order.n) return TTSDEC_ERR_INVALID_ARG;
   if (dropout_mode == TTSDEC_DROPOUT_MASKS && !masks) return TTSDEC_ERR_INVALID_ARG;
+  if (dropout_mode == TTSDEC_DROPOUT_PHILOX && h->d.p_dropout != 0.5f) return TTSDEC_ERR_INVALID_ARG;
   if (!h->blob) return TTSDEC_ERR_NOT_BOUND;
   int rc = check_device(h);
   if (rc != TTSDEC_OK) return rc;

@@ -39,7 +39,8 @@ struct Ctrl {
   const float* teacher;
   const uint8_t* teacher_flags;
   float *y, *s, *w;
-  int pad[32];
+  int range_err;  // split-fp16 mode: an activation entering a 16-bit GEMM was outside the fp16 range (saturated)
+  int pad[31];
 };
 
 // what a step kernel needs to know about "now"
@@ -192,11 +193,19 @@ typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 typedef __bf16 bf16;
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 constexpr float kSplitScale = 2048.0f;
+constexpr float kSplitMax = 65504.0f;  // largest finite fp16: |x| beyond it has no split-fp16 form
+// Saturating: |x| > kSplitMax becomes +-kSplitMax (never inf / NaN out of a finite input); NaN stays NaN.
+// Callers on the decode path report the saturation through Ctrl::range_err (split_f16_checked).
 __device__ __forceinline__ void split_f16(float x, f16& hi, f16& lo) {
+  if (fabsf(x) > kSplitMax) x = copysignf(kSplitMax, x);
   f16 h = (f16)x;
   if (fabsf(x) < 6.103515625e-05f) h = (f16)0.0f;
   hi = h;
   lo = (f16)((x - (float)h) * kSplitScale);
+}
+__device__ __forceinline__ void split_f16_checked(float x, f16& hi, f16& lo, Ctrl* ctrl) {
+  if (ctrl != nullptr && fabsf(x) > kSplitMax) ctrl->range_err = 1;  // (idempotent plain store)
+  split_f16(x, hi, lo);
 }
 
 template <int N, class F>

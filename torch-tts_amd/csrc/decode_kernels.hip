@@ -194,7 +194,7 @@ __global__ __launch_bounds__(kGemmThreads) void gemm_rows_kernel(GemmArgs g) {
     if (EK != EPI_BN_ISRU && EK != EPI_BN_LRELU && EK != EPI_BN_ISRLU && g.bias != nullptr) v = add_rn(v, pb);
     auto store16 = [&](float val) {  // 16-bit copies for a following 16-bit GEMM
       const size_t o = (size_t)m * g.ldo + n;
-      if (g.out_kind == 1) split_f16(val, g.out_h[o], g.out_l[o]);
+      if (g.out_kind == 1) split_f16_checked(val, g.out_h[o], g.out_l[o], g.ctrl);
       else if (g.out_kind == 2) reinterpret_cast<bf16*>(g.out_h)[o] = (bf16)val;
     };
     if (EK == EPI_PLAIN) {
@@ -635,7 +635,7 @@ __global__ __launch_bounds__(kAttnThreads) void attn_kernel(AttnArgs g) {
 #pragma unroll
     for (int w = 0; w < NW; ++w) s += part[((w * NJ + j) * 64 + ln) * 4 + comp];
     g.ctx[(size_t)b * D + d] = s;
-    if (g.ctx_h != nullptr) split_f16(s, g.ctx_h[(size_t)b * D + d], g.ctx_l[(size_t)b * D + d]);
+    if (g.ctx_h != nullptr) split_f16_checked(s, g.ctx_h[(size_t)b * D + d], g.ctx_l[(size_t)b * D + d], g.ctrl);
   }
 }
 
@@ -656,6 +656,7 @@ __global__ void init_state_kernel(InitArgs g) {
   if (i == 0) {
     g.ctrl->stop_t = kStopNever;
     g.ctrl->steps_done = 0;
+    g.ctrl->range_err = 0;
   }
   const size_t nHa = (size_t)g.B * g.Ha, nHd = (size_t)g.B * g.Hd;
   if (i < nHa) {
@@ -693,7 +694,7 @@ __global__ void finish_kernel(Ctrl* ctrl, int32_t* T_out) {
   ctrl->steps_done = done;
   if (T_out) {
     T_out[0] = done;
-    T_out[1] = fired;
+    T_out[1] = fired | (ctrl->range_err ? 2 : 0);
   }
 }
 
@@ -757,19 +758,42 @@ void launch_split(const float* src, f16* hi, f16* lo, size_t n, hipStream_t st) 
   hipLaunchKernelGGL(split_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, src, hi, lo, n);
 }
 
-__global__ void embed_kernel(const long long* ids, const float* table, int n_rows, int E, float* out_a, int lda, float* out_b,
-                             int ldb) {
+// max |x| over a tensor, folded into *out (a non-negative float's bits order like an unsigned int)
+__global__ void absmax_kernel(const float* src, size_t n, unsigned int* out) {
+  float m = 0.f;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+    const float a = fabsf(src[i]);
+    m = (a > m || a != a) ? a : m;  // a NaN weight poisons the maximum on purpose
+  }
+#pragma unroll
+  for (int off = 32; off >= 1; off >>= 1) {
+    const float o = __shfl_xor(m, off, 64);
+    m = (o > m || o != o) ? o : m;
+  }
+  if ((threadIdx.x & 63) == 0) atomicMax(out, __float_as_uint(m));
+}
+void launch_absmax(const float* src, size_t n, float* out, hipStream_t st) {
+  if (n == 0 || src == nullptr) return;
+  const unsigned blocks = (unsigned)((n + 256 * 16 - 1) / (256 * 16));
+  hipLaunchKernelGGL(absmax_kernel, dim3(blocks < 1024 ? blocks : 1024), dim3(256), 0, st, src, n, reinterpret_cast<unsigned int*>(out));
+}
+
+__global__ void embed_kernel(const long long* ids, const float* table, int n_table, int n_rows, int E, float* out_a, int lda,
+                             float* out_b, int ldb) {
   const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= (size_t)n_rows * E) return;
   const int m = (int)(i / E), c = (int)(i % E);
-  const float v = table[(size_t)ids[m] * E + c];
+  long long id = ids[m];  // the host wrapper range-checks ids (IndexError, like nn.Embedding); never read outside the table
+  id = id < 0 ? 0 : (id >= n_table ? n_table - 1 : id);
+  const float v = table[(size_t)id * E + c];
   out_a[(size_t)m * lda + c] = v;
   out_b[(size_t)m * ldb + c] = v;
 }
-void launch_embed(const long long* ids, const float* table, int n_rows, int E, float* out_a, int lda, float* out_b, int ldb,
-                  hipStream_t st) {
+void launch_embed(const long long* ids, const float* table, int n_table, int n_rows, int E, float* out_a, int lda, float* out_b,
+                  int ldb, hipStream_t st) {
   const size_t n = (size_t)n_rows * E;
-  hipLaunchKernelGGL(embed_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, ids, table, n_rows, E, out_a, lda, out_b, ldb);
+  hipLaunchKernelGGL(embed_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, ids, table, n_table, n_rows, E, out_a, lda, out_b,
+                     ldb);
 }
 
 __global__ void fill_rows_kernel(float* dst, const float* row, int n_rows, int n_cols) {

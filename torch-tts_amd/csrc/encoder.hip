@@ -30,6 +30,7 @@ struct ttsenc_handle {
   ttsenc_dims d;
   EncBlob bl;
   const float* blob;
+  int device;  // HIP device current at create (-1: none); must be current for every later call
   std::string hip_err;
 };
 
@@ -91,6 +92,7 @@ int ttsenc_create(const ttsenc_dims* dims, ttsenc_handle** out) {
   h->d = d;
   h->bl = make_layout(d);
   h->blob = nullptr;
+  h->device = current_device_or_minus1();
   *out = h;
   return TTSDEC_OK;
 }
@@ -113,6 +115,7 @@ int ttsenc_pack_weights(ttsenc_handle* h, const float* const* src, int n_src, vo
   for (int i = 0; i < n_src; ++i)
     if (!src[i]) return TTSDEC_ERR_INVALID_ARG;
   if (reinterpret_cast<uintptr_t>(blob) & 255) return TTSDEC_ERR_WORKSPACE;
+  if (!device_is_current(h->device)) return TTSDEC_ERR_DEVICE;
   hipStream_t st = static_cast<hipStream_t>(stream);
   const ttsenc_dims& d = h->d;
   const EncBlob& L = h->bl;
@@ -160,6 +163,7 @@ int ttsenc_forward(ttsenc_handle* h, const int64_t* ids, const int32_t* lengths,
                    void* workspace, size_t workspace_bytes, void* stream) {
   if (!h || !ids || !lengths || !memory || !workspace || B <= 0 || L <= 0 || L_out <= 0 || L_out > L) return TTSDEC_ERR_INVALID_ARG;
   if (!h->blob) return TTSDEC_ERR_NOT_BOUND;
+  if (!device_is_current(h->device)) return TTSDEC_ERR_DEVICE;
   const ttsenc_dims& d = h->d;
   const EncWs W = make_ws(d, B, L);
   if (workspace_bytes < W.total || (reinterpret_cast<uintptr_t>(workspace) & 255)) return TTSDEC_ERR_WORKSPACE;
@@ -173,7 +177,7 @@ int ttsenc_forward(ttsenc_handle* h, const int64_t* ids, const int32_t* lengths,
   float *x = F(W.x), *cat = F(W.cat), *gx = F(W.gx);
 
   // encoder.py:69: embedding (row 0 of the table is the zero padding vector); also the right half of the cat
-  launch_embed(reinterpret_cast<const long long*>(ids), blob + bl.emb, M, E, x, E, cat + E, 2 * E, st);
+  launch_embed(reinterpret_cast<const long long*>(ids), blob + bl.emb, d.alphabet_size, M, E, x, E, cat + E, 2 * E, st);
   // encoder.py:70: three conv blocks over the padded sequence; the last writes the left half of the cat
   // The convs and the input projection run in the GEMM core's split-fp16 mode (fp32-class accuracy,
   // gemm_tile.h): one elementwise pass makes the hi / lo planes of each A operand.

@@ -132,9 +132,12 @@ __global__ __launch_bounds__(kFrameThreads) void frame_kernel(FrameArgs g) {
       t = c->t_end;
       live = c->t_end > c->t_call && c->t_end - 1 <= c->stop_t;
     } else {
-      const StepNow now = step_now(c, g.slot);
-      t = now.t;
-      live = now.live;
+      // This launch finishes step t-1's frame, and its writer workgroups may lower stop_t to t-1
+      // while others are still reading it.  Gate on t-1 <= stop_t: that atomicMin cannot change it,
+      // so every wave of every workgroup takes the same decision and all rows of the firing step
+      // get written.  (When the rule fires here the PreNet below runs on a dead step: harmless.)
+      t = c->t_cur + g.slot;
+      live = t < c->t_end && t - 1 <= c->stop_t;
     }
     if (!live) return;
     t_rel = t - c->t_call;
@@ -190,7 +193,7 @@ __global__ __launch_bounds__(kFrameThreads) void frame_kernel(FrameArgs g) {
 
   // store one element of the input frame as the layer-0 A operand
   auto put_x = [&](int row, int c, float v) {
-    if constexpr (F16) split_f16(v, xs_h[row * (XS * 2) + c], xs_l[row * (XS * 2) + c]);
+    if constexpr (F16) split_f16_checked(v, xs_h[row * (XS * 2) + c], xs_l[row * (XS * 2) + c], g.ctrl);
     else xs[row * XS + c] = v;
   };
 
@@ -270,7 +273,7 @@ __global__ __launch_bounds__(kFrameThreads) void frame_kernel(FrameArgs g) {
       if (g.dropout_mode == TTSDEC_DROPOUT_MASKS) v = mk0[r] ? mul_rn(v, g.keep_scale) : 0.f;
       else if (g.dropout_mode == TTSDEC_DROPOUT_PHILOX)
         v = ((pm0[row * G0 * 4 + wave] >> l32) & 1u) ? mul_rn(v, g.keep_scale) : 0.f;  // unit = 32*wave + l32
-      if constexpr (F16) split_f16(v, h0_h[row * (HS * 2) + col], h0_l[row * (HS * 2) + col]);
+      if constexpr (F16) split_f16_checked(v, h0_h[row * (HS * 2) + col], h0_l[row * (HS * 2) + col], g.ctrl);
       else h0s[row * HS + col] = v;
     }
   }
@@ -325,7 +328,7 @@ __global__ __launch_bounds__(kFrameThreads) void frame_kernel(FrameArgs g) {
       v = ((pm1[row * 4 + ((n >> 5) & 3)] >> (n & 31)) & 1u) ? mul_rn(v, g.keep_scale) : 0.f;
     const size_t o = (size_t)m * g.P + n;
     g.xpre[o] = v;
-    if (g.xpre_h != nullptr) split_f16(v, g.xpre_h[o], g.xpre_l[o]);
+    if (g.xpre_h != nullptr) split_f16_checked(v, g.xpre_h[o], g.xpre_l[o], g.ctrl);
   }
 }
 

@@ -201,9 +201,15 @@ void launch_add_vec(const float* a, const float* b, float* out, int n, hipStream
 void launch_copy(const float* src, float* dst, size_t n, hipStream_t st);
 void launch_split(const float* src, f16* hi, f16* lo, size_t n, hipStream_t st);
 void launch_to_bf16(const float* src, void* dst, size_t n, hipStream_t st);
+// *out = max(*out, max |src[i]|)  (*out must hold a non-negative float, e.g. 0)
+void launch_absmax(const float* src, size_t n, float* out, hipStream_t st);
 // out_a[m, 0:E] (ld lda) and out_b[m, 0:E] (ld ldb) = table[ids[m], :]   (nn.Embedding lookup)
-void launch_embed(const long long* ids, const float* table, int n_rows, int E, float* out_a, int lda, float* out_b, int ldb,
-                  hipStream_t st);
+// (ids outside [0, n_table) are clamped: the host wrappers reject them before the call)
+void launch_embed(const long long* ids, const float* table, int n_table, int n_rows, int E, float* out_a, int lda, float* out_b,
+                  int ldb, hipStream_t st);
+// device bookkeeping shared by the three handle types
+int current_device_or_minus1();
+bool device_is_current(int device);
 void launch_fill_rows(float* dst, const float* row, int n_rows, int n_cols, hipStream_t st);  // dst[m, :] = row[:]
 void launch_conv_transpose(const float* w /*[Co,Ci,k]*/, float* out /*[Co,k,Ci]*/, int Co, int Ci, int k, hipStream_t st);
 // Conv1dFix (mps_fixes.py:22-29) pairs flat-weight column n*Ci + c with x[c, t + pad - n]:

@@ -47,6 +47,7 @@ struct ttsvits_handle {
   ttsvits_dims d;
   VitsBlob bl;
   const float* blob;
+  int device;  // HIP device current at create (-1: none); must be current for every later call
   std::string hip_err;
 };
 
@@ -111,14 +112,16 @@ int vits_fail(ttsvits_handle* h, const char* where) {
 // TextEncoder.forward, models.py:370-376: x = emb(ids) * sqrt(H), masked; also the per-frame mask
 // (every producer below can also emit the split-fp16 planes of its output - hi at p, lo at p + M*C - so
 // the GEMM that consumes it needs no separate conversion pass)
-__global__ void embed_scale_kernel(const long long* ids, const int* lengths, const float* table, int T, int H, float scale, float* x,
-                                   f16* xp, float* mask, int M) {
+__global__ void embed_scale_kernel(const long long* ids, const int* lengths, const float* table, int n_vocab, int T, int H, float scale,
+                                   float* x, f16* xp, float* mask, int M) {
   const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= (size_t)M * H) return;
   const int m = (int)(i / H), c = (int)(i % H);
   const int b = m / T, t = m - b * T;
   const float mk = t < lengths[b] ? 1.0f : 0.0f;
-  const float v = mul_rn(mul_rn(table[(size_t)ids[m] * H + c], scale), mk);
+  long long id = ids[m];  // the host wrapper range-checks ids (IndexError, like nn.Embedding); never read outside the table
+  id = id < 0 ? 0 : (id >= n_vocab ? n_vocab - 1 : id);
+  const float v = mul_rn(mul_rn(table[(size_t)id * H + c], scale), mk);
   x[i] = v;
   if (xp) split_f16(v, xp[i], xp[(size_t)M * H + i]);
   if (c == 0) mask[m] = mk;
@@ -761,6 +764,7 @@ int ttsvits_create(const ttsvits_dims* dims, ttsvits_handle** out) {
   h->d = *dims;
   h->bl = make_layout(*dims);
   h->blob = nullptr;
+  h->device = current_device_or_minus1();
   *out = h;
   return TTSDEC_OK;
 }
@@ -775,6 +779,7 @@ size_t ttsvits_packed_bytes(const ttsvits_handle* h) { return h ? h->bl.total * 
 int ttsvits_pack_weights(ttsvits_handle* h, const float* const* src, int n_src, void* blob, void* stream) {
   if (!h || !src || !blob || n_src != ttsvits_num_weight_tensors(h)) return TTSDEC_ERR_INVALID_ARG;
   if (reinterpret_cast<uintptr_t>(blob) & 255) return TTSDEC_ERR_WORKSPACE;
+  if (!device_is_current(h->device)) return TTSDEC_ERR_DEVICE;
   hipStream_t st = static_cast<hipStream_t>(stream);
   const ttsvits_dims& d = h->d;
   const VitsBlob& L = h->bl;
@@ -832,6 +837,7 @@ int ttsvits_text_encoder(ttsvits_handle* h, const int64_t* ids, const int32_t* l
   if (!h->blob) return TTSDEC_ERR_NOT_BOUND;
   if (workspace_bytes < ttsvits_text_encoder_workspace_bytes(h, B, T) || (reinterpret_cast<uintptr_t>(workspace) & 255))
     return TTSDEC_ERR_WORKSPACE;
+  if (!device_is_current(h->device)) return TTSDEC_ERR_DEVICE;
   hipStream_t st = static_cast<hipStream_t>(stream);
   const ttsvits_dims& d = h->d;
   const VitsBlob& L = h->bl;
@@ -843,7 +849,7 @@ int ttsvits_text_encoder(ttsvits_handle* h, const int64_t* ids, const int32_t* l
   float* stats = p;
   // models.py:370-376
   hipLaunchKernelGGL(embed_scale_kernel, grid1((size_t)M * H), dim3(256), 0, st, reinterpret_cast<const long long*>(ids), lengths,
-                     h->blob + L.emb, T, H, sqrtf((float)H), sw.xm, sw.xm_p, mask, M);
+                     h->blob + L.emb, d.n_vocab, T, H, sqrtf((float)H), sw.xm, sw.xm_p, mask, M);
   int rc = run_stack(h, L.enc, sd, sw, mask, B, T, st);
   if (rc != TTSDEC_OK) return rc;
   // models.py:377-379: stats = proj(x) * x_mask; m, logs = split(stats)
@@ -872,6 +878,7 @@ int ttsvits_flow_reverse(ttsvits_handle* h, const float* z, const int32_t* lengt
   if (!h || !z || !lengths || !out || !workspace || B <= 0 || T <= 0) return TTSDEC_ERR_INVALID_ARG;
   if (!h->blob) return TTSDEC_ERR_NOT_BOUND;
   if (workspace_bytes < ttsvits_flow_workspace_bytes(h, B, T) || (reinterpret_cast<uintptr_t>(workspace) & 255)) return TTSDEC_ERR_WORKSPACE;
+  if (!device_is_current(h->device)) return TTSDEC_ERR_DEVICE;
   hipStream_t st = static_cast<hipStream_t>(stream);
   const ttsvits_dims& d = h->d;
   const VitsBlob& L = h->bl;

@@ -12,13 +12,14 @@ import torch
 import torch.nn as nn
 
 from . import _lib
-from .engine import EngineCache, EngineDims
+from .engine import EngineCache, EngineDims, PackedWeightsMixin
 from .rng import MaskStream
 
 
-class Decoder(nn.Module):
+class Decoder(PackedWeightsMixin, nn.Module):
     def __init__(self, decoder_cell, r, dim_mel, stop_threshold=-2.0):
         super().__init__()
+        self._watch_state_dict_loads()
         self.decoder_cell = decoder_cell
         self.stop_threshold = stop_threshold
         self.r = r
@@ -124,7 +125,13 @@ class Decoder(nn.Module):
                 dropout_mode=mode, masks=masks_dev, seed=int(self.dropout_seed), teacher=teacher,
                 teacher_flags=flags_dev, y=y, s=s, w=w, t_out=t_out,
             )
-            done, fired = (int(v) for v in t_out.tolist())  # the one host sync of this chunk
+            done, flags = (int(v) for v in t_out.tolist())  # the one host sync of this chunk
+            fired = flags & 1
+            if flags & 2:
+                raise RuntimeError(
+                    "split_f16 precision: an activation (input/teacher frame, PreNet output or context) exceeded the fp16 "
+                    "range (|x| > 65504) and was saturated; set decoder.precision = 'f32' for such inputs"
+                )
             k = done - t
             ys.append(y[:, : k * r])
             ss.append(s[:, : k * r])

@@ -10,7 +10,7 @@ import torch
 import torch.nn as nn
 
 from . import _lib
-from .engine import EngineCache, EngineDims
+from .engine import EngineCache, EngineDims, PackedWeightsMixin
 
 
 def _fused_only(name: str):
@@ -57,9 +57,10 @@ class StepwiseMonotonicAttention(nn.Module):
         _fused_only("StepwiseMonotonicAttention")
 
 
-class Taco2ProdDecoderCell(nn.Module):
+class Taco2ProdDecoderCell(PackedWeightsMixin, nn.Module):
     def __init__(self, dim_ctx, dim_mel, r, dim_rnn, dim_pre=128, dim_att=128, p_zoneout=0.1):
         super().__init__()
+        self._watch_state_dict_loads()
         dim_att_hidden, dim_dec_hidden = dim_rnn[0], dim_rnn[1]
         self.dim_output = dim_dec_hidden + dim_ctx
         self.dim_ctx, self.dim_mel, self.r, self.dim_pre = dim_ctx, dim_mel, r, dim_pre
@@ -154,7 +155,7 @@ class Taco2ProdDecoderCell(nn.Module):
         return x_dec, ctx, (w, ctx, ((h_att, c_att), (h_dec, c_dec)))
 
 
-class Taco2DecoderCell(nn.Module):
+class Taco2DecoderCell(PackedWeightsMixin, nn.Module):
     """Drop-in for the reference's ``decoder_cell.Taco2DecoderCell`` (tacotron/decoder_cell.py:66-140),
     the cell of config-rdh / config-sandra / config_template: context from the PREVIOUS attention
     weights feeds two stacked zoneout LSTMs, the attention input and the cell output are
@@ -162,6 +163,7 @@ class Taco2DecoderCell(nn.Module):
 
     def __init__(self, dim_ctx, dim_mel, r, dim_rnn, dim_pre=128, dim_att=128, p_zoneout=0.1):
         super().__init__()
+        self._watch_state_dict_loads()
         if len(dim_rnn) != 2:
             raise ValueError("Taco2DecoderCell.forward indexes exactly two LSTM layers (decoder_cell.py:126)")
         self.dim_output = sum(dim_rnn) + dim_ctx

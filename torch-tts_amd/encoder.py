@@ -12,7 +12,7 @@ import torch
 import torch.nn as nn
 
 from . import _lib
-from .engine import _require_device, _stream, weights_fingerprint
+from .engine import PackedWeightsMixin, _require_device, _stream, weights_fingerprint
 
 
 class _ISRLU(nn.Module):
@@ -44,7 +44,9 @@ class EncoderEngine:
         self.device = device
         h = C.c_void_p()
         dims = _lib.EncDims(alphabet_size, d_emb, d_out, 5, bn_eps)
-        _lib.check(self._lib.ttsenc_create(C.byref(dims), C.byref(h)), "ttsenc_create")
+        with torch.cuda.device(device):  # the handle binds to the device current at create
+            _lib.check(self._lib.ttsenc_create(C.byref(dims), C.byref(h)), "ttsenc_create")
+        self.alphabet_size = alphabet_size
         self._h = h
         self.d_out = d_out
         self.blob: Optional[torch.Tensor] = None
@@ -86,6 +88,10 @@ class EncoderEngine:
         B, L = ids.shape
         l_out = int(lengths.max())
         ids = ids.to(torch.int64).contiguous()
+        if ids.numel():  # nn.Embedding raises on an out-of-range index (encoder.py:69); the kernel must never read outside the table
+            lo, hi = int(ids.min()), int(ids.max())
+            if lo < 0 or hi >= self.alphabet_size:
+                raise IndexError(f"token id out of range: ids span [{lo}, {hi}], alphabet size {self.alphabet_size}")
         lens = lengths.to(device=self.device, dtype=torch.int32).contiguous()
         key = (B, L)
         ws = self._ws.get(key)
@@ -116,9 +122,10 @@ class _EncCache:
         return _EncCache()
 
 
-class Encoder2(nn.Module):
+class Encoder2(PackedWeightsMixin, nn.Module):
     def __init__(self, alphabet_size, dim_out=512, dim_emb=512):
         super().__init__()
+        self._watch_state_dict_loads()
         self.dim_out, self.dim_emb = dim_out, dim_emb
         self.emb = nn.Embedding(alphabet_size, dim_emb, padding_idx=0)
         self.conv = nn.Sequential(

@@ -64,9 +64,37 @@ def _require_device(t: Tensor, what: str) -> None:
         )
 
 
+_EPOCH = [0]
+
+
+def invalidate_packed_weights() -> None:
+    """Forces every engine to repack its weight blob on next use.  Needed after edits that autograd's
+    version counter does not see: ``param.data.copy_(...)`` / ``param.data.mul_(...)`` leave
+    ``param._version`` unchanged (the reference's checkpoint loader does exactly that,
+    tacotron/train_util.py:43; so do EMA swaps).  ``load_state_dict`` calls this by itself (hook)."""
+    _EPOCH[0] += 1
+
+
+def _invalidate_hook(module, incompatible_keys) -> None:  # module-level: stays picklable
+    invalidate_packed_weights()
+
+
+class PackedWeightsMixin:
+    """For the nn.Modules whose parameters are mirrored in a packed device blob."""
+
+    def invalidate(self) -> None:
+        """Call after modifying parameters through ``.data`` (see invalidate_packed_weights)."""
+        invalidate_packed_weights()
+
+    def _watch_state_dict_loads(self) -> None:
+        self.register_load_state_dict_post_hook(_invalidate_hook)
+
+
 def weights_fingerprint(tensors: Sequence[Optional[Tensor]]) -> Tuple:
-    """Changes whenever a parameter is replaced or modified in place."""
-    return tuple((None if t is None else (t.data_ptr(), t._version, tuple(t.shape))) for t in tensors)
+    """Key of a packed blob: changes when a parameter is replaced, moved, or modified in place through
+    autograd-visible ops (``_version``), and when invalidate_packed_weights() was called.  In-place edits
+    through ``.data`` are NOT visible here - call ``module.invalidate()`` after them."""
+    return (_EPOCH[0],) + tuple((None if t is None else (t.data_ptr(), t._version, tuple(t.shape))) for t in tensors)
 
 
 class Engine:
@@ -160,7 +188,9 @@ class Engine:
         _require_device(blob, "blob")
         if blob.numel() * blob.element_size() != self.packed_bytes():
             raise ValueError("blob size does not match this engine's dims")
-        _lib.check(self._lib.ttsdec_bind_weights(self._h, blob.data_ptr()), "ttsdec_bind_weights")
+        with torch.cuda.device(self.device):
+            torch.cuda.current_stream(self.device).synchronize()  # the blob must be complete: its header is read back
+            _lib.check(self._lib.ttsdec_bind_weights(self._h, blob.data_ptr()), "ttsdec_bind_weights", self._h)
         self.blob = blob
         self._fingerprint = None
 

@@ -9,12 +9,13 @@ import torch
 import torch.nn as nn
 
 from . import _lib
-from .engine import EngineCache, EngineDims
+from .engine import EngineCache, EngineDims, PackedWeightsMixin
 
 
-class MelPostnet(nn.Module):
+class MelPostnet(PackedWeightsMixin, nn.Module):
     def __init__(self, dim_mel, dim_hidden=512, kernel_size=5, num_layers=3):
         super().__init__()
+        self._watch_state_dict_loads()
         padding = (kernel_size - 1) // 2
         conv_dims = [dim_mel] + [dim_hidden for _ in range(num_layers)]
         self.conv = nn.ModuleList(
@@ -83,7 +84,7 @@ class Conv1dFix(nn.Module):
         raise NotImplementedError("Conv1dFix holds parameters only: it runs fused inside MelPostnet2 on the HIP path")
 
 
-class MelPostnet2(nn.Module):
+class MelPostnet2(PackedWeightsMixin, nn.Module):
     """Drop-in for the reference's ``modules.modules.MelPostnet2`` (tacotron/modules/modules.py:187-216),
     selected when model.postnet.type is not "tacotron2" (tacotron.py:207-212): ``num_layers`` residual
     blocks of Conv1dFix(k=5)-BN-LeakyReLU-Dropout x2 + Conv1dFix.  Same state-dict keys
@@ -91,6 +92,7 @@ class MelPostnet2(nn.Module):
 
     def __init__(self, dim_in, dim_hidden=128, num_layers=3):
         super().__init__()
+        self._watch_state_dict_loads()
         self.layers = nn.ModuleList(
             [
                 nn.Sequential(

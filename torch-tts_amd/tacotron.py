@@ -9,6 +9,7 @@ import torch
 import torch.nn as nn
 
 from .decoder import Decoder
+from .engine import PackedWeightsMixin
 from .decoder_cell import Taco2DecoderCell, Taco2ProdDecoderCell
 from .encoder import Encoder2
 from .postnet import MelPostnet, MelPostnet2
@@ -29,7 +30,7 @@ def weights_init(m):
             nn.init.zeros_(m.bias)
 
 
-class Tacotron(nn.Module):
+class Tacotron(PackedWeightsMixin, nn.Module):
     def __init__(self, encoder, decoder, postnet=None, refencoder=None):
         super().__init__()
         self.refencoder = refencoder

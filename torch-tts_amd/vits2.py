@@ -19,7 +19,7 @@ import torch
 import torch.nn as nn
 
 from . import _lib
-from .engine import _require_device, _stream, weights_fingerprint
+from .engine import PackedWeightsMixin, _require_device, _stream, weights_fingerprint
 
 
 class _LayerNorm(nn.Module):  # modules.LayerNorm: parameters gamma / beta
@@ -90,7 +90,8 @@ class VitsEngine:
         self.dims = dict(dims)
         h = C.c_void_p()
         d = _lib.VitsDims(*[int(dims[n]) for n, _ in _lib.VitsDims._fields_])
-        _lib.check(self._lib.ttsvits_create(C.byref(d), C.byref(h)), "ttsvits_create")
+        with torch.cuda.device(device):  # the handle binds to the device current at create
+            _lib.check(self._lib.ttsvits_create(C.byref(d), C.byref(h)), "ttsvits_create")
         self._h = h
         self.blob: Optional[torch.Tensor] = None
         self._fingerprint = None
@@ -153,6 +154,10 @@ class VitsEngine:
         _require_device(ids, "ids")
         B, T = ids.shape
         ids = ids.to(torch.int64).contiguous()
+        if ids.numel():  # nn.Embedding raises on an out-of-range index (models.py:370); the kernel must never read outside the table
+            lo, hi = int(ids.min()), int(ids.max())
+            if lo < 0 or hi >= self.dims["n_vocab"]:
+                raise IndexError(f"token id out of range: ids span [{lo}, {hi}], n_vocab {self.dims['n_vocab']}")
         lens = lengths.to(device=self.device, dtype=torch.int32).contiguous()
         H, I = self.dims["hidden_channels"], self.dims["inter_channels"]
         x = torch.empty(B, T, H, device=self.device)
@@ -205,9 +210,10 @@ class _EngCache:
 _DEFAULT_FLOW = dict(flow_hidden=4, flow_kernel=1, flow_wn_layers=1, n_flows=0, flow_tf_layers=0, flow_tf_heads=1, flow_tf_kernel=1)
 
 
-class TextEncoder(nn.Module):
+class TextEncoder(PackedWeightsMixin, nn.Module):
     def __init__(self, n_vocab, out_channels, hidden_channels, filter_channels, n_heads, n_layers, kernel_size, p_dropout, gin_channels=0):
         super().__init__()
+        self._watch_state_dict_loads()
         if gin_channels:
             raise NotImplementedError("speaker-conditioned text encoder is outside the HIP path")
         self.n_vocab, self.out_channels, self.hidden_channels, self.filter_channels = n_vocab, out_channels, hidden_channels, filter_channels
@@ -285,10 +291,11 @@ class _Flip(nn.Module):
     pass
 
 
-class ResidualCouplingTransformersBlock(nn.Module):
+class ResidualCouplingTransformersBlock(PackedWeightsMixin, nn.Module):
     def __init__(self, channels, hidden_channels, kernel_size, dilation_rate, n_layers, n_flows=4, gin_channels=0,
                  use_transformer_flows=False, transformer_flow_type="pre_conv"):
         super().__init__()
+        self._watch_state_dict_loads()
         if not use_transformer_flows or transformer_flow_type != "pre_conv":
             raise NotImplementedError("only use_transformer_flows=True with transformer_flow_type='pre_conv' (the ModelConfig default) is built")
         self.channels, self.hidden_channels, self.kernel_size, self.n_layers, self.n_flows = channels, hidden_channels, kernel_size, n_layers, n_flows
