@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Benchmark of the Tacotron decoder hot path on MI355X.
 
-    python bench.py --gpus N --steps K --warmup W        (N > 1: launched by torch.distributed.run)
+    python bench.py --gpus N --steps K --warmup W
 
 One "step" = one pass of the hot path over one batch of synthetic LJSpeech-shaped input:
 600 autoregressive decode frames (max_steps=599; random-init stop logits never cross -2.0)
@@ -9,14 +9,28 @@ for B utterances per GPU with memory length L=120, followed by the Postnet over 
 [B, 600, 80] mel.  Metric: mel-frames/s over the whole job (all ranks), inputs resident
 in HBM.  Weak scaling: per-GPU batch fixed at 256 (BASELINE.json configs[2]/[3]:
 2048 = 8 x 256).  Rank 0 prints ONE JSON line.
+
+With --gpus N > 1 and no torchrun environment the script starts its own N ranks (a
+`python -m torch.distributed.run` child, before this process has made any GPU call) and
+exits with the child's code; under torchrun it is one of the ranks.
+
+One invocation times three legs, each with the same K steps / W warm-up steps, barrier +
+synchronize on both sides and the maximum over ranks:
+  * the headline leg (value / dtype / roofline of the line): --precision / --postnet, default
+    split-fp16 arithmetic (include/ttsdec.h TTSDEC_PREC_SPLIT_F16);
+  * "f32_exact": the same workload on the reference's own arithmetic (exact fp32 MFMA everywhere);
+  * "b64_f32": BASELINE.json configs[1] (batch 64 per GPU, fp32).
+The injected-mask parity of the timed configuration against the CPU oracle (all 600 frames
+when the CPU sample covers them) is reported under "parity".
 """
 import argparse
+import hashlib
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
-
-import torch
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
@@ -49,6 +63,14 @@ SANDRA = {
 CONFIGS = {"ljspeech": LJSPEECH, "rdh": RDH, "sandra": SANDRA}
 FRAME_SEC = 256.0 / 22050.0
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
+METRIC = "mel-frames/s (whole node) + real-time-factor, LJSpeech 22.05kHz hop256"
+DTYPE_TEXT = {
+    "f32": "f32 (exact fp32 matrix instruction for every GEMM)",
+    "split_f16": "f32 via split-fp16 (hi+lo fp16 planes = 22 significand bits per operand, 3 f16 MFMA products, fp32 accumulate) "
+                 "for the LSTM, PreNet, query and projection GEMMs; f32 elsewhere",
+}
+POSTNET_TEXT = {"f32": "; Postnet f32", "split_f16": "; Postnet split-fp16", "bf16": "; Postnet bf16"}
+
 
 # Algorithmic bytes per decode step (SURVEY.md 8d / BASELINE.md 4), split by kernel.
 # weights (fp32 params incl. biases) + per-utterance reads/writes, L = memory length.
@@ -74,7 +96,30 @@ def step_bytes(B, L, d):
     return out
 
 
-FP32_MFMA_PEAK_TFLOPS = 157.3  # MI355X_MICROARCH.md: dense fp32 matrix peak
+F16_MFMA_PEAK_TFLOPS = 2500.0  # MI355X_MICROARCH.md: dense bf16/f16 matrix peak
+
+
+def sources_digest():
+    """sha256 over the kernel sources: ties a PMC capture (profiles/*traffic.json) to the code it was taken on."""
+    h = hashlib.sha256()
+    for root in (os.path.join(ROOT, "torch-tts_amd", "csrc"), os.path.join(ROOT, "include")):
+        for fn in sorted(os.listdir(root)):
+            if fn.endswith((".hip", ".h")):
+                with open(os.path.join(root, fn), "rb") as f:
+                    h.update(fn.encode())
+                    h.update(f.read())
+    return h.hexdigest()[:16]
+
+
+def cpu_model():
+    try:
+        with open("/proc/cpuinfo") as f:
+            for line in f:
+                if line.startswith("model name"):
+                    return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
 
 
 def vits2_flops(Tx, Ty, d):
@@ -92,7 +137,7 @@ def vits2_flops(Tx, Ty, d):
     return te, d["n_flows"] * per_flow
 
 
-def bench_vits2(args, T, dist, dev, world, rank):
+def bench_vits2(args, T, torch, dist, dev, world, rank):
     """Second hot path: one step = TextEncoder over [B, 120] tokens + the reverse
     flow over [B, 192, 600] latent frames.  Utterances are independent: ranks take equal shares, no collective."""
     import warnings
@@ -148,17 +193,23 @@ def bench_vits2(args, T, dist, dev, world, rank):
     Bg = B * world
     f_te, f_fl = vits2_flops(Tx, Ty, D)
     fl_s = fl_ms / args.steps * 1e-3
+    # every GEMM runs as 3 f16 MFMA products per fp32 product (split-fp16), so the matrix pipe that bounds the
+    # pass is the f16 one and one algorithmic FLOP costs three of its FLOPs
+    peak = F16_MFMA_PEAK_TFLOPS / 3.0
     res = {
-        "metric": "mel-frames/s (whole node) + real-time-factor, LJSpeech 22.05kHz hop256",
+        "metric": METRIC,
         "value": round(Bg * Ty * args.steps / elapsed, 1), "unit": "mel-frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": round(elapsed * 1e3 / args.steps, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-        "dtype": "f32", "data": "synthetic",
+        "dtype": "f32 via split-fp16 (hi+lo fp16 planes, 3 f16 MFMA products, fp32 accumulate) for every GEMM; attention QK^T / PV and all "
+                 "elementwise math in f32",
+        "data": "synthetic",
         "config": {"workload": f"vits2 second hot path (BASELINE.json configs[4]): TextEncoder [B={B}/GPU, {Tx} tokens] + reverse flow "
                                f"[B, 192, {Ty} frames], ModelConfig defaults", "global_batch": Bg, "parallelism": f"utterance-shard x{world}"},
         "rtf": round((elapsed / args.steps) / (Ty * FRAME_SEC), 6),
         "text_encoder_ms": round(te_ms / args.steps, 3), "flow_reverse_ms": round(fl_ms / args.steps, 3),
         "roofline": {"bound": "mfma", "kernel": "flow_reverse (whole pass: GEMMs + attention)", "achieved": round(B * f_fl / fl_s / 1e12, 2),
-                     "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(B * f_fl / fl_s / 1e12 / FP32_MFMA_PEAK_TFLOPS, 4),
+                     "peak": round(peak, 1), "unit": "TFLOP/s", "frac": round(B * f_fl / fl_s / 1e12 / peak, 4),
+                     "peak_note": "dense f16 MFMA peak (2500 TFLOP/s) / 3 products per fp32 product",
                      "traffic": None, "alg_flops_per_utterance": {"text_encoder": f_te, "flow_reverse": f_fl}},
     }
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
@@ -175,12 +226,220 @@ def bench_vits2(args, T, dist, dev, world, rank):
             V.text_encoder(ids[:bc].cpu(), xl[:bc].cpu(), wts, d)
             V.flow_reverse(z[:bc].cpu(), ym[:bc].cpu(), wts, d)
         ct = time.perf_counter() - t1
-        res["cpu_baseline"] = {"value": round(bc * Ty / ct, 1), "unit": "mel-frames/s", "cores": cores, "kind": "port",
+        res["cpu_baseline"] = {"value": round(bc * Ty / ct, 1), "unit": "mel-frames/s", "cores": cores, "cpu": cpu_model(), "kind": "port",
                                "sample": f"oracle (torch-CPU restatement of the reference blocks) on B={bc}: TextEncoder {Tx} tokens + reverse flow {Ty} frames, {cores} threads"}
     if rank == 0:
         print(json.dumps(res), flush=True)
     if world > 1:
         dist.destroy_process_group()
+
+
+class Workload:
+    """The model (built once), and per batch size the resident inputs / output buffers."""
+
+    def __init__(self, args, T, torch, D, dev, world, rank):
+        self.args, self.T, self.torch, self.D, self.dev, self.world, self.rank = args, T, torch, D, dev, world, rank
+        from torch_tts_amd import _lib
+
+        self._lib = _lib
+        # model: LJSpeech dims, random init seed 42 (xavier_normal gain 1.5, default LSTMCell init)
+        torch.manual_seed(42)
+        self.cfg = CONFIGS[args.config]
+        self.model = T.build_tacotron(self.cfg).eval().to(dev)
+        self.dec, self.post = self.model.decoder, self.model.postnet
+        self.dec.dropout_source, self.dec.dropout_seed = "philox", 123
+        # weights: rank 0 packs, one RCCL broadcast of the blob, other ranks bind
+        self.eng = self.dec._engines.get(self.dec.decoder_cell.engine_dims(), dev)
+        self.peng = self.post._engines.get(self.post.engine_dims(), dev)
+        if world > 1:
+            D.broadcast_engine_weights(self.eng, self.dec.weight_tensors(), src=0)
+            D.broadcast_engine_weights(self.peng, self.post.weight_tensors(), src=0)
+        else:
+            self.eng.ensure_packed(self.dec.weight_tensors())
+            self.peng.ensure_packed(self.post.weight_tensors())
+        self.R = self.cfg["model"]["decoder"]["r"]
+        self._inputs = {}
+
+    def inputs(self, B):
+        """ids -> stock encoder -> memory for this rank's shard of the global batch (B per GPU), plus output buffers."""
+        if B in self._inputs:
+            return self._inputs[B]
+        torch, dev, L, NF = self.torch, self.dev, self.args.mem_len, self.args.frames
+        Bg = B * self.world
+        g = torch.Generator().manual_seed(1234)
+        ids_all = torch.randint(1, 40, (Bg, L), generator=g)
+        lo, hi = self.D.shard_bounds(Bg, self.world, self.rank)
+        ids = ids_all[lo:hi].to(dev)
+        lens = torch.full((hi - lo,), L, dtype=torch.long, device=dev)
+        with torch.no_grad():
+            mem = torch.cat([self.model.encoder(ids[i : i + 64], lens[i : i + 64]) for i in range(0, hi - lo, 64)]).contiguous()
+        assert mem.shape == (B, L, self.cfg["model"]["encoder"]["dim_out"])
+        NS = NF // self.R
+        io = {
+            "mem": mem, "NS": NS,
+            "y": torch.empty(B, NF, 80, device=dev), "s": torch.empty(B, NF, device=dev), "w": torch.empty(B, NS, L, device=dev),
+            "t_out": torch.zeros(2, dtype=torch.int32, device=dev),
+        }
+        self._inputs[B] = io
+        return io
+
+    def decode(self, io, mode, masks):
+        self.eng.decode(io["mem"], t_begin=0, n_steps=io["NS"], stop_threshold=-2.0, check_stop=True, dropout_mode=mode,
+                        masks=masks, seed=123, teacher=None, teacher_flags=None, y=io["y"], s=io["s"], w=io["w"], t_out=io["t_out"])
+
+    def time_leg(self, dist, B, precision, postnet, steps, warmup, dropout="philox"):
+        """K timed steps of decode + Postnet at batch B per GPU; returns the leg's record."""
+        torch, dev, world, _lib = self.torch, self.dev, self.world, self._lib
+        io = self.inputs(B)
+        self.eng.set_precision(precision)
+        pprec = {"f32": _lib.POSTNET_F32, "bf16": _lib.POSTNET_BF16, "split_f16": _lib.POSTNET_SPLIT_F16}[postnet]
+        mode, masks = _lib.DROPOUT_PHILOX, None
+        if dropout == "masks":  # [NS, 2, B, d_pre] uint8 keep-masks (p = 0.5), generated outside the timed region
+            dd = self.cfg["model"]["decoder"]
+            ph = 128 if dd["type"] == "tacotron2" else dd["dim_pre"]
+            gm = torch.Generator(device=dev).manual_seed(123 + self.rank)
+            masks = torch.randint(0, 2, (io["NS"], B * (ph + dd["dim_pre"])), generator=gm, device=dev, dtype=torch.uint8)
+            mode = _lib.DROPOUT_MASKS
+
+        def fence():
+            torch.cuda.synchronize()
+            if world > 1:
+                dist.barrier()
+            torch.cuda.synchronize()
+
+        for _ in range(warmup):
+            self.decode(io, mode, masks)
+            self.peng.postnet(io["y"], pprec)
+        fence()
+        ev0, ev1, ev2 = (torch.cuda.Event(enable_timing=True) for _ in range(3))
+        t0 = time.perf_counter()
+        dec_ms = 0.0
+        y_post = None
+        for _ in range(steps):
+            ev0.record()
+            self.decode(io, mode, masks)
+            ev1.record()
+            y_post = self.peng.postnet(io["y"], pprec)
+            ev2.record()
+            ev2.synchronize()
+            dec_ms += ev0.elapsed_time(ev1)
+        fence()
+        elapsed = time.perf_counter() - t0
+        assert io["t_out"].tolist() == [io["NS"], 0], f"decode ended early or saturated: {io['t_out'].tolist()}"
+        assert bool(torch.isfinite(y_post).all())
+        if world > 1:
+            tt = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+            elapsed = float(tt.item())
+        NF, Bg = self.args.frames, B * world
+        value = Bg * NF * steps / elapsed
+        return {
+            "value": round(value, 1), "ms_per_step": round(elapsed * 1e3 / steps, 3),
+            "rtf": round((elapsed / steps) / (NF * FRAME_SEC), 6),
+            "decode_only_frames_per_s": round(Bg * NF / (dec_ms / steps * 1e-3), 1),
+            "decode_step_ms": dec_ms / steps / io["NS"],
+            "lstm_precision": self.eng.precision(), "postnet_precision": postnet, "batch_per_gpu": B, "global_batch": Bg,
+        }
+
+    def roofline(self, B, precision, decode_step_ms):
+        """Roofline record of the dominant step kernel: HIP events inside the library, on the launch stream."""
+        args, _lib = self.args, self._lib
+        io = self.inputs(B)
+        self.eng.set_precision(precision)
+        kms = self.eng.profile_step(io["mem"], iters=50, dropout_mode=_lib.DROPOUT_PHILOX, masks=None, seed=123)
+        bytes_k = step_bytes(B, args.mem_len, LJSPEECH["model"]["decoder"])  # (byte model of the LJSpeech cell)
+        grp = {"prenet": ["prenet", "prenet0", "prenet1"], "lstm_att": ["lstm_att"], "query": ["query"],
+               "attention": ["attention"], "lstm_dec": ["lstm_dec"], "proj": ["proj"]}
+        per_kernel = {}
+        for k, names in grp.items():
+            ms = sum(kms[n] for n in names if n in kms)
+            if ms <= 0.0:  # (a phase that has been folded into another kernel of the step)
+                continue
+            per_kernel[k] = {"ms": round(ms, 5), "alg_bytes": bytes_k[k], "GBps": round(bytes_k[k] / (ms * 1e-3) / 1e9, 1)}
+        dom = max(per_kernel, key=lambda k: per_kernel[k]["ms"])
+        # HBM traffic of the dominant kernel from the PMC passes: those cannot be collected inside this process
+        # (rocprofv3 --pmc, separate passes), so the figure comes from the committed capture - and only when that
+        # capture was taken on exactly these kernel sources (digest match), else null
+        traffic, traffic_src = None, None
+        try:
+            tj = json.load(open(os.path.join(ROOT, "profiles", "r02_traffic.json")))
+            if tj.get("sources_digest") == sources_digest() and tj.get("precision") == precision and tj.get("batch") == B:
+                traffic = tj["per_launch"].get(dom, {}).get("hbm_bytes")
+                traffic_src = {"file": "profiles/r02_traffic.json", "sources_digest": tj["sources_digest"], "commit": tj.get("captured_at_commit")}
+        except Exception:
+            pass
+        return {
+            "bound": "hbm", "kernel": dom, "achieved": per_kernel[dom]["GBps"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            "frac": round(per_kernel[dom]["GBps"] / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_capture": traffic_src,
+            "alg_bytes_per_launch": per_kernel[dom]["alg_bytes"], "kernel_ms": per_kernel[dom]["ms"],
+            "decode_step": {
+                "alg_bytes": bytes_k["step"], "ms_in_loop": round(decode_step_ms, 5),
+                "GBps": round(bytes_k["step"] / (decode_step_ms * 1e-3) / 1e9, 1),
+                "frac": round(bytes_k["step"] / (decode_step_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+                "sum_kernel_ms": round(sum(v["ms"] for v in per_kernel.values()), 5),
+            },
+            "per_kernel": per_kernel,
+        }
+
+    def cpu_baseline_and_parity(self, B, precisions, postnets):
+        """The oracle (a port of the reference's CPU path) timed on this box's host cores, on the timed inputs
+        with injected masks; the same masks then go through the HIP path (outside any timed region) and the
+        two are compared - the parity of the timed configuration."""
+        torch, args, _lib = self.torch, self.args, self._lib
+        from oracle import tacotron_oracle as O
+
+        io = self.inputs(B)
+        NF, L = args.frames, args.mem_len
+        dims = O.DecoderDims()
+        sd = {k: v.detach().cpu() for k, v in self.dec.state_dict().items()}
+        pw = {k: v.detach().cpu() for k, v in self.post.state_dict().items()}
+        memc = io["mem"].cpu()
+        # the GPU box gives one GPU a 16-CPU share: do not oversubscribe it
+        cores = max(1, min(16, os.cpu_count() or 1, torch.get_num_threads()))
+        torch.set_num_threads(cores)
+        tc = args.cpu_frames
+        if tc <= 0:
+            t1 = time.perf_counter()
+            O.decode(sd, dims, memc, max_steps=1, masks=O.synthetic_masks(2, B, 256))
+            per = (time.perf_counter() - t1) / 2
+            tc = max(4, min(NF, int(20.0 / max(per, 1e-4))))
+        masks = O.synthetic_masks(tc, B, 256, seed=123)
+        t1 = time.perf_counter()
+        with torch.no_grad():
+            cy, cs, cw = O.decode(sd, dims, memc, max_steps=tc - 1, masks=masks)
+            cpost = O.mel_postnet(cy, pw, 3)
+        ct = time.perf_counter() - t1
+        cpu = {
+            "value": round(B * tc / ct, 1), "unit": "mel-frames/s", "cores": cores, "cpu": cpu_model(), "kind": "port",
+            "sample": f"oracle (torch-CPU restatement of the reference path) on B={B}, L={L}, {tc} decode frames + Postnet, {cores} threads",
+        }
+        # parity of the HIP path on the same inputs and masks (bar: 1e-4 relative with 1e-5 absolute floor; argmax exact)
+        dmasks = masks.to(self.dev).contiguous()
+        full = torch.zeros(io["NS"], *masks.shape[1:], dtype=torch.uint8, device=self.dev)
+        full[:tc] = dmasks
+
+        def rel(a, b):
+            return float(((a - b).abs() / (1e-5 / 1e-4 + b.abs())).max())
+
+        parity = {"frames_compared": tc, "batch": B, "tolerance": "max |hip - oracle| / (0.1 + |oracle|) <= 1e-4 (rtol 1e-4, atol 1e-5); argmax(w) exact"}
+        for precision, postnet in zip(precisions, postnets):
+            self.eng.set_precision(precision)
+            self.decode(io, _lib.DROPOUT_MASKS, full)
+            pprec = {"f32": _lib.POSTNET_F32, "bf16": _lib.POSTNET_BF16, "split_f16": _lib.POSTNET_SPLIT_F16}[postnet]
+            yp = self.peng.postnet(io["y"][:, :tc].contiguous(), pprec)
+            torch.cuda.synchronize()
+            y, s, w = io["y"][:, :tc].cpu(), io["s"][:, :tc].unsqueeze(2).cpu(), io["w"][:, :tc].cpu()
+            parity[f"{precision}+postnet_{postnet}"] = {
+                "max_rel_y": rel(y, cy), "max_rel_s": rel(s, cs), "max_rel_w": rel(w, cw), "max_rel_y_post": rel(yp.cpu(), cpost),
+                "argmax_mismatches": int((w.argmax(-1) != cw.argmax(-1)).sum()), "argmax_rows": int(w.shape[0] * w.shape[1]),
+            }
+        return cpu, parity
+
+
+def free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
 
 
 def main():
@@ -193,7 +452,7 @@ def main():
     ap.add_argument("--frames", type=int, default=600)
     ap.add_argument("--postnet", choices=["f32", "bf16", "split_f16"], default="split_f16")
     ap.add_argument("--precision", choices=["f32", "split_f16"], default="split_f16",
-                    help="arithmetic of the LSTM gate GEMMs (include/ttsdec.h TTSDEC_PREC_*)")
+                    help="arithmetic of the headline leg's LSTM / PreNet / query / projection GEMMs (include/ttsdec.h TTSDEC_PREC_*)")
     ap.add_argument("--config", choices=sorted(CONFIGS), default="ljspeech",
                     help="model dims: ljspeech = BASELINE.json's config (default); rdh / sandra = the other shipped configs")
     ap.add_argument("--workload", choices=["tacotron", "vits2"], default="tacotron",
@@ -202,17 +461,27 @@ def main():
     ap.add_argument("--dropout", choices=["philox", "masks"], default="philox",
                     help="PreNet dropout source: philox = drawn on the device (default, SURVEY 8d 'mode 2'); masks = injected keep-masks "
                          "resident in HBM ('mode 1': what the parity runs use)")
-    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-cpu-baseline", action="store_true", help="skip the CPU baseline and the parity record")
+    ap.add_argument("--no-extra-legs", action="store_true", help="time only the headline leg (no f32_exact / b64_f32 sub-records)")
     ap.add_argument("--cpu-frames", type=int, default=0, help="decode frames for the CPU baseline sample (0 = auto)")
     args = ap.parse_args()
 
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if args.gpus > 1 and "RANK" not in os.environ:
+        # Started like the N = 1 case (`python bench.py --gpus N ...`): become the launcher.  Nothing in this
+        # process has touched the GPU (torch is not even imported), so starting children is safe; the ranks are
+        # fresh interpreters.
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+               "--master-addr", "127.0.0.1", "--master-port", str(free_port()), os.path.abspath(__file__), *sys.argv[1:]]
+        raise SystemExit(subprocess.run(cmd).returncode)
+    if args.gpus != world:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: start with `python bench.py --gpus N` or torch.distributed.run with N ranks")
+
+    import torch
     import torch.distributed as dist
 
-    world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if args.gpus > 1 and world != args.gpus:
-        raise SystemExit(f"--gpus {args.gpus} needs torch.distributed.run with {args.gpus} ranks (WORLD_SIZE={world})")
     # Rehearsal switch (not for measurements): TTSDEC_BENCH_BACKEND=gloo lets several ranks share the
     # GPUs of a smaller box to exercise the N > 1 code path; the real run is RCCL, one rank per GPU.
     backend = os.environ.get("TTSDEC_BENCH_BACKEND", "nccl")
@@ -227,198 +496,52 @@ def main():
             dist.init_process_group(backend, rank=rank, world_size=world)
 
     import torch_tts_amd as T
-    from torch_tts_amd import _lib
     from torch_tts_amd import distributed as D
 
     if args.workload == "vits2":
-        return bench_vits2(args, T, dist, dev, world, rank)
+        return bench_vits2(args, T, torch, dist, dev, world, rank)
 
+    wk = Workload(args, T, torch, D, dev, world, rank)
     B, L, NF = args.batch, args.mem_len, args.frames
-    Bg = B * world  # global batch
+    lj = args.config == "ljspeech"
 
-    # ---- model: LJSpeech dims, random init seed 42 (xavier_normal gain 1.5, default LSTMCell init) ----
-    torch.manual_seed(42)
-    CFG = CONFIGS[args.config]
-    if args.config != "ljspeech":
-        args.no_cpu_baseline = True  # the CPU leg and the byte model below are written for the LJSpeech cell
-    model = T.build_tacotron(CFG).eval()
-    model.to(dev)
-    dec, post = model.decoder, model.postnet
-    dec.dropout_source, dec.dropout_seed = "philox", 123
-    dec.precision = args.precision
-    post.precision = args.postnet
-
-    # ---- weights: rank 0 packs, one RCCL broadcast of the blob, other ranks bind ----
-    eng = dec._engines.get(dec.decoder_cell.engine_dims(), dev)
-    peng = post._engines.get(post.engine_dims(), dev)
-    if world > 1:
-        D.broadcast_engine_weights(eng, dec.weight_tensors(), src=0)
-        D.broadcast_engine_weights(peng, post.weight_tensors(), src=0)
-        eng._fingerprint = None
-    else:
-        eng.ensure_packed(dec.weight_tensors())
-        peng.ensure_packed(post.weight_tensors())
-    eng.set_precision(args.precision)
-
-    # ---- synthetic input: ids -> stock encoder -> memory, this rank's shard of the global batch ----
-    g = torch.Generator().manual_seed(1234)
-    ids_all = torch.randint(1, 40, (Bg, L), generator=g)
-    lo, hi = D.shard_bounds(Bg, world, rank)
-    ids = ids_all[lo:hi].to(dev)
-    lens = torch.full((hi - lo,), L, dtype=torch.long, device=dev)
-    with torch.no_grad():
-        mem = torch.cat([model.encoder(ids[i : i + 64], lens[i : i + 64]) for i in range(0, hi - lo, 64)]).contiguous()
-    assert mem.shape == (B, L, CFG["model"]["encoder"]["dim_out"])
-    R = CFG["model"]["decoder"]["r"]
-    NS = NF // R  # decode steps for NF frames
-
-    y = torch.empty(B, NF, 80, device=dev)
-    s = torch.empty(B, NF, device=dev)
-    w = torch.empty(B, NS, L, device=dev)
-    t_out = torch.zeros(2, dtype=torch.int32, device=dev)
-    prec = {"f32": _lib.POSTNET_F32, "bf16": _lib.POSTNET_BF16, "split_f16": _lib.POSTNET_SPLIT_F16}[args.postnet]
-
-    dmode, dmasks = _lib.DROPOUT_PHILOX, None
-    if args.dropout == "masks":  # [NS, 2, B, d_pre] uint8 keep-masks (p = 0.5), generated outside the timed region
-        dd = CFG["model"]["decoder"]
-        ph = 128 if dd["type"] == "tacotron2" else dd["dim_pre"]
-        gm = torch.Generator(device=dev).manual_seed(123 + rank)
-        dmasks = torch.randint(0, 2, (NS, B * (ph + dd["dim_pre"])), generator=gm, device=dev, dtype=torch.uint8)
-        dmode = _lib.DROPOUT_MASKS
-
-    def one_step():
-        eng.decode(mem, t_begin=0, n_steps=NS, stop_threshold=-2.0, check_stop=True, dropout_mode=dmode,
-                   masks=dmasks, seed=123, teacher=None, teacher_flags=None, y=y, s=s, w=w, t_out=t_out)
-        return peng.postnet(y, prec)
-
-    def fence():
-        torch.cuda.synchronize()
-        if world > 1:
-            dist.barrier()
-        torch.cuda.synchronize()
-
-    for _ in range(args.warmup):
-        one_step()
-    fence()
-    ev0, ev1, ev2 = (torch.cuda.Event(enable_timing=True) for _ in range(3))
-    t0 = time.perf_counter()
-    dec_ms = 0.0
-    for _ in range(args.steps):
-        ev0.record()
-        eng.decode(mem, t_begin=0, n_steps=NS, stop_threshold=-2.0, check_stop=True, dropout_mode=dmode,
-                   masks=dmasks, seed=123, teacher=None, teacher_flags=None, y=y, s=s, w=w, t_out=t_out)
-        ev1.record()
-        y_post = peng.postnet(y, prec)
-        ev2.record()
-        ev2.synchronize()
-        dec_ms += ev0.elapsed_time(ev1)
-    fence()
-    elapsed = time.perf_counter() - t0
-    assert t_out.tolist() == [NS, 0], f"decode ended early: {t_out.tolist()}"
-    assert bool(torch.isfinite(y_post).all())
-    if world > 1:
-        tt = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        elapsed = float(tt.item())
-
-    frames_total = Bg * NF * args.steps
-    value = frames_total / elapsed
-    ms_per_step = elapsed * 1e3 / args.steps
-
-    # ---- roofline of the dominant kernel: HIP events inside the library, on the launch stream ----
-    kms = eng.profile_step(mem, iters=50, dropout_mode=_lib.DROPOUT_PHILOX, masks=None, seed=123)
-    bytes_k = step_bytes(B, L, LJSPEECH["model"]["decoder"])  # (byte model of the LJSpeech cell)
-    grp = {"prenet": ["prenet", "prenet0", "prenet1"], "lstm_att": ["lstm_att"], "query": ["query"],
-           "attention": ["attention"], "lstm_dec": ["lstm_dec"], "proj": ["proj"]}
-    per_kernel = {}
-    for k, names in grp.items():
-        ms = sum(kms[n] for n in names if n in kms)
-        per_kernel[k] = {"ms": round(ms, 5), "alg_bytes": bytes_k[k], "GBps": round(bytes_k[k] / (ms * 1e-3) / 1e9, 1)}
-    dom = max(per_kernel, key=lambda k: per_kernel[k]["ms"])
-    step_ms_kernels = sum(v["ms"] for v in per_kernel.values())
-    decode_step_ms = dec_ms / args.steps / NS
-    # HBM traffic of the dominant kernel from the PMC passes (cannot be collected inside this
-    # process; see profiles/r01_traffic.json for the command and the gfx950 FETCH_SIZE correction)
-    traffic = None
-    try:
-        tj = json.load(open(os.path.join(ROOT, "profiles", "r01_traffic.json")))
-        if args.precision == "split_f16" and B == 256 and L == 120:
-            traffic = tj["per_launch"].get(dom, {}).get("hbm_bytes")
-    except Exception:
-        traffic = None
-    roofline = {
-        "bound": "hbm",
-        "kernel": dom,
-        "achieved": per_kernel[dom]["GBps"],
-        "peak": HBM_PEAK_GBS,
-        "unit": "GB/s",
-        "frac": round(per_kernel[dom]["GBps"] / HBM_PEAK_GBS, 4),
-        "traffic": traffic,
-        "alg_bytes_per_launch": per_kernel[dom]["alg_bytes"],
-        "kernel_ms": per_kernel[dom]["ms"],
-        "decode_step": {
-            "alg_bytes": bytes_k["step"],
-            "ms_in_loop": round(decode_step_ms, 5),
-            "GBps": round(bytes_k["step"] / (decode_step_ms * 1e-3) / 1e9, 1),
-            "frac": round(bytes_k["step"] / (decode_step_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
-            "sum_kernel_ms": round(step_ms_kernels, 5),
-        },
-        "per_kernel": per_kernel,
-    }
-
+    head = wk.time_leg(dist, B, args.precision, args.postnet, args.steps, args.warmup, args.dropout)
     out = {
-        "metric": "mel-frames/s (whole node) + real-time-factor, LJSpeech 22.05kHz hop256",
-        "value": round(value, 1),
-        "unit": "mel-frames/s",
-        "n_gpus": world,
-        "steps": args.steps,
-        "warmup": args.warmup,
-        "ms_per_step": round(ms_per_step, 3),
-        "higher_is_better": True,
-        "scaling": "weak",
-        "vs_baseline": None,
-        "dtype": ("f32" if args.precision == "f32" else "f32 via split-fp16 (hi+lo fp16 planes, 3 f16 MFMA products, fp32 accumulate) for the LSTM and PreNet GEMMs; f32 elsewhere")
-                 + {"f32": "; Postnet f32", "split_f16": "; Postnet split-fp16", "bf16": "; Postnet bf16"}[args.postnet],
+        "metric": METRIC, "value": head["value"], "unit": "mel-frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": head["ms_per_step"], "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": DTYPE_TEXT[head["lstm_precision"]] + POSTNET_TEXT[args.postnet],
         "data": "synthetic",
         "config": {
-            "workload": f"{args.config} dims, batch={B}/GPU (global {Bg}), L={L}, {NF} decode frames + Postnet({args.postnet}); "
+            "workload": f"{args.config} dims, batch={B}/GPU (global {B * world}), L={L}, {NF} decode frames + Postnet({args.postnet}); "
                         "BASELINE.json configs[2] per GPU, configs[3] at 8 GPUs",
-            "global_batch": Bg, "mem_len": L, "frames": NF, "dropout": args.dropout, "parallelism": f"utterance-shard x{world}",
-            "lstm_precision": eng.precision(),
+            "global_batch": B * world, "mem_len": L, "frames": NF, "dropout": args.dropout, "parallelism": f"utterance-shard x{world}",
+            "lstm_precision": head["lstm_precision"],
         },
-        "rtf": round((elapsed / args.steps) / (NF * FRAME_SEC), 6),
-        "audio_seconds_per_s": round(value * FRAME_SEC, 1),
-        "decode_only_frames_per_s": round(Bg * NF / (dec_ms / args.steps * 1e-3), 1),
-        "roofline": roofline,
+        "rtf": head["rtf"], "audio_seconds_per_s": round(head["value"] * FRAME_SEC, 1),
+        "decode_only_frames_per_s": head["decode_only_frames_per_s"],
+        "roofline": wk.roofline(B, args.precision, head["decode_step_ms"]),
     }
-
-    # ---- CPU baseline: the oracle (a port of the reference's CPU path) on this box's host cores ----
-    if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        from oracle import tacotron_oracle as O
-
-        dims = O.DecoderDims()
-        sd = {k: v.detach().cpu() for k, v in dec.state_dict().items()}
-        pw = {k: v.detach().cpu() for k, v in post.state_dict().items()}
-        memc = mem.cpu()
-        # the GPU box gives one GPU a 16-CPU share: do not oversubscribe it
-        cores = max(1, min(16, os.cpu_count() or 1, torch.get_num_threads()))
-        torch.set_num_threads(cores)
-        tc = args.cpu_frames
-        if tc <= 0:
-            t1 = time.perf_counter()
-            O.decode(sd, dims, memc, max_steps=1, masks=O.synthetic_masks(2, B, 256))
-            per = (time.perf_counter() - t1) / 2
-            tc = max(4, min(NF, int(15.0 / max(per, 1e-4))))
-        masks = O.synthetic_masks(tc, B, 256)
-        t1 = time.perf_counter()
-        with torch.no_grad():
-            cy, _, _ = O.decode(sd, dims, memc, max_steps=tc - 1, masks=masks)
-            O.mel_postnet(cy, pw, 3)
-        ct = time.perf_counter() - t1
-        out["cpu_baseline"] = {
-            "value": round(B * tc / ct, 1), "unit": "mel-frames/s", "cores": cores, "kind": "port",
-            "sample": f"oracle (torch-CPU restatement of the reference path) on B={B}, L={L}, {tc} decode frames + Postnet, {cores} threads",
+    legs = []
+    if lj and not args.no_extra_legs:
+        if not (args.precision == "f32" and args.postnet == "f32"):
+            legs.append(("f32_exact", B, "f32", "f32", "the headline workload on the reference's own arithmetic: exact fp32 for every GEMM, Postnet fp32"))
+        if B != 64:
+            legs.append(("b64_f32", 64, "f32", "f32", "BASELINE.json configs[1]: batch 64 per GPU, exact fp32"))
+    for name, b, pr, pp, what in legs:
+        leg = wk.time_leg(dist, b, pr, pp, args.steps, args.warmup, args.dropout)
+        rf = wk.roofline(b, pr, leg["decode_step_ms"])
+        out[name] = {
+            "what": what, "value": leg["value"], "unit": "mel-frames/s", "ms_per_step": leg["ms_per_step"], "steps": args.steps,
+            "warmup": args.warmup, "dtype": DTYPE_TEXT[leg["lstm_precision"]] + POSTNET_TEXT[pp], "rtf": leg["rtf"],
+            "decode_only_frames_per_s": leg["decode_only_frames_per_s"], "global_batch": leg["global_batch"],
+            "roofline": {k: rf[k] for k in ("bound", "kernel", "achieved", "peak", "unit", "frac", "traffic", "alg_bytes_per_launch", "kernel_ms", "decode_step")},
         }
+
+    if rank == 0 and world == 1 and lj and not args.no_cpu_baseline:
+        precs, posts = [args.precision], [args.postnet]
+        if not args.no_extra_legs and not (args.precision == "f32" and args.postnet == "f32"):
+            precs.append("f32"); posts.append("f32")
+        out["cpu_baseline"], out["parity"] = wk.cpu_baseline_and_parity(B, precs, posts)
     if rank == 0:
         print(json.dumps(out), flush=True)
     if world > 1:

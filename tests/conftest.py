@@ -30,9 +30,12 @@ def golden():
     meta = json.load(open(os.path.join(GOLDEN, "meta.json")))
     dec = {k[4:]: torch.from_numpy(model[k]) for k in model.files if k.startswith("dec/")}
     post = {k[5:]: torch.from_numpy(model[k]) for k in model.files if k.startswith("post/")}
+    enc = {k[4:]: torch.from_numpy(model[k]) for k in model.files if k.startswith("enc/")}
     return {
         "dec": dec,
         "post": post,
+        "enc": enc,
+        "ids": torch.from_numpy(model["ids"]),
         "memory": torch.from_numpy(model["memory"]),
         "lengths": torch.from_numpy(model["lengths"]),
         "cases": {k: torch.from_numpy(cases[k]) for k in cases.files},

@@ -6,7 +6,7 @@ mounted read-only at /root/reference) on CPU.  Run in the build container only:
 
 Outputs (committed; data only - inputs, weights at reduced dims, expected
 outputs; no reference source):
-    tests/golden/small_model.npz   reduced-dims weights + encoder memory
+    tests/golden/small_model.npz   reduced-dims weights (encoder, decoder, postnet) + ids + encoder memory
     tests/golden/small_cases.npz   decode / stop / teacher / postnet / unit vectors
     tests/golden/meta.json         sizes, seeds, oracle-vs-reference errors
                                    (incl. a full LJSpeech-dims check whose
@@ -140,6 +140,14 @@ def main():
     errs["infer"] = {"y": maxerr(oy, y), "s": maxerr(os_, s), "w": maxerr(ow, w), "y_post": maxerr(opost, y_post)}
     cases.update({"infer/masks": masks, "infer/y": y, "infer/s": s, "infer/w": w, "infer/y_post": y_post})
     meta["infer"] = {"seed": seed1, "max_steps": max_steps, "T": T}
+
+    # ---- case 1b: the same through Tacotron.forward itself (tacotron.py:29-56): ids -> encoder -> decoder -> postnet ----
+    with torch.no_grad():
+        torch.manual_seed(seed1)
+        ye, ype, se, oute = model(ids, lengths, max_steps=max_steps)
+    assert maxerr(ye, y) == 0.0 and maxerr(ype, y_post) == 0.0  # (the eval-mode encoder draws nothing from the generator)
+    cases.update({"e2e/y": ye, "e2e/y_post": ype, "e2e/s": se, "e2e/w": oute["w"], "e2e/kl_loss": oute["kl_loss"].reshape(1)})
+    meta["e2e"] = {"seed": seed1, "max_steps": max_steps, "T": int(ye.shape[1])}
 
     # ---- case 2: batch-global, inclusive stop rule fired mid-sequence ----
     m_t = s[:, :, 0].min(dim=0).values  # per-step batch minimum of the stop logit
@@ -283,6 +291,9 @@ def main():
         model_npz["dec/" + k] = v.numpy()
     for k, v in post_w.items():
         model_npz["post/" + k] = v.numpy()
+    for k, v in model.state_dict().items():  # the encoder's parameters too: the end-to-end Tacotron.forward test starts from ids
+        if k.startswith("encoder.") and not k.endswith("num_batches_tracked"):
+            model_npz["enc/" + k[len("encoder."):]] = v.detach().numpy()
     np.savez_compressed(os.path.join(HERE, "small_model.npz"), **model_npz)
     np.savez_compressed(os.path.join(HERE, "small_cases.npz"), **{k: v.detach().numpy() for k, v in cases.items()})
     with open(os.path.join(HERE, "meta.json"), "w") as f:

@@ -534,14 +534,106 @@ def test_philox_mode_matches_oracle_masks(H):
 
 
 # --------------------------------------------------------------------------
+# parity at the headline size and length (BASELINE.json configs[1] and [2]): B = 64 / 256, L = 120,
+# T = 600 frames, on bench.py's own model and inputs, both arithmetic modes, injected masks and the
+# on-device Philox masks.  SURVEY 7 H7: argmax equality over >= 600 steps x 256 utterances.
+# --------------------------------------------------------------------------
+_HEADLINE = {}
+
+
+def _headline_case(B, mask_kind):
+    """bench.py's workload (LJSpeech dims, init seed 42, ids seed 1234 through the encoder), the oracle's
+    outputs for all 600 frames (computed once per case) and the masks that produced them."""
+    key = (B, mask_kind)
+    if key in _HEADLINE:
+        return _HEADLINE[key]
+    import bench
+    import torch_tts_amd as T
+
+    L, NF = 120, 600
+    if "model" not in _HEADLINE:
+        torch.manual_seed(42)
+        _HEADLINE["model"] = T.build_tacotron(bench.LJSPEECH).eval().cuda()
+    model = _HEADLINE["model"]
+    g = torch.Generator().manual_seed(1234)
+    ids = torch.randint(1, 40, (B, L), generator=g).cuda()
+    lens = torch.full((B,), L, dtype=torch.long).cuda()
+    with torch.no_grad():
+        mem = torch.cat([model.encoder(ids[i : i + 64], lens[i : i + 64]) for i in range(0, B, 64)]).contiguous()
+    if mask_kind == "injected":
+        masks = O.synthetic_masks(NF, B, 256, seed=123)
+    else:
+        masks = torch.stack([O.philox_keep_masks(123, t, B, 256) for t in range(NF)])
+    sd = {k: v.detach().cpu() for k, v in model.decoder.state_dict().items()}
+    pw = {k: v.detach().cpu() for k, v in model.postnet.state_dict().items()}
+    with torch.no_grad():
+        oy, os_, ow = O.decode(sd, O.DecoderDims(), mem.cpu(), max_steps=NF - 1, masks=masks)
+        opost = O.mel_postnet(oy, pw, 3)
+    _HEADLINE[key] = (model, mem, masks, oy, os_, ow, opost)
+    return _HEADLINE[key]
+
+
+def _drift_report(name, a, b, block=100):
+    """max relative error (bar: 1e-4 with a 1e-5 absolute floor) per block of steps, so drift is visible"""
+    e = (a - b).abs() / (ATOL / RTOL + b.abs())
+    per = [float(e[:, t : t + block].max()) for t in range(0, a.shape[1], block)]
+    print(f"  {name}: max rel err per {block}-step block: " + " ".join(f"{v:.2e}" for v in per))
+    return max(per)
+
+
+@pytest.mark.parametrize("B", [256, 64])
+@pytest.mark.parametrize("prec", ["f32", "split_f16"])
+def test_headline_600_frames_vs_oracle(H, B, prec):
+    model, mem, masks, oy, os_, ow, opost = _headline_case(B, "injected")
+    dec = model.decoder
+    dec.precision = prec
+    y, s, w, fired = H.run_decoder_with_masks(dec, mem, masks, max_steps=599)
+    assert dec.engine(torch.device("cuda:0")).precision() == prec
+    assert not fired and y.shape == oy.shape == (B, 600, 80)
+    print(f"B={B} {prec}:")
+    worst = max(_drift_report("y", y, oy), _drift_report("s", s, os_), _drift_report("w", w, ow))
+    model.postnet.precision = prec
+    with torch.no_grad():
+        yp = model.postnet(y.cuda()).cpu()
+    worst = max(worst, _drift_report("y_post", yp, opost))
+    mism = int((w.argmax(-1) != ow.argmax(-1)).sum())
+    print(f"  argmax mismatches: {mism} of {B * 600}")
+    assert mism == 0, "attention argmax must be bit-exact on all 600 steps of every utterance"
+    H.assert_close(y, oy, RTOL, ATOL, "y")
+    H.assert_close(s, os_, RTOL, ATOL, "s")
+    H.assert_close(w, ow, RTOL, ATOL, "w")
+    H.assert_close(yp, opost, RTOL, ATOL, "y_post")
+    assert worst <= 1.0
+
+
+def test_headline_600_frames_philox_vs_oracle(H):
+    """The configuration bench.py times by default: B = 256, split-fp16, on-device Philox dropout (seed 123)."""
+    model, mem, masks, oy, os_, ow, opost = _headline_case(256, "philox")
+    dec = model.decoder
+    dec.precision, dec.dropout_source, dec.dropout_seed = "split_f16", "philox", 123
+    with torch.no_grad():
+        y, s, w = dec(mem, None, None, 599)
+        model.postnet.precision = "split_f16"
+        yp = model.postnet(y).cpu()
+    y, s, w = y.cpu(), s.cpu(), w.cpu()
+    print("B=256 split_f16 philox:")
+    for n, a, b in (("y", y, oy), ("s", s, os_), ("w", w, ow), ("y_post", yp, opost)):
+        _drift_report(n, a, b)
+        H.assert_close(a, b, RTOL, ATOL, n)
+    assert torch.equal(w.argmax(-1), ow.argmax(-1))
+
+
+# --------------------------------------------------------------------------
 # size-independent properties at BASELINE.json's full size (B=256, L=120, T=600)
 # --------------------------------------------------------------------------
-def test_full_size_properties(H):
+@pytest.mark.parametrize("prec", ["f32", "split_f16"])
+def test_full_size_properties(H, prec):
     dims = O.DecoderDims()
     wts = O.random_decoder_weights(dims, seed=42)
     B, L, T = 256, 120, 600
     mem = O.synthetic_memory(B, L, dims.d_ctx, seed=1234).cuda()
     dec = H.make_decoder(dims, wts)
+    dec.precision = prec
     dec.dropout_source, dec.dropout_seed = "philox", 123
     with torch.no_grad():
         y, s, w = dec(mem, None, None, T - 1)
@@ -778,3 +870,193 @@ def test_frame_kernel_cell_step_at_ljspeech_prenet_dims(H, prec):
     H.assert_close(w2.cpu(), ow, RTOL, ATOL, "w")
     H.assert_close(ha2.cpu(), oha, RTOL, ATOL, "h_att")
     H.assert_close(cd2.cpu(), ocd, RTOL, ATOL, "c_dec")
+
+
+# --------------------------------------------------------------------------
+# round-2 additions: end-to-end glue against the reference's own Tacotron.forward vectors,
+# bound (not locally packed) blobs, invalidation, range guard, argument rejection
+# --------------------------------------------------------------------------
+def test_tacotron_forward_end_to_end_vs_reference(golden, H):
+    """ids -> Encoder2(HIP) -> Decoder(HIP, reference RNG replay) -> MelPostnet(HIP) against the vectors the
+    reference's Tacotron.forward produced under the same torch.manual_seed (tacotron.py:29-56)."""
+    import torch_tts_amd as T
+
+    d, c, m = golden["meta"]["small_dims"], golden["cases"], golden["meta"]["e2e"]
+    enc = T.Encoder2(golden["enc"]["emb.weight"].shape[0], dim_out=d["d_ctx"], dim_emb=golden["enc"]["emb.weight"].shape[1])
+    dec = H.make_decoder(_small_dims(golden), golden["dec"], device="cpu")
+    pn = T.MelPostnet(d["d_mel"], dim_hidden=d["postnet_hidden"], kernel_size=5, num_layers=d["postnet_layers"])
+    model = T.Tacotron(enc, dec, pn)  # (its constructor re-initialises: load the fixture's weights afterwards)
+    sd = {"encoder." + k: v for k, v in golden["enc"].items()}
+    sd.update({"decoder." + k: v for k, v in golden["dec"].items()})
+    sd.update({"postnet." + k: v for k, v in golden["post"].items()})
+    missing, unexpected = model.load_state_dict(sd, strict=False)
+    assert not unexpected and all(k.endswith("num_batches_tracked") or k.endswith("attention_module.bias") for k in missing), (missing, unexpected)
+    model = model.cuda().eval()
+    assert model.decoder.dropout_source == "reference_rng"
+    with torch.no_grad():
+        torch.manual_seed(m["seed"])
+        y, y_post, s, out = model(golden["ids"].cuda(), golden["lengths"], max_steps=m["max_steps"])
+        after = torch.rand(1)
+    assert y.shape[1] == m["T"]
+    H.assert_close(y.cpu(), c["e2e/y"], RTOL, ATOL, "y")
+    H.assert_close(y_post.cpu(), c["e2e/y_post"], RTOL, ATOL, "y_post")
+    H.assert_close(s.cpu(), c["e2e/s"], RTOL, ATOL, "s")
+    H.assert_close(out["w"].cpu(), c["e2e/w"], RTOL, ATOL, "w")
+    assert torch.equal(out["w"].cpu().argmax(-1), c["e2e/w"].argmax(-1))
+    assert float(out["kl_loss"]) == float(c["e2e/kl_loss"]) == 0.0
+    # the host generator is left where the reference leaves it: T steps x 2 Bernoulli draws
+    torch.manual_seed(m["seed"])
+    for _ in range(m["T"]):
+        O.draw_prenet_masks(golden["ids"].shape[0], d["d_pre"], d["d_pre"])
+    assert torch.equal(after, torch.rand(1))
+
+
+@pytest.mark.parametrize("prec", ["f32", "split_f16"])
+def test_bound_blob_decodes_like_the_packing_handle(H, prec):
+    """What non-source ranks do after the weight broadcast (distributed.broadcast_engine_weights): a second handle
+    `bind`s a copy of the blob another handle packed, and must decode bit for bit like it."""
+    from torch_tts_amd import _lib
+    from torch_tts_amd.engine import Engine
+
+    dims = O.DecoderDims()
+    wts = O.random_decoder_weights(dims, seed=5, nonzero_init_state=True)
+    B, L, T = 64, 40, 34
+    mem = O.synthetic_memory(B, L, dims.d_ctx, seed=2).cuda()
+    masks = O.synthetic_masks(T, B, dims.d_pre, seed=3)
+    dec = H.make_decoder(dims, wts)
+    dec.precision = prec
+    ya, sa, wa, _ = H.run_decoder_with_masks(dec, mem, masks, max_steps=T - 1)
+    eng_a = dec.engine(torch.device("cuda:0"))
+    eng_b = Engine(eng_a.dims, torch.device("cuda:0"))
+    eng_b.bind(eng_a.blob.clone())  # (a copy: the bytes a broadcast delivers)
+    eng_b.set_precision(prec)
+    assert eng_b.precision() == prec
+    y = torch.empty(B, T, 80, device="cuda")
+    s = torch.empty(B, T, device="cuda")
+    w = torch.empty(B, T, L, device="cuda")
+    t_out = torch.zeros(2, dtype=torch.int32, device="cuda")
+    eng_b.decode(mem, t_begin=0, n_steps=T, stop_threshold=-2.0, check_stop=True, dropout_mode=_lib.DROPOUT_MASKS,
+                 masks=masks.cuda().contiguous(), seed=0, teacher=None, teacher_flags=None, y=y, s=s, w=w, t_out=t_out)
+    assert t_out.tolist() == [T, 0]
+    assert torch.equal(y.cpu(), ya) and torch.equal(s.cpu().unsqueeze(2), sa) and torch.equal(w.cpu(), wa)
+
+
+def test_data_edits_need_invalidate_and_load_state_dict_repacks(H):
+    """`param.data.copy_()` does not bump the version counter the blob key watches (the reference's checkpoint
+    loader does exactly that, train_util.py:43): invalidate() makes the next forward repack; load_state_dict
+    repacks by itself."""
+    dims = O.DecoderDims(d_mel=80, d_pre=128, d_ctx=64, h_att=128, h_dec=128)
+    w1 = O.random_decoder_weights(dims, seed=1)
+    w2 = O.random_decoder_weights(dims, seed=2)
+    B, L, T = 4, 9, 6
+    mem = O.synthetic_memory(B, L, dims.d_ctx).cuda()
+    masks = O.synthetic_masks(T, B, dims.d_pre)
+    dec = H.make_decoder(dims, w1)
+    y1, _, _, _ = H.run_decoder_with_masks(dec, mem, masks, max_steps=T - 1)
+    o2, _, _ = O.decode(w2, dims, mem.cpu(), max_steps=T - 1, masks=masks)
+    with torch.no_grad():
+        for k, p in dec.state_dict().items():
+            if k in w2:
+                p.data.copy_(w2[k])
+    dec.invalidate()
+    y2, _, _, _ = H.run_decoder_with_masks(dec, mem, masks, max_steps=T - 1)
+    H.assert_close(y2, o2, RTOL, ATOL, "after .data edit + invalidate()")
+    assert not torch.equal(y1, y2)
+    dec.load_state_dict(w1, strict=False)  # hook -> repack without an explicit invalidate()
+    y3, _, _, _ = H.run_decoder_with_masks(dec, mem, masks, max_steps=T - 1)
+    assert torch.equal(y3, y1)
+
+
+def test_stop_rule_with_a_grid_larger_than_one_residency_wave(H):
+    """B = 8192 -> 1024 frame-kernel workgroups (4 per CU): workgroups dispatched after the stop flag was lowered
+    must still write their rows of the firing step (the frame kernel gates on t-1 <= stop_t)."""
+    dims = O.DecoderDims(d_mel=80, r=1, d_pre=128, d_ctx=32, h_att=64, h_dec=64)
+    wts = O.random_decoder_weights(dims, seed=21, nonzero_init_state=True)
+    B, L, T = 8192, 6, 12
+    mem = O.synthetic_memory(B, L, dims.d_ctx, seed=4)
+    masks = O.synthetic_masks(T, B, dims.d_pre, seed=9)
+    w2, thr, k = _stop_case(wts, dims, mem, masks, T, first=3)
+    oy, os_, ow = O.decode(w2, dims, mem, max_steps=T - 1, stop_threshold=thr, masks=masks)
+    assert oy.shape[1] == k + 1
+    for prec in ("f32", "split_f16"):
+        dec = H.make_decoder(dims, w2, stop_threshold=thr)
+        dec.precision = prec
+        for _ in range(3):
+            y, s, w, fired = H.run_decoder_with_masks(dec, mem, masks, max_steps=T - 1)
+            assert fired and y.shape[1] == k + 1
+            assert torch.isfinite(y).all() and torch.isfinite(s).all()
+            H.assert_close(y, oy, RTOL, ATOL, f"y ({prec})")
+            H.assert_close(s, os_, RTOL, ATOL, f"s ({prec})")
+
+
+def test_split_f16_range_guard(H):
+    """A weight at or beyond the fp16 range keeps the handle on exact fp32 (reported by precision()); an activation
+    beyond it (a teacher frame of 7e4) is saturated, never inf/NaN, and reported by the call."""
+    from torch_tts_amd import _lib
+
+    dims = O.DecoderDims(d_mel=80, d_pre=128, d_ctx=64, h_att=128, h_dec=128)
+    wts = O.random_decoder_weights(dims, seed=3)
+    B, L, T = 5, 7, 6
+    mem = O.synthetic_memory(B, L, dims.d_ctx).cuda()
+    masks = O.synthetic_masks(T, B, dims.d_pre)
+    big = {k: v.clone() for k, v in wts.items()}
+    big["decoder_cell.decoder_rnn.weight_hh"][3, 5] = 7.0e4
+    dec = H.make_decoder(dims, big)
+    dec.precision = "split_f16"
+    assert dec.engine(torch.device("cuda:0")).precision() == "f32", "an out-of-range weight must keep the GEMMs on fp32"
+    oy, _, _ = O.decode(big, dims, mem.cpu(), max_steps=T - 1, masks=masks)
+    y, _, _, _ = H.run_decoder_with_masks(dec, mem, masks, max_steps=T - 1)
+    H.assert_close(y, oy, RTOL, ATOL, "y with a 7e4 weight (fp32 path)")
+    # activation out of range: teacher frame of 7e4 in split mode
+    dec = H.make_decoder(dims, wts)
+    dec.precision = "split_f16"
+    eng = dec.engine(torch.device("cuda:0"))
+    assert eng.precision() == "split_f16"
+    x = torch.zeros(B, T, 80)
+    x[2, 1, 7] = 7.0e4
+    y = torch.empty(B, T, 80, device="cuda"); s = torch.empty(B, T, device="cuda"); w = torch.empty(B, T, L, device="cuda")
+    t_out = torch.zeros(2, dtype=torch.int32, device="cuda")
+    eng.decode(mem, t_begin=0, n_steps=T, stop_threshold=-2.0, check_stop=False, dropout_mode=_lib.DROPOUT_MASKS,
+               masks=masks.cuda().contiguous(), seed=0, teacher=x.cuda(), teacher_flags=torch.ones(T, dtype=torch.uint8, device="cuda"),
+               y=y, s=s, w=w, t_out=t_out)
+    done, flags = t_out.tolist()
+    assert done == T and flags & 2, "the saturation must be reported in T_out[1] bit 1"
+    assert torch.isfinite(y).all() and torch.isfinite(s).all() and torch.isfinite(w).all()
+    with pytest.raises(RuntimeError, match="fp16 range"), torch.no_grad():
+        dec(mem, None, x.cuda())
+    dec.precision = "f32"  # the exact path takes the same input without complaint and matches the oracle
+    oy, _, _ = O.decode(wts, dims, mem.cpu(), masks=masks, x=x, p_no_forcing=None)
+    yt, _, _, _ = H.run_decoder_with_masks(dec, mem, masks, x=x)
+    H.assert_close(yt, oy, RTOL, ATOL, "teacher 7e4, fp32")
+
+
+def test_argument_rejection_through_the_c_abi(H):
+    import ctypes as C
+
+    import torch_tts_amd as T
+    from torch_tts_amd import _lib
+    from torch_tts_amd.engine import Engine, EngineDims
+
+    lib = _lib.load()
+    h = C.c_void_p()
+    assert lib.ttsdec_create(C.byref(EngineDims(d_ctx=2048).to_c()), C.byref(h)) == _lib.ERR_DIMS  # attention covers d_ctx <= 1024
+    # Philox draws one keep bit per unit: only p = 0.5
+    eng = Engine(EngineDims(p_dropout=0.25), torch.device("cuda:0"))
+    eng.pack([None] * eng.num_weight_tensors())
+    mem = torch.zeros(2, 3, 512, device="cuda")
+    y = torch.empty(2, 2, 80, device="cuda"); s = torch.empty(2, 2, device="cuda"); w = torch.empty(2, 2, 3, device="cuda")
+    with pytest.raises(_lib.TtsdecError) as ei:
+        eng.decode(mem, t_begin=0, n_steps=2, stop_threshold=-2.0, check_stop=True, dropout_mode=_lib.DROPOUT_PHILOX, masks=None, seed=1,
+                   teacher=None, teacher_flags=None, y=y, s=s, w=w, t_out=torch.zeros(2, dtype=torch.int32, device="cuda"))
+    assert ei.value.code == _lib.ERR_INVALID_ARG
+    # token ids outside the table: IndexError like nn.Embedding, never an out-of-bounds read
+    enc = T.Encoder2(40, dim_out=64, dim_emb=32).cuda().eval()
+    ids = torch.randint(1, 40, (2, 9)).cuda()
+    ids[1, 4] = 40
+    with pytest.raises(IndexError), torch.no_grad():
+        enc(ids, torch.tensor([9, 9]))
+    te = T.vits2.TextEncoder(50, 192, 192, 768, 2, 2, 3, 0.1).cuda().eval()
+    bad = torch.randint(0, 50, (2, 7)).cuda()
+    bad[0, 0] = -1
+    with pytest.raises(IndexError), torch.no_grad():
+        te(bad, torch.tensor([7, 7]).cuda())

@@ -309,3 +309,33 @@ def test_vits2_modules_keys_tensor_counts_and_refusals():
     assert lib.ttsvits_create(C.byref(bad), C.byref(h)) == _lib.ERR_DIMS
     with pytest.raises(RuntimeError):
         te.eval()(torch.zeros(1, 4, dtype=torch.long), torch.tensor([4]))  # CPU tensors: no fallback
+
+
+def test_blob_key_sees_invalidate_but_not_data_edits():
+    """engine.weights_fingerprint: `.data` edits leave Parameter._version alone (why invalidate() exists);
+    invalidate() and load_state_dict change the key; modules with the hook still pickle / deepcopy."""
+    import copy
+    import pickle
+
+    import torch
+
+    import torch_tts_amd as T
+    from torch_tts_amd.engine import weights_fingerprint
+
+    cell = T.Taco2ProdDecoderCell(16, 8, 1, [16, 16], dim_pre=8, dim_att=16)
+    dec = T.Decoder(cell, 1, 8)
+    k0 = weights_fingerprint(dec.weight_tensors())
+    dec.fc_mel.weight.data.mul_(2.0)
+    assert weights_fingerprint(dec.weight_tensors()) == k0, "(documented blind spot: .data edits are invisible)"
+    dec.invalidate()
+    k1 = weights_fingerprint(dec.weight_tensors())
+    assert k1 != k0
+    dec.load_state_dict(dec.state_dict())
+    assert weights_fingerprint(dec.weight_tensors()) != k1
+    with torch.no_grad():
+        dec.fc_mel.weight.mul_(2.0)  # a tracked in-place op is seen without help
+    k2 = weights_fingerprint(dec.weight_tensors())
+    assert k2 != weights_fingerprint([t.clone() for t in dec.weight_tensors()])
+    for m in (pickle.loads(pickle.dumps(dec)), copy.deepcopy(dec)):
+        assert set(m.state_dict()) == set(dec.state_dict())
+        m.load_state_dict(dec.state_dict())

@@ -37,6 +37,19 @@ def test_decode_inference(golden):
     _close(yp, c["infer/y_post"], 2e-6)
 
 
+def test_end_to_end_ids_to_postnet(golden):
+    """Tacotron.forward (tacotron.py:29-56) restated as encoder -> decoder -> postnet, from token ids."""
+    c, m = golden["cases"], golden["meta"]["e2e"]
+    mem = O.encoder2(golden["ids"], golden["lengths"], golden["enc"])
+    _close(mem, golden["memory"], 2e-6)
+    y, s, w = O.decode(golden["dec"], _dims(golden), mem, max_steps=m["max_steps"], masks=c["infer/masks"])
+    _close(y, c["e2e/y"], 5e-6)
+    _close(s, c["e2e/s"], 5e-6)
+    _close(w, c["e2e/w"], 5e-6)
+    _close(O.mel_postnet(y, golden["post"], golden["meta"]["small_dims"]["postnet_layers"]), c["e2e/y_post"], 5e-6)
+    assert float(c["e2e/kl_loss"]) == 0.0
+
+
 def test_decode_stop_rule_is_batch_global_and_inclusive(golden):
     c, m = golden["cases"], golden["meta"]["stop"]
     y, s, w = O.decode(
