@@ -39,7 +39,9 @@ def test_host_only_queries_and_layout_sizes():
     assert e.packed_bytes() >= 4 * (n_dec + n_lstm_w) and e.packed_bytes() % 256 == 0
     # + postnet fp32 (2 870 272 params incl. BN folded to alpha/beta) and its bf16 / fp16-hi / fp16-lo planes
     n_post_w = 512 * 80 * 5 + 2 * 512 * 512 * 5 + 80 * 512
-    assert e.packed_bytes() < 4 * (n_dec + n_lstm_w + 2870272) * 1.01 + 6 * n_post_w + 128 * 256
+    # + the planes of the query and mel/stop projection weights
+    n_small_w = 512 * 1024 + 81 * 1536
+    assert e.packed_bytes() < 4 * (n_dec + n_lstm_w + n_small_w + 2870272) * 1.01 + 6 * n_post_w + 128 * 256
     w1, w2 = e.workspace_bytes(64, 120), e.workspace_bytes(256, 120)
     assert 0 < w1 < w2 and w2 % 256 == 0
     assert e.postnet_workspace_bytes(256, 600) == 2 * 256 * 600 * 512 * 4 + 256 * 600 * 80 * 4

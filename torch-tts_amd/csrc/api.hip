@@ -35,6 +35,7 @@ inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 struct BlobLayout {  // offsets in floats
   size_t pre0_w, pre0_b, pre1_w, pre1_b, wq;
   size_t pre0_h, pre0_l, pre1_h, pre1_l;  // split-fp16 planes of the PreNet weights
+  size_t wq_h, wq_l, proj_h, proj_l;      // ... of the query and mel/stop projection weights
   size_t att_ih, att_hh, att_b, dec_ih, dec_hh, dec_b;
   size_t att_ih_h, att_ih_l, att_hh_h, att_hh_l, dec_ih_h, dec_ih_l, dec_hh_h, dec_hh_l;  // split-fp16 planes
   size_t h0a, c0a, h0d, c0d;
@@ -144,6 +145,8 @@ BlobLayout make_blob_layout(const ttsdec_dims& d) {
   L.c0d = take(Hd);
   L.proj_w = take((R * Mel + R) * (size_t)proj_ld(d));
   L.proj_b = take(R * Mel + R);
+  L.wq_h = take((D * (size_t)query_ld(d) + 1) / 2); L.wq_l = take((D * (size_t)query_ld(d) + 1) / 2);
+  L.proj_h = take(((R * Mel + R) * (size_t)proj_ld(d) + 1) / 2); L.proj_l = take(((R * Mel + R) * (size_t)proj_ld(d) + 1) / 2);
   size_t cin = Mel;
   if (d.postnet_type == TTSDEC_POSTNET_TYPE_MEL2) {
     const size_t Hh = d.postnet_hidden, k = d.postnet_kernel;
@@ -421,6 +424,17 @@ void launch_node(const ttsdec_handle* h, const StepBufs& sb, const StepIo& io, N
       if (is_taco2(d)) g.a = make_seg2(sb.h_att[1 - p], Ha, Ha, sb.h_dec[1 - p], Hd, Hd);
       else g.a = make_seg1(sb.h_att[1 - p], Ha, Ha);
       g.W = blob + bl.wq; g.ldw = query_ld(d); g.K = query_k(d); g.M = B; g.N = D; g.out = sb.q; g.ldo = D;
+      if (prec) {  // split-fp16 planes: the LSTM epilogues emitted them for h, the pack step for the weights
+        g.prec = PREC_F16S;
+        g.W = plane(bl.wq_h); g.W_lo = plane(bl.wq_l);
+        if (is_taco2(d)) {
+          g.a = make_seg2(sb.h_att_h[1 - p], Ha, Ha, sb.h_dec_h[1 - p], Hd, Hd);
+          g.a_lo = make_seg2(sb.h_att_l[1 - p], Ha, Ha, sb.h_dec_l[1 - p], Hd, Hd);
+        } else {
+          g.a = make_seg1(sb.h_att_h[1 - p], Ha, Ha);
+          g.a_lo = make_seg1(sb.h_att_l[1 - p], Ha, Ha);
+        }
+      }
       g.ksplit = query_split(d); g.kchunk = g.K / g.ksplit; g.split_stride = (size_t)B * D;
       g.ctrl = ctrl; g.slot = io.slot; g.t = io.t;
       launch_gemm(g, A_PLAIN, EPI_PLAIN, st);
@@ -468,6 +482,17 @@ void launch_node(const ttsdec_handle* h, const StepBufs& sb, const StepIo& io, N
       else g.a = make_seg2(sb.h_dec[1 - p], Hd, Hd, sb.ctx, D, D);
       g.W = blob + bl.proj_w; g.ldw = proj_ld(d); g.K = proj_k(d); g.M = B; g.N = proj_n(d);
       g.ctrl = ctrl; g.slot = io.slot; g.t = io.t;
+      if (prec && use_frame(d)) {
+        g.prec = PREC_F16S;
+        g.W = plane(bl.proj_h); g.W_lo = plane(bl.proj_l);
+        if (is_taco2(d)) {
+          g.a = make_seg2(sb.h_att_h[1 - p], Ha, Ha, sb.h_dec_h[1 - p], Hd, Hd);
+          g.a_lo = make_seg2(sb.h_att_l[1 - p], Ha, Ha, sb.h_dec_l[1 - p], Hd, Hd);
+        } else {
+          g.a = make_seg2(sb.h_dec_h[1 - p], Hd, Hd, sb.ctx_h, D, D);
+          g.a_lo = make_seg2(sb.h_dec_l[1 - p], Hd, Hd, sb.ctx_l, D, D);
+        }
+      }
       if (use_frame(d)) {
         // raw split-K partial sums; bias, leaky-ReLU, y / s / stop rule happen in the next frame kernel
         g.out = sb.jparts; g.ldo = proj_ldp(d);
@@ -671,6 +696,9 @@ int ttsdec_pack_weights(ttsdec_handle* h, const float* const* src, int n_src, vo
   launch_copy(src[TTSDEC_W_STOP_W], b + L.proj_w + R * Mel * Dp, R * Dp, st);
   launch_copy(src[TTSDEC_W_MEL_B], b + L.proj_b, R * Mel, st);
   launch_copy(src[TTSDEC_W_STOP_B], b + L.proj_b + R * Mel, R, st);
+  launch_split(src[TTSDEC_W_QUERY_W], hp(L.wq_h), hp(L.wq_l), D * (size_t)query_ld(d), st);
+  if (src[TTSDEC_W_MEL_W] && src[TTSDEC_W_STOP_W])
+    launch_split(b + L.proj_w, hp(L.proj_h), hp(L.proj_l), (R * Mel + R) * Dp, st);
   int cin = d.d_mel;
   if (d.postnet_type == TTSDEC_POSTNET_TYPE_MEL2) {
     const int Hh = d.postnet_hidden, k = d.postnet_kernel;
@@ -721,6 +749,8 @@ int ttsdec_pack_weights(ttsdec_handle* h, const float* const* src, int n_src, vo
     launch_absmax(src[TTSDEC_W_ATT_HH], 4 * Ha * Ha, wm, st);
     launch_absmax(src[TTSDEC_W_DEC_IH], 4 * Hd * (Ha + D), wm, st);
     launch_absmax(src[TTSDEC_W_DEC_HH], 4 * Hd * Hd, wm, st);
+    launch_absmax(src[TTSDEC_W_QUERY_W], D * (size_t)query_ld(d), wm, st);
+    launch_absmax(b + L.proj_w, (R * Mel + R) * Dp, wm, st);
     if (d.postnet_type == TTSDEC_POSTNET_TYPE_MEL2) {
       const size_t Hh = d.postnet_hidden, k = d.postnet_kernel;
       const size_t n3[3] = {Hh * Mel * k, Hh * Hh * k, Mel * Hh * k};

@@ -261,6 +261,16 @@ static void launch_gemm_cfg(const GemmArgs& a, hipStream_t st) {
   // Pick the tile so the grid covers the 256 CUs when it can; small M uses 32x32 tiles
   // with the four MFMA waves splitting K.
   const long tiles_big = (long)((a.M + 63) / 64) * ((a.N + 63) / 64);
+  if constexpr (PREC == PREC_F16S && EK == EPI_PLAIN) {
+    // the step's small split-K GEMMs (query, mel/stop projection): 32x32 tiles on two MFMA waves that split a
+    // 128-element K tile, so the grid stays as wide as the exact path's (these launches are latency-bound)
+    if (tiles_big < 512) {
+      using Cfg = TileCfg<1, 1, 2, 4, PREC_F16S>;
+      dim3 grid((a.N + Cfg::BN - 1) / Cfg::BN, (a.M + Cfg::BM - 1) / Cfg::BM, a.ksplit > 1 ? a.ksplit : 1);
+      hipLaunchKernelGGL((gemm_rows_kernel<Cfg, AK, EK>), grid, dim3(kGemmThreads), 0, st, a);
+      return;
+    }
+  }
   if constexpr (PREC != PREC_F32) {
     // large 16-bit GEMMs (Postnet convs): 128x128 tiles, half-depth stages (see TileCfg)
     if (a.N >= 128 && a.M >= 2048) {
@@ -298,7 +308,9 @@ void launch_gemm(const GemmArgs& a, AKind ak, EpiKind ek, hipStream_t st) {
   if (ak == A_CONV && ek == EPI_GENERIC) return launch_gemm_prec<A_CONV, EPI_GENERIC>(a, st);
   if (ek == EPI_GENERIC) return launch_gemm_prec<A_PLAIN, EPI_GENERIC>(a, st);
   switch (ek) {
-    case EPI_PLAIN: return launch_gemm_cfg<A_PLAIN, EPI_PLAIN, PREC_F32>(a, st);
+    case EPI_PLAIN:
+      if (a.prec == PREC_F16S) return launch_gemm_cfg<A_PLAIN, EPI_PLAIN, PREC_F16S>(a, st);
+      return launch_gemm_cfg<A_PLAIN, EPI_PLAIN, PREC_F32>(a, st);
     case EPI_RELU_DROPOUT: return launch_gemm_cfg<A_PLAIN, EPI_RELU_DROPOUT, PREC_F32>(a, st);
     case EPI_PROJ: return launch_gemm_cfg<A_PLAIN, EPI_PROJ, PREC_F32>(a, st);
     case EPI_RESIDUAL: return launch_gemm_prec<A_PLAIN, EPI_RESIDUAL>(a, st);
@@ -587,7 +599,8 @@ __global__ __launch_bounds__(kAttnThreads) void attn_kernel(AttnArgs g) {
       const float p0 = isru_sigmoid(dot_row(r));  // l0-1 < L-1, never the overridden column
       w1_prev = mul_rn(wprev[l0 - 1], sub_rn(1.0f, p0));
     }
-    constexpr int G = 4;  // rows in flight per wave (8 measured slower: 17.2 vs 15.2 us - the pass is at the Infinity-Cache rate)
+    constexpr int G = 4;  // rows in flight per wave (8 measured slower, 17.2 vs 15.2 us; all 15 rows of a wave at once 18.2 vs 15.6 us at
+                          // B = 256 and no faster at B = 1: the pass runs at the Infinity-Cache rate, not at a latency chain's)
     for (int lb = l0; lb < l1; lb += G) {
       float4 r[G][NJ];
       float e[G];
