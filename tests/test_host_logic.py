@@ -34,8 +34,9 @@ def test_host_only_queries_and_layout_sizes():
     # 18 577 489 decoder params + 4 initial-state vectors + postnet, padded per tensor to 256 B
     n_dec = 86528 + 7348224 + 524288 + 10493952 + 124497
     assert n_dec == 18577489
-    # + the split-fp16 planes (hi, lo) of the four LSTM weight matrices: another 4 bytes per LSTM weight
-    n_lstm_w = 4096 * (768 + 1024) + 4096 * (1536 + 1024)
+    # + the split-fp16 planes (hi, lo) of the four LSTM weight matrices, row-major and in the chunked layout:
+    # another 2 x 4 bytes per LSTM weight
+    n_lstm_w = 2 * (4096 * (768 + 1024) + 4096 * (1536 + 1024))
     assert e.packed_bytes() >= 4 * (n_dec + n_lstm_w) and e.packed_bytes() % 256 == 0
     # + postnet fp32 (2 870 272 params incl. BN folded to alpha/beta) and its bf16 / fp16-hi / fp16-lo planes
     n_post_w = 512 * 80 * 5 + 2 * 512 * 512 * 5 + 80 * 512

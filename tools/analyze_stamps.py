@@ -1,0 +1,38 @@
+#!/usr/bin/env python3
+"""Reads the stamp file written under TTSDEC_STAMPS (csrc/api.hip) and prints, per two-role launch of the last step:
+role placement over CUs and the start / gate / end times (us, relative to the launch's first start)."""
+import sys
+from collections import Counter
+
+import numpy as np
+
+a = np.fromfile(sys.argv[1], dtype=np.uint64).reshape(2, 1024, 8)
+for kind, name in ((0, "frame || lstm_att"), (1, "attention || lstm_dec")):
+    s = a[kind]
+    used = s[:, 2] > 0
+    if not used.any():
+        continue
+    s = s[used]
+    role = (s[:, 0] >> 32).astype(int)
+    hw = (s[:, 0] & 0xFFFFFFFF).astype(int)
+    cu = ((s[:, 1].astype(int) & 0xF) << 16) | (hw & 0xFF00)  # xcc | se/sh/cu bits of HW_ID
+    t0 = int(s[:, 2].min())
+    us = lambda col: (s[:, col].astype(np.int64) - t0) / 100.0
+    print(f"== {name}: {used.sum()} workgroups stamped")
+    for r, rn in ((0, "producer"), (1, "lstm")):
+        m = role == r
+        if not m.any():
+            continue
+        st, en = us(2)[m], us(5)[m]
+        print(f"  {rn:8s} n={m.sum():4d} start {st.min():6.2f}..{st.max():6.2f}  end {en.min():6.2f}..{en.max():6.2f} (mean {en.mean():6.2f})")
+        if r == 1:
+            gi, go = us(3)[m], us(4)[m]
+            ok = s[:, 3][m] > 0
+            print(f"           gate reached {gi[ok].min():6.2f}..{gi[ok].max():6.2f} (mean {gi[ok].mean():6.2f})  passed {go[ok].min():6.2f}..{go[ok].max():6.2f} (mean {go[ok].mean():6.2f})")
+    per_cu = Counter()
+    for c, r in zip(cu, role):
+        per_cu[(c, r)] += 1
+    lstm_per_cu = Counter(v for (c, r), v in per_cu.items() if r == 1)
+    prod_per_cu = Counter(v for (c, r), v in per_cu.items() if r == 0)
+    both = sum(1 for c in set(cu) if per_cu.get((c, 0), 0) and per_cu.get((c, 1), 0))
+    print(f"  CUs seen {len(set(cu))}; lstm workgroups per CU {dict(lstm_per_cu)}; producer workgroups per CU {dict(prod_per_cu)}; CUs holding both roles {both}")

@@ -115,6 +115,50 @@ __global__ __launch_bounds__(512) void ingest_kernel(const char* a_hi, const cha
   }
 }
 
+
+// Lean-tile geometry (csrc/gemm_tile.h HK = 1): 16 KiB stages of 32 k (64-byte row pieces), 5 stages, 2 x kTiles tiles.
+// MODE 0: row-major operands (a wave-instruction covers 16 rows x 64 B = 16 half cache lines);
+// MODE 1: both operands pre-tiled (a wave-instruction reads 1 KiB contiguous); MODE 2: only B pre-tiled.
+template <int MODE, int DS>
+__global__ __launch_bounds__(512) void ingest_lean_kernel(const char* a_hi, const char* a_lo, const char* b_hi, const char* b_lo,
+                                                          const char* a_packed, const char* b_packed, int tiles, unsigned* sink) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int x = blockIdx.x & 63, y = blockIdx.x >> 6;
+  constexpr int kStage = 16 * 1024;
+  if (wave < 4) return;
+  const int w = wave - 4;
+  const int r16 = lane >> 2, c = lane & 3;
+  const int row = w * 16 + r16;
+  gbyte* p[4];  // A hi, A lo, B hi, B lo
+  const long aoff = (long)(y * 64 + row) * kRowBytes + ((c ^ ((row >> 2) & 3)) * 16);
+  const long boff = (long)(x * 64 + row) * kRowBytes + ((c ^ ((row >> 2) & 3)) * 16);
+  p[0] = (gbyte*)a_hi + aoff; p[1] = (gbyte*)a_lo + aoff; p[2] = (gbyte*)b_hi + boff; p[3] = (gbyte*)b_lo + boff;
+  int inc[4] = {64, 64, 64, 64};
+  if (MODE == 1) {
+    for (int i = 0; i < 2; ++i) { p[i] = (gbyte*)a_packed + (long)y * (2 * kTiles + 16) * 8192 + i * 4096 + w * 1024 + lane * 16; inc[i] = 8192; }
+  }
+  if (MODE >= 1) {
+    for (int i = 2; i < 4; ++i) { p[i] = (gbyte*)b_packed + (long)x * (2 * kTiles + 16) * 8192 + (i - 2) * 4096 + w * 1024 + lane * 16; inc[i] = 8192; }
+  }
+  int stage = 0;
+  auto issue = [&]() {
+    char* st = smem + stage * kStage;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      __builtin_amdgcn_global_load_lds((global_void*)p[i], (lds_void*)(st + i * 4096 + w * 1024), 16, 0, 0);
+      p[i] += inc[i];
+    }
+    stage = stage + 1 == DS ? 0 : stage + 1;
+  };
+  for (int t = 0; t < DS - 1; ++t) issue();
+  for (int t = 0; t < tiles; ++t) {
+    wait_vmcnt<(DS - 2) * 4>();
+    issue();
+  }
+  wait_vmcnt<0>();
+}
+
 #define CHECK(e) do { hipError_t _e = (e); if (_e != hipSuccess) { printf("HIP error %s at %d\n", hipGetErrorString(_e), __LINE__); exit(1); } } while (0)
 
 template <int DNA, int DNB, int DS, int RNB, int RD, int BT = 0, int AUXB = 0>
@@ -137,6 +181,30 @@ void run(const char* name, char* a_hi, char* a_lo, char* b_hi, char* b_lo, char*
   const double us = ms[0] * 1000.0 / 200, us0 = ms[1] * 1000.0 / 200;
   const double bytes = (double)kTiles * ((DNA + DNB) * 4096.0 + RNB * 4096.0);
   printf("%-44s lds %3d KiB  %6.2f us/launch (empty %5.2f)  per tile %5.3f us  %6.1f GB/s per CU (loop only %6.1f)\n", name,
+         lds / 1024, us, us0, (us - us0) / kTiles, bytes / us * 1e-3, bytes / (us - us0) * 1e-3);
+  fflush(stdout);
+}
+
+template <int MODE, int DS>
+void run_lean(const char* name, char* a_hi, char* a_lo, char* b_hi, char* b_lo, char* a_packed, char* b_packed, unsigned* sink) {
+  auto kern = ingest_lean_kernel<MODE, DS>;
+  const int lds = 16 * 1024 * DS;
+  CHECK(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+  hipEvent_t e0, e1;
+  CHECK(hipEventCreate(&e0)); CHECK(hipEventCreate(&e1));
+  float ms[2];
+  const int tl[2] = {2 * kTiles, 0};
+  for (int v = 0; v < 2; ++v) {
+    for (int i = 0; i < 20; ++i) hipLaunchKernelGGL(kern, dim3(256), dim3(512), lds, 0, a_hi, a_lo, b_hi, b_lo, a_packed, b_packed, tl[v], sink);
+    CHECK(hipEventRecord(e0));
+    for (int i = 0; i < 200; ++i) hipLaunchKernelGGL(kern, dim3(256), dim3(512), lds, 0, a_hi, a_lo, b_hi, b_lo, a_packed, b_packed, tl[v], sink);
+    CHECK(hipEventRecord(e1));
+    CHECK(hipEventSynchronize(e1));
+    CHECK(hipEventElapsedTime(&ms[v], e0, e1));
+  }
+  const double us = ms[0] * 1000.0 / 200, us0 = ms[1] * 1000.0 / 200;
+  const double bytes = (double)kTiles * 32768.0;
+  printf("%-44s lds %3d KiB  %6.2f us/launch (empty %5.2f)  per 64-k %5.3f us  %6.1f GB/s per CU (loop only %6.1f)\n", name,
          lds / 1024, us, us0, (us - us0) / kTiles, bytes / us * 1e-3, bytes / (us - us0) * 1e-3);
   fflush(stdout);
 }
@@ -175,5 +243,13 @@ int main() {
   run<4, 4, 4, 0, 1, 1, 2>("dma A+B, pre-tiled B nt, 4 stages", a_hi, a_lo, b_hi, b_lo, b_packed, sink);
   run<4, 4, 4, 0, 1, 1, 1>("dma A+B, pre-tiled B sc0, 4 stages", a_hi, a_lo, b_hi, b_lo, b_packed, sink);
   run<4, 4, 4, 0, 1, 0, 2>("dma A+B, row-major B nt, 4 stages", a_hi, a_lo, b_hi, b_lo, b_packed, sink);
+  char* a_packed;
+  CHECK(hipMalloc(&a_packed, 4 * (size_t)(2 * kTiles + 16) * 8192));
+  CHECK(hipMemset(a_packed, 6, 4 * (size_t)(2 * kTiles + 16) * 8192));
+  run_lean<0, 5>("lean 16-KiB stages x5, row-major A+B", a_hi, a_lo, b_hi, b_lo, a_packed, b_packed, sink);
+  run_lean<0, 4>("lean 16-KiB stages x4, row-major A+B", a_hi, a_lo, b_hi, b_lo, a_packed, b_packed, sink);
+  run_lean<2, 5>("lean x5, pre-tiled B", a_hi, a_lo, b_hi, b_lo, a_packed, b_packed, sink);
+  run_lean<1, 5>("lean x5, pre-tiled A+B", a_hi, a_lo, b_hi, b_lo, a_packed, b_packed, sink);
+  run_lean<1, 4>("lean x4, pre-tiled A+B", a_hi, a_lo, b_hi, b_lo, a_packed, b_packed, sink);
   return 0;
 }

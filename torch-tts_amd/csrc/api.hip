@@ -38,6 +38,8 @@ struct BlobLayout {  // offsets in floats
   size_t wq_h, wq_l, proj_h, proj_l;      // ... of the query and mel/stop projection weights
   size_t att_ih, att_hh, att_b, dec_ih, dec_hh, dec_b;
   size_t att_ih_h, att_ih_l, att_hh_h, att_hh_l, dec_ih_h, dec_ih_l, dec_hh_h, dec_hh_l;  // split-fp16 planes
+  // the same planes in the chunked layout (common.h Seg3 / launch_pack_lstm_chunked), used when chunk_ok(dims)
+  size_t att_ih_ch, att_ih_cl, att_hh_ch, att_hh_cl, dec_ih_ch, dec_ih_cl, dec_hh_ch, dec_hh_cl;
   size_t h0a, c0a, h0d, c0d;
   size_t proj_w, proj_b;
   size_t conv_w[kMaxPostnetLayers], conv_alpha[kMaxPostnetLayers], conv_beta[kMaxPostnetLayers];
@@ -54,6 +56,7 @@ struct WsLayout {  // offsets in bytes
   size_t ctrl, xpre0, xpre, ctx, h_att[2], c_att, h_dec[2], c_dec, q, ynext, w[2];
   size_t xpre_h, xpre_l, ctx_h, ctx_l, h_att_h[2], h_att_l[2], h_dec_h[2], h_dec_l[2];  // split-fp16 planes
   size_t jparts;  // split-K partial sums of the mel/stop projection [kProjSplit][B, proj_ldp]
+  size_t pa, pd;  // fp32 partial gate sums [B, 4H] of the two LSTMs' early parts (two-role step)
   size_t total;
 };
 
@@ -74,6 +77,12 @@ struct ttsdec_handle {
   const float* blob;
   std::string hip_err;
   bool use_graph;   // replay a captured hipGraph instead of launching every kernel
+  // Two-role launches (fused_kernels.hip) where they apply: 1 = frame || lstm_att (default: measured 28 us in the
+  // loop against 12.3 + 21.1 as two launches); 2 = also attention || lstm_dec (measured SLOWER, 50 against 15.3 + 27.4:
+  // the attention workgroups starve beside the LSTM's tile stream and the LSTM then waits for the slowest of them);
+  // 0 = off.  TTSDEC_OVERLAP=0/1/2 or TTSDEC_NO_OVERLAP=1 (measurement switches).
+  int overlap;
+  bool chunk_a, chunk_b;  // chunked layout of the activation planes / LSTM weight planes; TTSDEC_CHUNK_A/B=0 (measurement)
   hipStream_t cap_stream;
   bool streams_ready;
   // one cached graph: valid for exactly this (workspace, blob, B, L, precision)
@@ -101,6 +110,12 @@ inline int proj_ldp(const ttsdec_dims& d) { return (proj_n(d) + 3) & ~3; }
 // The fused frame kernel (frame_kernel.hip) covers the shipped PreNet shapes; other dims keep the
 // three-launch form (proj with its own epilogue, prenet0, prenet1).
 inline bool use_frame(const ttsdec_dims& d) { return frame_supported(d.d_mel, d.r, pre_hidden(d), d.d_pre); }
+// The chunked operand layout of the LSTM GEMMs (common.h Seg3): whole 32-element chunks in every K segment,
+// whole 16-unit blocks, and the frame kernel as the producer of the x_pre planes.
+inline bool chunk_ok(const ttsdec_dims& d) {
+  return use_frame(d) && !((d.d_pre | d.d_ctx | d.h_att | d.h_dec) & 31);
+}
+inline int rows_pad(int B) { return (B + 63) / 64 * 64; }  // rows per chunk of the activation planes
 inline int split_of(int K, int want);
 inline int query_split(const ttsdec_dims& d);
 inline int split_of(int K, int want) {  // split-K factor: slices must be whole 128-element K tiles
@@ -139,6 +154,12 @@ BlobLayout make_blob_layout(const ttsdec_dims& d) {
   L.att_hh_h = take(2 * Ha * Ha);      L.att_hh_l = take(2 * Ha * Ha);
   L.dec_ih_h = take(2 * Hd * (Ha + D)); L.dec_ih_l = take(2 * Hd * (Ha + D));
   L.dec_hh_h = take(2 * Hd * Hd);      L.dec_hh_l = take(2 * Hd * Hd);
+  if (chunk_ok(d)) {
+    L.att_ih_ch = take(2 * Ha * (P + D)); L.att_ih_cl = take(2 * Ha * (P + D));
+    L.att_hh_ch = take(2 * Ha * Ha);      L.att_hh_cl = take(2 * Ha * Ha);
+    L.dec_ih_ch = take(2 * Hd * (Ha + D)); L.dec_ih_cl = take(2 * Hd * (Ha + D));
+    L.dec_hh_ch = take(2 * Hd * Hd);      L.dec_hh_cl = take(2 * Hd * Hd);
+  }
   L.h0a = take(Ha);
   L.c0a = take(Ha);
   L.h0d = take(Hd);
@@ -204,13 +225,16 @@ WsLayout make_ws_layout(const ttsdec_dims& d, int B, int Lm) {
   W.w[0] = take(b * Lm);
   W.w[1] = take(b * Lm);
   auto takeh = [&](size_t nhalfs) { return take((nhalfs + 1) / 2); };
-  W.xpre_h = takeh(b * d.d_pre); W.xpre_l = takeh(b * d.d_pre);
-  W.ctx_h = takeh(b * d.d_ctx); W.ctx_l = takeh(b * d.d_ctx);
+  const size_t bp = (size_t)rows_pad(B);  // (the chunked layout pads the rows of a plane to whole 64-row blocks)
+  W.xpre_h = takeh(bp * d.d_pre); W.xpre_l = takeh(bp * d.d_pre);
+  W.ctx_h = takeh(bp * d.d_ctx); W.ctx_l = takeh(bp * d.d_ctx);
   for (int i = 0; i < 2; ++i) {
-    W.h_att_h[i] = takeh(b * d.h_att); W.h_att_l[i] = takeh(b * d.h_att);
-    W.h_dec_h[i] = takeh(b * d.h_dec); W.h_dec_l[i] = takeh(b * d.h_dec);
+    W.h_att_h[i] = takeh(bp * d.h_att); W.h_att_l[i] = takeh(bp * d.h_att);
+    W.h_dec_h[i] = takeh(bp * d.h_dec); W.h_dec_l[i] = takeh(bp * d.h_dec);
   }
   W.jparts = take((size_t)kProjSplit * b * proj_ldp(d));
+  W.pa = take(b * 4 * d.h_att);
+  W.pd = take(b * 4 * d.h_dec);
   W.total = off;
   return W;
 }
@@ -257,6 +281,7 @@ struct StepBufs {
   float *xpre0, *xpre, *ctx, *h_att[2], *c_att, *h_dec[2], *c_dec, *q, *ynext, *w[2];
   f16 *xpre_h, *xpre_l, *ctx_h, *ctx_l, *h_att_h[2], *h_att_l[2], *h_dec_h[2], *h_dec_l[2];
   float* jparts;
+  float *pa, *pd;
 };
 
 StepBufs carve(const WsLayout& W, void* ws) {
@@ -275,6 +300,7 @@ StepBufs carve(const WsLayout& W, void* ws) {
     s.h_dec_h[i] = hf(W.h_dec_h[i]); s.h_dec_l[i] = hf(W.h_dec_l[i]);
   }
   s.jparts = f(W.jparts);
+  s.pa = f(W.pa); s.pd = f(W.pd);
   return s;
 }
 
@@ -298,7 +324,11 @@ struct StepIo {
 // The kernels of one decode step.  N_F is the fused frame kernel (finish the previous step's
 // projection + both PreNet layers), N_FIN its end-of-call form; N_P0 / N_P1 are the separate
 // PreNet layers used when the dims are outside what the frame kernel covers.
-enum Node { N_F, N_FIN, N_P0, N_P1, N_A, N_Q, N_T, N_D, N_J };
+// Two-role step (fused_kernels.hip): N_FA = frame || attention LSTM, N_TD = attention || decoder LSTM;
+// N_AG / N_DG are those LSTMs alone on the lean tile (profiling).
+enum Node { N_F, N_FIN, N_P0, N_P1, N_A, N_Q, N_T, N_D, N_J, N_FA, N_TD, N_AG, N_DG };
+// PART_GATED: the whole cell with the segment that waits for the other role of the launch LAST
+enum LstmPart { PART_WHOLE = 0, PART_EARLY = 1, PART_LATE = 2, PART_GATED = 3 };
 
 constexpr int kMaxKernelsPerStep = 7;
 struct StepOrder {
@@ -310,7 +340,7 @@ struct StepOrder {
 // split-fp16 needs every K segment to be whole 16-byte columns of fp16 (multiples of 8)
 bool split_ok(const ttsdec_dims& d) { return !((d.d_pre | d.d_ctx | d.h_att | d.h_dec) & 7); }
 // launch order of one step: the Prod cell attends between its two LSTMs, the Taco2 cell after both
-const StepOrder& step_order(const ttsdec_dims& d);
+const StepOrder& step_order(const ttsdec_handle* h, int B);
 int lstm_prec(const ttsdec_handle* h) {
   return (h->precision == TTSDEC_PREC_SPLIT_F16 && split_ok(h->d) && h->wmax_dec < kSplitMax) ? 1 : 0;
 }
@@ -337,34 +367,150 @@ void launch_node(const ttsdec_handle* h, const StepBufs& sb, const StepIo& io, N
   const float keep_scale = 1.0f / (1.0f - d.p_dropout);
   const int prec = lstm_prec(h);
   auto plane = [&](size_t float_off) { return reinterpret_cast<const f16*>(blob + float_off); };
+  // chunked operand layout of the split-fp16 planes (0 = row-major)
+  const int mpad = (prec && chunk_ok(d) && h->chunk_a) ? rows_pad(B) : 0;
+  auto act = [&](Seg3 s) { return chunked(s, mpad); };  // an activation-plane segment list in the layout in use
+
+  auto frame_args = [&](bool fin_only) {
+    FrameArgs f;
+    memset(&f, 0, sizeof(f));
+    const int Ph = pre_hidden(d);
+    f.parts = sb.jparts; f.n_parts = split_of(proj_k(d), kProjSplit); f.ldp = proj_ldp(d);
+    f.part_stride = (size_t)B * proj_ldp(d);
+    f.proj_bias = blob + bl.proj_b;
+    f.y_out = io.y; f.s_out = io.s; f.ynext = sb.ynext;
+    f.r = d.r; f.d_mel = d.d_mel; f.t_rel = io.t_rel; f.t_stride = io.t_stride;
+    f.finalize = io.finalize; f.only_finalize = fin_only ? 1 : 0;
+    f.dbg = io.dbg;
+    if (io.dbg & 1) f.finalize = 0;       // measurement ablations (profile_step only)
+    if (io.dbg & 8) f.only_finalize = 1;
+    f.W0 = blob + bl.pre0_w; f.b0 = blob + bl.pre0_b; f.W1 = blob + bl.pre1_w; f.b1 = blob + bl.pre1_b;
+    f.W0h = plane(bl.pre0_h); f.W0l = plane(bl.pre0_l); f.W1h = plane(bl.pre1_h); f.W1l = plane(bl.pre1_l);
+    f.prec = prec ? PREC_F16S : PREC_F32;
+    f.Ph = Ph; f.P = P;
+    f.dropout_mode = io.dropout_mode; f.masks = io.masks; f.mask_step_stride = (size_t)B * (Ph + P);
+    f.seed = io.seed; f.keep_scale = keep_scale;
+    f.xpre = sb.xpre;
+    if (prec) { f.xpre_h = sb.xpre_h; f.xpre_l = sb.xpre_l; f.out_mpad = mpad; }
+    f.M = B; f.ctrl = ctrl; f.slot = io.slot; f.t = io.t;
+    return f;
+  };
+  // One LSTM cell as a whole, or cut along its K axis (fused_kernels.hip): EARLY = the segments that do not wait
+  // for the launch just before the cell (raw gate sums parked in `partial`), LATE = the segment that does, plus
+  // the parked sums, then the cell update.  which = 0: attention LSTM, cat[x_pre, ctx_prev | h_att]
+  // (decoder_cell.py:187), early = [ctx_prev | h_att]; which = 1: decoder LSTM, cat[h_att, ctx | h_dec] (:191),
+  // early = [h_att | h_dec].
+  auto lstm_args = [&](int which, LstmPart part) {
+    LstmArgs a;
+    memset(&a, 0, sizeof(a));
+    a.prec = prec;
+    const int H = which ? Hd : Ha;
+    const int k0 = which ? Ha : P;  // W_ih = [seg0 | ctx] columns
+    const void *x0, *x0l, *x1, *x1l, *x2, *x2l;
+    if (which == 0) {
+      x0 = prec ? (const void*)sb.xpre_h : sb.xpre; x0l = prec ? (const void*)sb.xpre_l : sb.xpre;
+      x2 = prec ? (const void*)sb.h_att_h[p] : sb.h_att[p]; x2l = prec ? (const void*)sb.h_att_l[p] : sb.h_att[p];
+    } else {
+      x0 = prec ? (const void*)sb.h_att_h[1 - p] : sb.h_att[1 - p]; x0l = prec ? (const void*)sb.h_att_l[1 - p] : sb.h_att[1 - p];
+      x2 = prec ? (const void*)sb.h_dec_h[p] : sb.h_dec[p]; x2l = prec ? (const void*)sb.h_dec_l[p] : sb.h_dec[p];
+    }
+    x1 = prec ? (const void*)sb.ctx_h : sb.ctx; x1l = prec ? (const void*)sb.ctx_l : sb.ctx;
+    const bool ck = prec && chunk_ok(d) && h->chunk_b;
+    const size_t o_ih_h = which ? (ck ? bl.dec_ih_ch : bl.dec_ih_h) : (ck ? bl.att_ih_ch : bl.att_ih_h);
+    const size_t o_ih_l = which ? (ck ? bl.dec_ih_cl : bl.dec_ih_l) : (ck ? bl.att_ih_cl : bl.att_ih_l);
+    const size_t o_hh_h = which ? (ck ? bl.dec_hh_ch : bl.dec_hh_h) : (ck ? bl.att_hh_ch : bl.att_hh_h);
+    const size_t o_hh_l = which ? (ck ? bl.dec_hh_cl : bl.dec_hh_l) : (ck ? bl.att_hh_cl : bl.att_hh_l);
+    const f16 *wih_h = plane(o_ih_h), *wih_l = plane(o_ih_l), *whh_h = plane(o_hh_h), *whh_l = plane(o_hh_l);
+    const float *wih = blob + (which ? bl.dec_ih : bl.att_ih), *whh = blob + (which ? bl.dec_hh : bl.att_hh);
+    // column k0 of W_ih: row-major + k0 elements; chunked: chunk k0 / 32 of unit block 0 = k0 / 32 * (64 rows * 32) elements
+    const size_t w1_off = ck ? (size_t)k0 * 64 : (size_t)k0;
+    auto W0 = [&](bool lo) { return prec ? (const void*)(lo ? wih_l : wih_h) : (const void*)wih; };
+    auto W1 = [&](bool lo) { return prec ? (const void*)((lo ? wih_l : wih_h) + w1_off) : (const void*)(wih + k0); };
+    auto W2 = [&](bool lo) { return prec ? (const void*)(lo ? whh_l : whh_h) : (const void*)whh; };
+    // leading "dimension" of a weight segment: row-major elements per row, or (chunked) the matrix's chunks per unit block
+    const int wld_ih = ck ? (k0 + D) / kChunkK : k0 + D, wld_hh = ck ? H / kChunkK : H;
+    if (part == PART_WHOLE) {
+      a.a = act(make_seg3(x0, k0, k0, x1, D, D, x2, H, H)); a.a_lo = act(make_seg3(x0l, k0, k0, x1l, D, D, x2l, H, H));
+      a.w = make_seg3(W0(false), wld_ih, k0, W1(false), wld_ih, D, W2(false), wld_hh, H);
+      a.w_lo = make_seg3(W0(true), wld_ih, k0, W1(true), wld_ih, D, W2(true), wld_hh, H);
+      a.K = k0 + D + H;
+    } else if (part == PART_GATED && which == 0) {
+      // [ctx_prev | h_att | x_pre]: x_pre is written by the frame role of the same launch
+      a.a = act(make_seg3(x1, D, D, x2, H, H, x0, k0, k0)); a.a_lo = act(make_seg3(x1l, D, D, x2l, H, H, x0l, k0, k0));
+      a.w = make_seg3(W1(false), wld_ih, D, W2(false), wld_hh, H, W0(false), wld_ih, k0);
+      a.w_lo = make_seg3(W1(true), wld_ih, D, W2(true), wld_hh, H, W0(true), wld_ih, k0);
+      a.K = k0 + D + H;
+      a.dep_n = frame_grid_size(B, P); a.dep_seg = 2; a.dep_which = 0;
+      a.live_lag = 1;  // (same launch as the frame kernel: see lstm_body)
+    } else if (part == PART_GATED) {
+      // [h_att | h_dec | ctx]: ctx is written by the attention role of the same launch
+      a.a = act(make_seg3(x0, k0, k0, x2, H, H, x1, D, D)); a.a_lo = act(make_seg3(x0l, k0, k0, x2l, H, H, x1l, D, D));
+      a.w = make_seg3(W0(false), wld_ih, k0, W2(false), wld_hh, H, W1(false), wld_ih, D);
+      a.w_lo = make_seg3(W0(true), wld_ih, k0, W2(true), wld_hh, H, W1(true), wld_ih, D);
+      a.K = k0 + D + H;
+      a.dep_n = B; a.dep_seg = 2; a.dep_which = 1;
+    } else if (which == 0 ? part == PART_EARLY : part == PART_LATE) {
+      // [ctx (| h_att)]: the attention LSTM's early part, or the decoder LSTM's late part (ctx alone)
+      const int kh = which == 0 ? H : 0;
+      a.a = act(make_seg2(x1, D, D, x2, H, kh)); a.a_lo = act(make_seg2(x1l, D, D, x2l, H, kh));
+      a.w = make_seg2(W1(false), wld_ih, D, W2(false), wld_hh, kh); a.w_lo = make_seg2(W1(true), wld_ih, D, W2(true), wld_hh, kh);
+      a.K = D + kh;
+    } else {
+      // [seg0 (| h_dec)]: the attention LSTM's late part (x_pre alone), or the decoder LSTM's early part
+      const int kh = which == 1 ? H : 0;
+      a.a = act(make_seg2(x0, k0, k0, x2, H, kh)); a.a_lo = act(make_seg2(x0l, k0, k0, x2l, H, kh));
+      a.w = make_seg2(W0(false), wld_ih, k0, W2(false), wld_hh, kh); a.w_lo = make_seg2(W0(true), wld_ih, k0, W2(true), wld_hh, kh);
+      a.K = k0 + kh;
+    }
+    if (ck) { a.w.mpad = 1; a.w_lo.mpad = 1; }  // (flag: LoaderWLstm reads the chunked weight image)
+    a.mode = part == PART_GATED ? 0 : (int)part;
+    a.partial = which ? sb.pd : sb.pa;
+    if (prec) { a.h_out_h = which ? sb.h_dec_h[1 - p] : sb.h_att_h[1 - p]; a.h_out_l = which ? sb.h_dec_l[1 - p] : sb.h_att_l[1 - p]; a.out_mpad = mpad; }
+    a.bsum = blob + (which ? bl.dec_b : bl.att_b);
+    a.h_prev = which ? sb.h_dec[p] : sb.h_att[p];
+    a.c = which ? sb.c_dec : sb.c_att;
+    a.h_out = which ? sb.h_dec[1 - p] : sb.h_att[1 - p];
+    a.M = B; a.H = H; a.pz = d.p_zoneout; a.ctrl = ctrl; a.slot = io.slot; a.dbg = io.dbg;
+    a.tag = which;
+    return a;
+  };
+  auto attn_args = [&]() {
+    AttnArgs a;
+    memset(&a, 0, sizeof(a));
+    if (prec) { a.ctx_h = sb.ctx_h; a.ctx_l = sb.ctx_l; a.out_mpad = mpad; }
+    a.memory = io.memory; a.q = sb.q; a.q_parts = query_split(d); a.q_stride = (size_t)B * D;
+    a.w_prev = sb.w[p]; a.w_new = sb.w[1 - p]; a.w_out = io.w; a.ctx = sb.ctx;
+    a.B = B; a.L = io.L; a.D = D; a.t_rel = io.t_rel; a.t_stride = io.t_stride; a.ctrl = ctrl; a.slot = io.slot;
+    return a;
+  };
 
   switch (node) {
     case N_F:
-    case N_FIN: {
-      FrameArgs f;
-      memset(&f, 0, sizeof(f));
-      const int Ph = pre_hidden(d);
-      f.parts = sb.jparts; f.n_parts = split_of(proj_k(d), kProjSplit); f.ldp = proj_ldp(d);
-      f.part_stride = (size_t)B * proj_ldp(d);
-      f.proj_bias = blob + bl.proj_b;
-      f.y_out = io.y; f.s_out = io.s; f.ynext = sb.ynext;
-      f.r = d.r; f.d_mel = d.d_mel; f.t_rel = io.t_rel; f.t_stride = io.t_stride;
-      f.finalize = io.finalize; f.only_finalize = node == N_FIN ? 1 : 0;
-      f.dbg = io.dbg;
-      if (io.dbg & 1) f.finalize = 0;       // measurement ablations (profile_step only)
-      if (io.dbg & 8) f.only_finalize = 1;
-      f.W0 = blob + bl.pre0_w; f.b0 = blob + bl.pre0_b; f.W1 = blob + bl.pre1_w; f.b1 = blob + bl.pre1_b;
-      f.W0h = plane(bl.pre0_h); f.W0l = plane(bl.pre0_l); f.W1h = plane(bl.pre1_h); f.W1l = plane(bl.pre1_l);
-      f.prec = prec ? PREC_F16S : PREC_F32;
-      f.Ph = Ph; f.P = P;
-      f.dropout_mode = io.dropout_mode; f.masks = io.masks; f.mask_step_stride = (size_t)B * (Ph + P);
-      f.seed = io.seed; f.keep_scale = keep_scale;
-      f.xpre = sb.xpre;
-      if (prec) { f.xpre_h = sb.xpre_h; f.xpre_l = sb.xpre_l; }
-      f.M = B; f.ctrl = ctrl; f.slot = io.slot; f.t = io.t;
-      launch_frame(f, st);
+    case N_FIN:
+      launch_frame(frame_args(node == N_FIN), st);
+      break;
+    case N_FA: {
+      FrameArgs f = frame_args(false);
+      f.dep_signal = 1;
+      launch_frame_lstm(f, lstm_args(0, PART_GATED), st);
       break;
     }
+    case N_TD: {
+      AttnArgs a = attn_args();
+      a.dep_signal = 1;
+      launch_attn_lstm(a, lstm_args(1, PART_GATED), st);
+      break;
+    }
+    case N_AG:
+    case N_DG: {
+      LstmArgs l = lstm_args(node == N_DG ? 1 : 0, PART_GATED);
+      l.dep_n = 0;  // (alone: nothing to wait for)
+      launch_lstm_lean(l, st);
+      break;
+    }
+    case N_A: launch_lstm(lstm_args(0, PART_WHOLE), st); break;
+    case N_D: launch_lstm(lstm_args(1, PART_WHOLE), st); break;
+    case N_T: launch_attn(attn_args(), st); break;
     case N_P0:
     case N_P1: {
       const int layer = node == N_P0 ? 0 : 1;
@@ -393,30 +539,6 @@ void launch_node(const ttsdec_handle* h, const StepBufs& sb, const StepIo& io, N
       launch_gemm(g, A_PLAIN, EPI_RELU_DROPOUT, st);
       break;
     }
-    case N_A: {
-      // attention LSTM: input cat[x_pre, ctx_prev] (decoder_cell.py:187), state h_att
-      LstmArgs a;
-      memset(&a, 0, sizeof(a));
-      a.prec = prec;
-      const int wld = P + D;
-      // segment lists: whole = [x_pre | ctx | h], early = [ctx | h], late = [x_pre]
-      const void *x0 = prec ? (const void*)sb.xpre_h : sb.xpre, *x0l = prec ? (const void*)sb.xpre_l : sb.xpre;
-      const void *x1 = prec ? (const void*)sb.ctx_h : sb.ctx, *x1l = prec ? (const void*)sb.ctx_l : sb.ctx;
-      const void *x2 = prec ? (const void*)sb.h_att_h[p] : sb.h_att[p], *x2l = prec ? (const void*)sb.h_att_l[p] : sb.h_att[p];
-      const f16 *wih_h = plane(bl.att_ih_h), *wih_l = plane(bl.att_ih_l), *whh_h = plane(bl.att_hh_h), *whh_l = plane(bl.att_hh_l);
-      const float *wih = blob + bl.att_ih, *whh = blob + bl.att_hh;
-      auto W0 = [&](bool lo) { return prec ? (const void*)(lo ? wih_l : wih_h) : (const void*)wih; };
-      auto W1 = [&](bool lo) { return prec ? (const void*)((lo ? wih_l : wih_h) + P) : (const void*)(wih + P); };
-      auto W2 = [&](bool lo) { return prec ? (const void*)(lo ? whh_l : whh_h) : (const void*)whh; };
-      a.a = make_seg3(x0, P, P, x1, D, D, x2, Ha, Ha); a.a_lo = make_seg3(x0l, P, P, x1l, D, D, x2l, Ha, Ha);
-      a.w = make_seg3(W0(false), wld, P, W1(false), wld, D, W2(false), Ha, Ha);
-      a.w_lo = make_seg3(W0(true), wld, P, W1(true), wld, D, W2(true), Ha, Ha);
-      if (prec) { a.h_out_h = sb.h_att_h[1 - p]; a.h_out_l = sb.h_att_l[1 - p]; }
-      a.bsum = blob + bl.att_b; a.h_prev = sb.h_att[p]; a.c = sb.c_att; a.h_out = sb.h_att[1 - p];
-      a.M = B; a.H = Ha; a.K = P + D + Ha; a.pz = d.p_zoneout; a.ctrl = ctrl; a.slot = io.slot; a.dbg = io.dbg;
-      launch_lstm(a, st);
-      break;
-    }
     case N_Q: {
       GemmArgs g;
       memset(&g, 0, sizeof(g));
@@ -428,50 +550,16 @@ void launch_node(const ttsdec_handle* h, const StepBufs& sb, const StepIo& io, N
         g.prec = PREC_F16S;
         g.W = plane(bl.wq_h); g.W_lo = plane(bl.wq_l);
         if (is_taco2(d)) {
-          g.a = make_seg2(sb.h_att_h[1 - p], Ha, Ha, sb.h_dec_h[1 - p], Hd, Hd);
-          g.a_lo = make_seg2(sb.h_att_l[1 - p], Ha, Ha, sb.h_dec_l[1 - p], Hd, Hd);
+          g.a = act(make_seg2(sb.h_att_h[1 - p], Ha, Ha, sb.h_dec_h[1 - p], Hd, Hd));
+          g.a_lo = act(make_seg2(sb.h_att_l[1 - p], Ha, Ha, sb.h_dec_l[1 - p], Hd, Hd));
         } else {
-          g.a = make_seg1(sb.h_att_h[1 - p], Ha, Ha);
-          g.a_lo = make_seg1(sb.h_att_l[1 - p], Ha, Ha);
+          g.a = act(make_seg1(sb.h_att_h[1 - p], Ha, Ha));
+          g.a_lo = act(make_seg1(sb.h_att_l[1 - p], Ha, Ha));
         }
       }
       g.ksplit = query_split(d); g.kchunk = g.K / g.ksplit; g.split_stride = (size_t)B * D;
       g.ctrl = ctrl; g.slot = io.slot; g.t = io.t;
       launch_gemm(g, A_PLAIN, EPI_PLAIN, st);
-      break;
-    }
-    case N_T: {
-      AttnArgs a;
-      memset(&a, 0, sizeof(a));
-      if (prec) { a.ctx_h = sb.ctx_h; a.ctx_l = sb.ctx_l; }
-      a.memory = io.memory; a.q = sb.q; a.q_parts = query_split(d); a.q_stride = (size_t)B * D;
-      a.w_prev = sb.w[p]; a.w_new = sb.w[1 - p]; a.w_out = io.w; a.ctx = sb.ctx;
-      a.B = B; a.L = io.L; a.D = D; a.t_rel = io.t_rel; a.t_stride = io.t_stride; a.ctrl = ctrl; a.slot = io.slot;
-      launch_attn(a, st);
-      break;
-    }
-    case N_D: {
-      // decoder LSTM: input cat[h_att, ctx] (decoder_cell.py:191), state h_dec
-      LstmArgs a;
-      memset(&a, 0, sizeof(a));
-      a.prec = prec;
-      const int wld = Ha + D;
-      const void *x0 = prec ? (const void*)sb.h_att_h[1 - p] : sb.h_att[1 - p], *x0l = prec ? (const void*)sb.h_att_l[1 - p] : sb.h_att[1 - p];
-      const void *x1 = prec ? (const void*)sb.ctx_h : sb.ctx, *x1l = prec ? (const void*)sb.ctx_l : sb.ctx;
-      const void *x2 = prec ? (const void*)sb.h_dec_h[p] : sb.h_dec[p], *x2l = prec ? (const void*)sb.h_dec_l[p] : sb.h_dec[p];
-      const f16 *wih_h = plane(bl.dec_ih_h), *wih_l = plane(bl.dec_ih_l), *whh_h = plane(bl.dec_hh_h), *whh_l = plane(bl.dec_hh_l);
-      const float *wih = blob + bl.dec_ih, *whh = blob + bl.dec_hh;
-      auto W0 = [&](bool lo) { return prec ? (const void*)(lo ? wih_l : wih_h) : (const void*)wih; };
-      auto W1 = [&](bool lo) { return prec ? (const void*)((lo ? wih_l : wih_h) + Ha) : (const void*)(wih + Ha); };
-      auto W2 = [&](bool lo) { return prec ? (const void*)(lo ? whh_l : whh_h) : (const void*)whh; };
-      a.a = make_seg3(x0, Ha, Ha, x1, D, D, x2, Hd, Hd); a.a_lo = make_seg3(x0l, Ha, Ha, x1l, D, D, x2l, Hd, Hd);
-      a.w = make_seg3(W0(false), wld, Ha, W1(false), wld, D, W2(false), Hd, Hd);
-      a.w_lo = make_seg3(W0(true), wld, Ha, W1(true), wld, D, W2(true), Hd, Hd);
-      if (prec) { a.h_out_h = sb.h_dec_h[1 - p]; a.h_out_l = sb.h_dec_l[1 - p]; }
-      a.bsum = blob + bl.dec_b; a.h_prev = sb.h_dec[p]; a.c = sb.c_dec; a.h_out = sb.h_dec[1 - p];
-      a.M = B; a.H = Hd; a.K = Ha + D + Hd; a.pz = d.p_zoneout; a.ctrl = ctrl; a.slot = io.slot; a.dbg = io.dbg;
-      a.tag = 1;
-      launch_lstm(a, st);
       break;
     }
     case N_J: {
@@ -486,11 +574,11 @@ void launch_node(const ttsdec_handle* h, const StepBufs& sb, const StepIo& io, N
         g.prec = PREC_F16S;
         g.W = plane(bl.proj_h); g.W_lo = plane(bl.proj_l);
         if (is_taco2(d)) {
-          g.a = make_seg2(sb.h_att_h[1 - p], Ha, Ha, sb.h_dec_h[1 - p], Hd, Hd);
-          g.a_lo = make_seg2(sb.h_att_l[1 - p], Ha, Ha, sb.h_dec_l[1 - p], Hd, Hd);
+          g.a = act(make_seg2(sb.h_att_h[1 - p], Ha, Ha, sb.h_dec_h[1 - p], Hd, Hd));
+          g.a_lo = act(make_seg2(sb.h_att_l[1 - p], Ha, Ha, sb.h_dec_l[1 - p], Hd, Hd));
         } else {
-          g.a = make_seg2(sb.h_dec_h[1 - p], Hd, Hd, sb.ctx_h, D, D);
-          g.a_lo = make_seg2(sb.h_dec_l[1 - p], Hd, Hd, sb.ctx_l, D, D);
+          g.a = act(make_seg2(sb.h_dec_h[1 - p], Hd, Hd, sb.ctx_h, D, D));
+          g.a_lo = act(make_seg2(sb.h_dec_l[1 - p], Hd, Hd, sb.ctx_l, D, D));
         }
       }
       if (use_frame(d)) {
@@ -515,7 +603,16 @@ const StepOrder kOrderTaco2 = {7, {N_P0, N_P1, N_A, N_D, N_Q, N_T, N_J},  // dec
                                {"prenet0", "prenet1", "lstm_att", "lstm_dec", "query", "attention", "proj"}};
 const StepOrder kOrderProdF = {6, {N_F, N_A, N_Q, N_T, N_D, N_J}, {"prenet", "lstm_att", "query", "attention", "lstm_dec", "proj"}};
 const StepOrder kOrderTaco2F = {6, {N_F, N_A, N_D, N_Q, N_T, N_J}, {"prenet", "lstm_att", "lstm_dec", "query", "attention", "proj"}};
-const StepOrder& step_order(const ttsdec_dims& d) {
+const StepOrder kOrderProdO = {5, {N_FA, N_Q, N_T, N_D, N_J}, {"prenet+lstm_att", "query", "attention", "lstm_dec", "proj"}};
+const StepOrder kOrderProdO2 = {4, {N_FA, N_Q, N_TD, N_J}, {"prenet+lstm_att", "query", "attention+lstm_dec", "proj"}};
+// the two-role step: LJSpeech-type cell, split-fp16, batches that fill the chip with 64-row tiles
+bool use_overlap(const ttsdec_handle* h, int B) {
+  const ttsdec_dims& d = h->d;
+  return h->overlap > 0 && !is_taco2(d) && lstm_prec(h) && B >= 192 && fused_supported(d.d_mel, d.r, pre_hidden(d), d.d_pre, d.d_ctx);
+}
+const StepOrder& step_order(const ttsdec_handle* h, int B) {
+  const ttsdec_dims& d = h->d;
+  if (use_overlap(h, B)) return h->overlap >= 2 ? kOrderProdO2 : kOrderProdO;
   if (use_frame(d)) return is_taco2(d) ? kOrderTaco2F : kOrderProdF;
   return is_taco2(d) ? kOrderTaco2 : kOrderProd;
 }
@@ -524,7 +621,7 @@ const StepOrder& step_order(const ttsdec_dims& d) {
 // kernel at the end of step t also produces the context bmm(w_t, memory) that step t+1 starts
 // from, decoder_cell.py:118.)
 void launch_step_serial(const ttsdec_handle* h, const StepBufs& sb, const StepIo& io, hipStream_t st) {
-  const StepOrder& order = step_order(h->d);
+  const StepOrder& order = step_order(h, io.B);
   for (int i = 0; i < order.n; ++i) launch_node(h, sb, io, order.nodes[i], st);
 }
 
@@ -619,6 +716,11 @@ int ttsdec_create(const ttsdec_dims* dims, ttsdec_handle** out) {
   // queue behind them - and was removed; see DESIGN.md.)
   const char* e2 = getenv("TTSDEC_NO_GRAPH");
   h->use_graph = !(e2 && atoi(e2));
+  const char *e3 = getenv("TTSDEC_NO_OVERLAP"), *e3b = getenv("TTSDEC_OVERLAP");
+  h->overlap = (e3 && atoi(e3)) ? 0 : (e3b ? atoi(e3b) : 1);
+  const char *e4 = getenv("TTSDEC_CHUNK_A"), *e5 = getenv("TTSDEC_CHUNK_B");
+  h->chunk_a = !(e4 && !atoi(e4));
+  h->chunk_b = !(e5 && !atoi(e5));
   h->device = current_device_or_minus1();
   *out = h;
   return TTSDEC_OK;
@@ -687,6 +789,12 @@ int ttsdec_pack_weights(ttsdec_handle* h, const float* const* src, int n_src, vo
   launch_split(src[TTSDEC_W_ATT_HH], hp(L.att_hh_h), hp(L.att_hh_l), 4 * Ha * Ha, st);
   launch_split(src[TTSDEC_W_DEC_IH], hp(L.dec_ih_h), hp(L.dec_ih_l), 4 * Hd * (Ha + D), st);
   launch_split(src[TTSDEC_W_DEC_HH], hp(L.dec_hh_h), hp(L.dec_hh_l), 4 * Hd * Hd, st);
+  if (chunk_ok(d)) {
+    launch_pack_lstm_chunked(src[TTSDEC_W_ATT_IH], hp(L.att_ih_ch), hp(L.att_ih_cl), (int)Ha, (int)(P + D), st);
+    launch_pack_lstm_chunked(src[TTSDEC_W_ATT_HH], hp(L.att_hh_ch), hp(L.att_hh_cl), (int)Ha, (int)Ha, st);
+    launch_pack_lstm_chunked(src[TTSDEC_W_DEC_IH], hp(L.dec_ih_ch), hp(L.dec_ih_cl), (int)Hd, (int)(Ha + D), st);
+    launch_pack_lstm_chunked(src[TTSDEC_W_DEC_HH], hp(L.dec_hh_ch), hp(L.dec_hh_cl), (int)Hd, (int)Hd, st);
+  }
   launch_copy(src[TTSDEC_W_INIT_H0], b + L.h0a, Ha, st);
   launch_copy(src[TTSDEC_W_INIT_C0], b + L.c0a, Ha, st);
   launch_copy(src[TTSDEC_W_INIT_H1], b + L.h0d, Hd, st);
@@ -817,6 +925,7 @@ int ttsdec_decode(ttsdec_handle* h, const float* memory, int B, int L, int t_beg
     ia.ctx = sb.ctx; ia.w = sb.w[0]; ia.ynext = sb.ynext;
     ia.h_att_h = sb.h_att_h[0]; ia.h_att_l = sb.h_att_l[0]; ia.h_dec_h = sb.h_dec_h[0]; ia.h_dec_l = sb.h_dec_l[0];
     ia.ctx_h = sb.ctx_h; ia.ctx_l = sb.ctx_l;
+    ia.out_mpad = (lstm_prec(h) && chunk_ok(d) && h->chunk_a) ? rows_pad(B) : 0;
     ia.memory = is_taco2(d) ? memory : nullptr;
     ia.B = B; ia.L = L; ia.D = d.d_ctx; ia.Ha = d.h_att; ia.Hd = d.h_dec; ia.d_mel = d.d_mel;
     launch_init(ia, st);
@@ -826,6 +935,16 @@ int ttsdec_decode(ttsdec_handle* h, const float* memory, int B, int L, int t_beg
   ca.dropout_mode = dropout_mode; ca.teacher_T = teacher_T; ca.stop_thr = stop_threshold; ca.seed = seed;
   ca.memory = memory; ca.masks = masks; ca.teacher = teacher; ca.teacher_flags = teacher_flags;
   ca.y = y; ca.s = s; ca.w = w;
+  // measurement only: TTSDEC_STAMPS=<file> collects per-workgroup time stamps of the two-role launches of the
+  // call's last step and writes them to <file> (synchronises; never set in production)
+  static unsigned long long* g_stamps = nullptr;
+  const char* stamp_file = getenv("TTSDEC_STAMPS");
+  ca.stamps = nullptr;
+  if (stamp_file && *stamp_file) {
+    if (!g_stamps) { HIP_TRY(h, hipMalloc(&g_stamps, 2 * 1024 * 8 * sizeof(unsigned long long))); }
+    HIP_TRY(h, hipMemsetAsync(g_stamps, 0, 2 * 1024 * 8 * sizeof(unsigned long long), st));
+    ca.stamps = g_stamps;
+  }
   launch_set_call(sb.ctrl, ca, st);
 
   StepIo io;
@@ -843,6 +962,12 @@ int ttsdec_decode(ttsdec_handle* h, const float* memory, int B, int L, int t_beg
   }
   if (use_frame(d)) launch_node(h, sb, io, N_FIN, st);  // the last step's frame: y, s, stop rule, next input
   launch_finish(sb.ctrl, T_out, st);
+  if (ca.stamps) {
+    std::string buf(2 * 1024 * 8 * sizeof(unsigned long long), '\0');
+    HIP_TRY(h, hipStreamSynchronize(st));
+    HIP_TRY(h, hipMemcpy(&buf[0], ca.stamps, buf.size(), hipMemcpyDeviceToHost));
+    if (FILE* f = fopen(stamp_file, "wb")) { fwrite(buf.data(), 1, buf.size(), f); fclose(f); }
+  }
   return check_launch(h, "decode");
 }
 
@@ -1032,7 +1157,12 @@ int ttsdec_cell_step(ttsdec_handle* h, const float* x, const float* memory, int 
   launch_copy(h_dec, sb.h_dec[p], b * d.h_dec, st);
   launch_copy(c_dec, sb.c_dec, b * d.h_dec, st);
   const int prec = lstm_prec(h);
-  if (prec) {
+  if (prec && chunk_ok(d) && h->chunk_a) {
+    const int mp = rows_pad(B);
+    if (!t2) launch_split_chunked(ctx, sb.ctx_h, sb.ctx_l, B, d.d_ctx, mp, st);
+    launch_split_chunked(h_att, sb.h_att_h[p], sb.h_att_l[p], B, d.h_att, mp, st);
+    launch_split_chunked(h_dec, sb.h_dec_h[p], sb.h_dec_l[p], B, d.h_dec, mp, st);
+  } else if (prec) {
     if (!t2) launch_split(ctx, sb.ctx_h, sb.ctx_l, b * d.d_ctx, st);
     launch_split(h_att, sb.h_att_h[p], sb.h_att_l[p], b * d.h_att, st);
     launch_split(h_dec, sb.h_dec_h[p], sb.h_dec_l[p], b * d.h_dec, st);
@@ -1048,7 +1178,7 @@ int ttsdec_cell_step(ttsdec_handle* h, const float* x, const float* memory, int 
     AttnArgs a;
     memset(&a, 0, sizeof(a));
     a.memory = memory; a.w_prev = sb.w[p]; a.w_new = sb.w[1 - p]; a.ctx = sb.ctx; a.ctx_only = 1;
-    if (prec) { a.ctx_h = sb.ctx_h; a.ctx_l = sb.ctx_l; }
+    if (prec) { a.ctx_h = sb.ctx_h; a.ctx_l = sb.ctx_l; a.out_mpad = (chunk_ok(d) && h->chunk_a) ? rows_pad(B) : 0; }
     a.B = B; a.L = L; a.D = d.d_ctx; a.t_stride = 1;
     launch_attn(a, st);
     if (use_frame(d)) launch_node(h, sb, io, N_F, st);  // (io.finalize = 0: the input frame is x itself)
@@ -1095,7 +1225,7 @@ int ttsdec_profile_step(ttsdec_handle* h, const float* memory, int B, int L, int
                         size_t workspace_bytes, void* stream, float* ms_out, const char** names_out, int n_out,
                         int* n_kernels) {
   if (!h || !memory || !y || !s || !w || !workspace || !ms_out || iters <= 0) return TTSDEC_ERR_INVALID_ARG;
-  const StepOrder& order = step_order(h->d);
+  const StepOrder& order = step_order(h, B);
   if (n_kernels) *n_kernels = order.n;
   if (n_out < order.n) return TTSDEC_ERR_INVALID_ARG;
   if (dropout_mode == TTSDEC_DROPOUT_MASKS && !masks) return TTSDEC_ERR_INVALID_ARG;
@@ -1117,8 +1247,19 @@ int ttsdec_profile_step(ttsdec_handle* h, const float* memory, int B, int L, int
   hipEvent_t e0, e1;
   HIP_TRY(h, hipEventCreate(&e0));
   HIP_TRY(h, hipEventCreate(&e1));
-  const Node* nodes = order.nodes;
-  for (int k = 0; k < order.n; ++k) {
+  // the step's own launches, then (two-role step only, when the caller left room) each role on its own:
+  // what the partner of a two-role launch costs alone
+  Node nodes[kMaxKernelsPerStep + 4];
+  const char* names[kMaxKernelsPerStep + 4];
+  int nn = 0;
+  for (int k = 0; k < order.n; ++k) { nodes[nn] = order.nodes[k]; names[nn++] = order.names[k]; }
+  if ((&order == &kOrderProdO || &order == &kOrderProdO2) && n_out >= order.n + 4) {
+    const Node extra[4] = {N_F, N_AG, N_T, N_DG};
+    const char* extra_names[4] = {"prenet(alone)", "lstm_att_lean(alone)", "attention(alone)", "lstm_dec_lean(alone)"};
+    for (int k = 0; k < 4; ++k) { nodes[nn] = extra[k]; names[nn++] = extra_names[k]; }
+  }
+  if (n_kernels) *n_kernels = nn;
+  for (int k = 0; k < nn; ++k) {
     for (int i = 0; i < 3; ++i) launch_node(h, sb, io, nodes[k], st);  // warm
     HIP_TRY(h, hipEventRecord(e0, st));
     for (int i = 0; i < iters; ++i) launch_node(h, sb, io, nodes[k], st);
@@ -1127,7 +1268,7 @@ int ttsdec_profile_step(ttsdec_handle* h, const float* memory, int B, int L, int
     float ms = 0.f;
     HIP_TRY(h, hipEventElapsedTime(&ms, e0, e1));
     ms_out[k] = ms / iters;
-    if (names_out) names_out[k] = order.names[k];
+    if (names_out) names_out[k] = names[k];
   }
   (void)hipEventDestroy(e0);
   (void)hipEventDestroy(e1);

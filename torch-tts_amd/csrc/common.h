@@ -39,9 +39,21 @@ struct Ctrl {
   const float* teacher;
   const uint8_t* teacher_flags;
   float *y, *s, *w;
-  int range_err;  // split-fp16 mode: an activation entering a 16-bit GEMM was outside the fp16 range (saturated)
-  int pad[31];
+  int range_err;  // bit 0: split-fp16 mode, an activation entering a 16-bit GEMM was outside the fp16 range (saturated);
+                  // bit 1: a two-role launch gave up waiting for its producer role (results of the call are invalid)
+  // Two-role launches (fused_kernels.hip): arrival counters of the producer roles, zeroed at the start of every
+  // ttsdec_decode call; after step t of the call they read (t - t_call + 1) * (producer workgroups per step).
+  unsigned int dep_frame, dep_attn;
+  // measurement only (TTSDEC_STAMPS=1): per-workgroup wall-clock stamps of the two-role launches, else nullptr
+  unsigned long long* stamps;
+  int pad[27];
 };
+// stamps[(kind * 1024 + block) * 8 + k]; kind 0 = frame || lstm_att, 1 = attention || lstm_dec;
+// k: 0 = role << 32 | HW_ID, 1 = XCC_ID, 2 = start, 3 = gate reached, 4 = gate passed, 5 = end (s_memrealtime, 10 ns units)
+__device__ __forceinline__ void stamp(const Ctrl* c, int kind, int k, unsigned long long v) {
+  if (c != nullptr && c->stamps != nullptr && (threadIdx.x & 63) == 0) c->stamps[((size_t)kind * 1024 + blockIdx.x) * 8 + k] = v;
+}
+__device__ __forceinline__ unsigned long long now_rt() { return __builtin_amdgcn_s_memrealtime(); }
 
 // what a step kernel needs to know about "now"
 struct StepNow {
@@ -123,7 +135,17 @@ struct Seg3 {
   const void *p0, *p1, *p2;  // element type (fp32 or fp16 plane) is the kernel's business
   int ld0, ld1, ld2;         // leading dimensions in elements
   int e0, e1, e2;            // cumulative segment ends in the virtual K axis (elements)
+  // Chunked layout (fp16 planes only), mpad > 0: the operand is stored as [K / 32][mpad rows][32 elements], i.e.
+  // element (row, k) sits at ((k / 32) * mpad + row) * 32 + k % 32 - the 64-byte pieces that a tile takes from
+  // consecutive rows are adjacent, so an LDS-DMA instruction (16 rows x 64 B, or 8 rows x 2 chunks) reads whole
+  // cache lines back to back.  Measured (profiles/r02_b_ubench_ingest.txt): 0.32 us per 32 KiB tile with both
+  // operands chunked against 0.38 row-major, and 0.56 for row-major 64-byte pieces (half lines).  ld is unused.
+  // For the LSTM weights (LoaderWLstm) mpad != 0 is just the flag and ld = chunks per 16-unit block of the matrix.
+  int mpad;
 };
+constexpr int kChunkK = 32;      // elements per chunk row
+constexpr int kChunkBytes = 64;  // = kChunkK fp16
+__host__ __device__ inline size_t chunk_idx(int row, int k, int mpad) { return ((size_t)(k >> 5) * mpad + row) * kChunkK + (k & 31); }
 
 __host__ __device__ inline Seg3 make_seg3(const void* p0, int ld0, int k0, const void* p1, int ld1, int k1,
                                           const void* p2, int ld2, int k2) {
@@ -131,6 +153,11 @@ __host__ __device__ inline Seg3 make_seg3(const void* p0, int ld0, int k0, const
   s.p0 = p0; s.ld0 = ld0; s.e0 = k0;
   s.p1 = p1; s.ld1 = ld1; s.e1 = k0 + k1;
   s.p2 = p2; s.ld2 = ld2; s.e2 = k0 + k1 + k2;
+  s.mpad = 0;
+  return s;
+}
+__host__ __device__ inline Seg3 chunked(Seg3 s, int mpad) {
+  s.mpad = mpad;
   return s;
 }
 __host__ __device__ inline Seg3 make_seg2(const void* p0, int ld0, int k0, const void* p1, int ld1, int k1) {
@@ -156,7 +183,15 @@ template <int EB>
 __device__ __forceinline__ gbyte* seg_row_ptr(const Seg3& s, int row, int seg) {
   const void* p = seg == 0 ? s.p0 : (seg == 1 ? s.p1 : s.p2);
   const int ld = seg == 0 ? s.ld0 : (seg == 1 ? s.ld1 : s.ld2);
+  if (s.mpad > 0) return as_global(p) + (long)row * kChunkBytes;
   return as_global(p) + (long)row * ld * EB;
+}
+// byte offset of a tile row's 16-byte column c16, and the per-tile pointer advance (rowb = tile row bytes per plane)
+__device__ __forceinline__ long seg_col_off(const Seg3& s, int c16) {
+  return s.mpad > 0 ? (long)(c16 >> 2) * s.mpad * kChunkBytes + (c16 & 3) * 16 : (long)c16 * 16;
+}
+__device__ __forceinline__ long seg_tile_inc(const Seg3& s, int rowb) {
+  return s.mpad > 0 ? (long)(rowb / kChunkBytes) * s.mpad * kChunkBytes : (long)rowb;
 }
 __device__ __forceinline__ int seg_len(const Seg3& s, int seg) {
   return seg == 0 ? s.e0 : (seg == 1 ? s.e1 - s.e0 : s.e2 - s.e1);
@@ -169,7 +204,7 @@ __device__ __forceinline__ Seg3 seg_window(const Seg3& s, int lo, int hi, int eb
   auto cut = [&](const void* p, int b, int e, const char*& q, int& n) {
     const int a = lo > b ? lo : b, z = hi < e ? hi : e;
     n = z > a ? z - a : 0;
-    q = static_cast<const char*>(p) + (size_t)(a - b) * eb;
+    q = static_cast<const char*>(p) + (s.mpad > 0 ? (size_t)((a - b) / kChunkK) * s.mpad * kChunkBytes : (size_t)(a - b) * eb);
   };
   const char *q0, *q1, *q2;
   int n0, n1, n2, l0 = s.ld0, l1 = s.ld1, l2 = s.ld2;
@@ -179,7 +214,7 @@ __device__ __forceinline__ Seg3 seg_window(const Seg3& s, int lo, int hi, int eb
   if (n0 == 0) { q0 = q1; n0 = n1; l0 = l1; q1 = q2; n1 = n2; l1 = l2; n2 = 0; }
   if (n0 == 0) { q0 = q1; n0 = n1; l0 = l1; n1 = 0; }
   if (n1 == 0) { q1 = q2; n1 = n2; l1 = l2; n2 = 0; }
-  return make_seg3(q0, l0, n0, q1, l1, n1, q2, l2, n2);
+  return chunked(make_seg3(q0, l0, n0, q1, l1, n1, q2, l2, n2), s.mpad);
 }
 
 // ---------------------------------------------------------------------------
@@ -204,8 +239,44 @@ __device__ __forceinline__ void split_f16(float x, f16& hi, f16& lo) {
   lo = (f16)((x - (float)h) * kSplitScale);
 }
 __device__ __forceinline__ void split_f16_checked(float x, f16& hi, f16& lo, Ctrl* ctrl) {
-  if (ctrl != nullptr && fabsf(x) > kSplitMax) ctrl->range_err = 1;  // (idempotent plain store)
+  if (ctrl != nullptr && fabsf(x) > kSplitMax) atomicOr(&ctrl->range_err, 1);
   split_f16(x, hi, lo);
+}
+
+// ---------------------------------------------------------------------------
+// Hand-off between the two roles of one launch (fused_kernels.hip), after MI355X_MICROARCH.md "Workgroup
+// dispatch ... inter-workgroup visibility" / cdna_hip_programming.md Guideline 16.
+//   producer workgroup, after its last store_wt() of the handed-off data:  role_signal()  (whole workgroup calls it)
+//   consumer wave, before its first load of that data:                 role_wait()
+// Workgroups of the producer role have the LOWEST block ids of the launch and never wait for anything, so they
+// are resident (or done) before any consumer spins; the spin is bounded all the same - on a timeout the call
+// is flagged (Ctrl::range_err bit 1) and the consumer proceeds, so the grid always drains.
+// ---------------------------------------------------------------------------
+// The handed-off data is stored WRITE-THROUGH (store_wt: relaxed agent-scope stores = global_store ... sc1), so the
+// producer needs no release fence: an agent-scope release is a write-back of the whole XCD L2 (buffer_wbl2), and
+// 32 attention workgroups per XCD each paying one cost the step 20 us (98.9 vs 76 us of kernel time).
+__device__ __forceinline__ void store_wt(float* p, float v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ void store_wt(f16* p, f16 v) {
+  __hip_atomic_store(reinterpret_cast<unsigned short*>(p), __builtin_bit_cast(unsigned short, v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ void role_signal(unsigned int* counter) {
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's (write-through) stores have left
+  __syncthreads();
+  if (threadIdx.x == 0) __hip_atomic_fetch_add(counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+constexpr int kRoleSpinLimit = 1 << 16;  // x ~0.45 us of s_sleep: ~30 ms, far beyond any producer's run time
+__device__ __forceinline__ void role_wait(const unsigned int* counter, unsigned int target, Ctrl* ctrl) {
+  if (target == 0) return;
+  int spins = 0;
+  while (__hip_atomic_load(counter, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
+    __builtin_amdgcn_s_sleep(16);
+    if (++spins > kRoleSpinLimit) {
+      if (ctrl != nullptr) atomicOr(&ctrl->range_err, 2);
+      break;
+    }
+  }
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 }
 
 template <int N, class F>

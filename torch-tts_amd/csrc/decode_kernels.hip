@@ -7,31 +7,13 @@
 // hidden vector produced by all workgroups of the previous phase).  This file holds the row
 // GEMM (PreNet / query / projection / Postnet / Encoder2 / VITS2 GEMMs), the LSTM cell, the
 // attention kernel and the small bookkeeping / packing kernels.
-#include "gemm_tile.h"
-#include "kernels.h"
+#include "step_bodies.h"
 
 namespace ttsdec {
 
 // ===========================================================================
 // generic row GEMM:  out[m, n] = epi( sum_k A[m, k] * W[n, k] )
 // ===========================================================================
-// rows m0.. of an [M, K] activation made of up to three K segments; EB-byte elements,
-// plane 1 (fp16 lo) comes from a second Seg3 of identical shape
-template <int EB>
-struct LoaderPlain {
-  Seg3 s, s_lo;
-  int m0, M;
-  static constexpr bool kRange = false;
-  __device__ __forceinline__ int nseg() const { return seg_count(s); }
-  __device__ __forceinline__ int seglen(int i) const { return seg_len(s, i); }
-  __device__ __forceinline__ bool row_ok(int r) const { return m0 + r < M; }
-  __device__ __forceinline__ gbyte* row_ptr(int r, int i, int plane) const {
-    return seg_row_ptr<EB>(plane == 0 ? s : s_lo, m0 + r, i);
-  }
-  __device__ __forceinline__ int k_lo(int) const { return 0; }
-  __device__ __forceinline__ int k_hi(int) const { return 0; }
-};
-
 // implicit im2col for Conv1d(k, padding=(k-1)/2) on channel-last activations x [B*T, Cin]:
 // with k = tap*Cin + c the im2col row of frame m is the contiguous window
 // x[(m - taps/2)*Cin + k], valid while the tapped frame stays inside the utterance.
@@ -55,6 +37,8 @@ struct LoaderConv {
     const int hi = (T - t + half) * Cin;
     return hi < K ? hi : K;
   }
+  __device__ __forceinline__ long col_off(int c16) const { return (long)c16 * 16; }
+  __device__ __forceinline__ long tile_inc(int rowb) const { return rowb; }
 };
 
 // rows n0.. of a PyTorch-layout weight [N, K] cut into the same K segments as A
@@ -69,6 +53,8 @@ struct LoaderW {
   __device__ __forceinline__ gbyte* row_ptr(int r, int i, int plane) const {
     return seg_row_ptr<EB>(plane == 0 ? w : w_lo, n0 + r, i);
   }
+  __device__ __forceinline__ long col_off(int c16) const { return (long)c16 * 16; }
+  __device__ __forceinline__ long tile_inc(int rowb) const { return rowb; }
 };
 
 template <class Cfg, int AK, int EK>
@@ -319,122 +305,14 @@ void launch_gemm(const GemmArgs& a, AKind ak, EpiKind ek, hipStream_t st) {
 }
 
 // ===========================================================================
-// LSTMZoneoutCell (eval), tacotron/modules/rnn.py:24-39.  A workgroup owns BU hidden
-// units x BM batch rows and computes all four gates of those units (B-tile rows are
-// gathered from the i/f/g/o row blocks of the PyTorch-layout weights), so the cell
-// update happens in the epilogue without another pass.
+// LSTM cell launches (body: step_bodies.h lstm_body)
 // ===========================================================================
-template <int BU, int EB>
-struct LoaderWLstm {
-  Seg3 w, w_lo;
-  int u0, H;
-  static constexpr bool kRange = false;
-  __device__ __forceinline__ int nseg() const { return seg_count(w); }
-  __device__ __forceinline__ int seglen(int i) const { return seg_len(w, i); }
-  __device__ __forceinline__ bool row_ok(int r) const { return u0 + (r % BU) < H; }
-  __device__ __forceinline__ gbyte* row_ptr(int r, int i, int plane) const {
-    return seg_row_ptr<EB>(plane == 0 ? w : w_lo, (r / BU) * H + u0 + (r % BU), i);  // PyTorch gate blocks i,f,g,o
-  }
-};
-
-template <class Cfg>
-__device__ __forceinline__ void lstm_body(LstmArgs g) {
-  const bool live = g.ctrl == nullptr || step_now(g.ctrl, g.slot).live;
-  __shared__ __attribute__((aligned(16))) float smem[Cfg::kLdsFloats];
-  constexpr int BM = Cfg::BM, BN = Cfg::BN, LDO = Cfg::LDO, BU = BN / 4, EB = Cfg::EB;
-  constexpr int EPT = (BM * BU + kGemmThreads - 1) / kGemmThreads;  // (row, unit) pairs per thread
-  const int m0 = blockIdx.y * BM;
-  const int u0 = blockIdx.x * BU;
-  const int H = g.H;
-
-  // cell-update operands are requested BEFORE the K loop (their latency hides under it)
-  float pb[EPT][4], pc[EPT], ph[EPT], pp[EPT][4];
-#pragma unroll
-  for (int j = 0; j < EPT; ++j) {
-    const int e = threadIdx.x + j * kGemmThreads;
-    const int m = m0 + e / BU, unit = u0 + e % BU;
-    const bool ok = live && e < BM * BU && m < g.M && unit < H && g.mode != 1;
-    const size_t idx = (size_t)m * H + unit;
-    size_t pidx = (size_t)m * 4 * H + unit;
-    const float* part = g.partial;
-    bool pok = ok && g.mode == 2;
-    if (g.seq_lens != nullptr && ok) {  // packed-sequence step: this row's input projection at its own position
-      const int len = g.seq_lens[m];
-      const int pos = g.seq_reverse ? len - 1 - g.seq_t : g.seq_t;
-      pok = g.seq_t < len;
-      part = g.gx;
-      pidx = ((size_t)m * g.seq_L + (pok ? pos : 0)) * g.gx_ld + g.gx_off + unit;
-    }
-#pragma unroll
-    for (int k = 0; k < 4; ++k) {
-      pb[j][k] = (ok && g.bsum != nullptr) ? g.bsum[k * H + unit] : 0.f;
-      pp[j][k] = pok ? part[pidx + (size_t)k * H] : 0.f;
-    }
-    pc[j] = ok ? g.c[idx] : 0.f;
-    ph[j] = ok ? g.h_prev[idx] : 0.f;
-  }
-
-  const LoaderPlain<EB> la{g.a, g.a_lo, m0, g.M};
-  const LoaderWLstm<BU, EB> lb{g.w, g.w_lo, u0, g.H};
-  gemm_tile<Cfg>(la, lb, smem, live, g.dbg);
-  if (!live) return;
-
-#pragma unroll
-  for (int j = 0; j < EPT; ++j) {
-    const int e = threadIdx.x + j * kGemmThreads;
-    const int row = e / BU, u = e % BU;
-    const int m = m0 + row, unit = u0 + u;
-    if (e >= BM * BU || m >= g.M || unit >= H) continue;
-    const float* tr = smem + row * LDO;
-    float si = tr[0 * BU + u], sf = tr[1 * BU + u], sg = tr[2 * BU + u], so = tr[3 * BU + u];
-    const size_t pidx = (size_t)m * 4 * H + unit;
-    if (g.mode == 1) {  // early part: park the raw gate sums
-      g.partial[pidx] = si;
-      g.partial[pidx + H] = sf;
-      g.partial[pidx + 2 * H] = sg;
-      g.partial[pidx + 3 * H] = so;
-      continue;
-    }
-    const size_t idx = (size_t)m * H + unit;
-    int seq_pos = 0;
-    if (g.seq_lens != nullptr) {
-      const int len = g.seq_lens[m];
-      if (g.seq_t >= len) {  // this utterance has ended: state is carried unchanged, nothing is emitted
-        g.h_out[idx] = ph[j];
-        continue;
-      }
-      seq_pos = g.seq_reverse ? len - 1 - g.seq_t : g.seq_t;
-    }
-    if (g.mode == 2) {  // finishing part: early sums + the late segments (fixed order: deterministic)
-      si = add_rn(pp[j][0], si);
-      sf = add_rn(pp[j][1], sf);
-      sg = add_rn(pp[j][2], sg);
-      so = add_rn(pp[j][3], so);
-    }
-    const float gi = add_rn(si, pb[j][0]);
-    const float gf = add_rn(sf, pb[j][1]);
-    const float gg = add_rn(sg, pb[j][2]);
-    const float go = add_rn(so, pb[j][3]);
-    const float c_prev = pc[j];
-    const float h_prev = ph[j];
-    // nn.LSTMCell: c' = sigmoid(f)*c + sigmoid(i)*tanh(g); h' = sigmoid(o)*tanh(c')
-    const float c_new = add_rn(mul_rn(sigmoid_f(gf), c_prev), mul_rn(sigmoid_f(gi), tanhf(gg)));
-    const float h_new = mul_rn(sigmoid_f(go), tanhf(c_new));
-    // rnn.py:36-38 eval-mode zoneout: p*prev + (1-p)*new
-    const float q = sub_rn(1.0f, g.pz);
-    const float h = add_rn(mul_rn(g.pz, h_prev), mul_rn(q, h_new));
-    g.h_out[idx] = h;
-    if (g.h_out_h != nullptr) split_f16(h, g.h_out_h[idx], g.h_out_l[idx]);
-    if (g.seq_out != nullptr) g.seq_out[((size_t)m * g.seq_Lout + seq_pos) * g.seq_out_ld + g.seq_out_off + unit] = h;
-    g.c[idx] = add_rn(mul_rn(g.pz, c_prev), mul_rn(q, c_new));
-  }
-}
-
 // TAG only names the instantiation (0 = attention LSTM / generic, 1 = decoder LSTM) so that profilers
 // list the two cells of a decode step as separate kernels.
 template <class Cfg, int TAG = 0>
 __global__ __launch_bounds__(kGemmThreads) void lstm_kernel(LstmArgs g) {
-  lstm_body<Cfg>(g);
+  __shared__ __attribute__((aligned(16))) float smem[Cfg::kLdsFloats];
+  lstm_body<Cfg>(g, smem, blockIdx.x, blockIdx.y);
 }
 template <class Cfg>
 static void launch_lstm_tagged(const LstmArgs& a, dim3 grid, hipStream_t st) {
@@ -447,7 +325,8 @@ struct LstmPair {
 };
 template <class Cfg>
 __global__ __launch_bounds__(kGemmThreads) void lstm_pair_kernel(LstmPair p) {
-  lstm_body<Cfg>(blockIdx.z ? p.d[1] : p.d[0]);
+  __shared__ __attribute__((aligned(16))) float smem[Cfg::kLdsFloats];
+  lstm_body<Cfg>(blockIdx.z ? p.d[1] : p.d[0], smem, blockIdx.x, blockIdx.y);
 }
 
 void launch_lstm_pair(const LstmArgs& a0, const LstmArgs& a1, hipStream_t st) {
@@ -509,147 +388,12 @@ void launch_lstm(const LstmArgs& a, hipStream_t st) {
 }
 
 // ===========================================================================
-// StepwiseMonotonicAttention + context (tacotron/modules/attention.py:104-126,
-// tacotron/decoder_cell.py:189).  One workgroup per utterance, 8 waves; a wave
-// owns a contiguous range of memory rows and makes ONE pass over them: each row
-// is loaded once (float4 per lane, coalesced), dotted with q (wave butterfly),
-// turned into p0 and the new weight, and accumulated into the context while it
-// is still in registers.  Row l needs p0[l-1], so a wave recomputes the energy
-// of the row just before its range.
+// attention + context launch (body: step_bodies.h attn_body)
 // ===========================================================================
-__device__ __forceinline__ float wave_sum(float v) {
-#pragma unroll
-  for (int off = 32; off >= 1; off >>= 1) v += __shfl_xor(v, off, 64);
-  return v;
-}
-
 template <int NJ>
 __global__ __launch_bounds__(kAttnThreads) void attn_kernel(AttnArgs g) {
-  if (g.ctrl != nullptr) {
-    const Ctrl* c = g.ctrl;
-    const StepNow now = step_now(c, g.slot);
-    if (!now.live) return;
-    g.memory = c->memory;
-    g.w_out = c->w;
-    g.t_rel = now.t_rel;
-    g.t_stride = c->t_stride;
-  }
-  constexpr int NW = kAttnThreads / 64;
-  __shared__ __attribute__((aligned(16))) float part[NW * NJ * 256];
-  const int b = blockIdx.x;
-  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-  const int L = g.L, D = g.D, D4 = D >> 2;
-  const float* mem = g.memory + (size_t)b * L * D;
-  const float* wprev = g.w_prev + (size_t)b * L;
-  float* wnew = g.w_new + (size_t)b * L;
-  float* wout = g.w_out ? g.w_out + ((size_t)b * g.t_stride + g.t_rel) * L : nullptr;
-
-  float4 qv[NJ];
-#pragma unroll
-  for (int j = 0; j < NJ; ++j) {
-    const int c4 = lane + 64 * j;
-    qv[j] = (c4 < D4 && !g.ctx_only) ? *reinterpret_cast<const float4*>(g.q + (size_t)b * D + c4 * 4)
-                                     : make_float4(0.f, 0.f, 0.f, 0.f);  // ctx_only: no query, energies unused
-  }
-  if (!g.ctx_only) {  // split-K query: add the partial slabs in index order
-    for (int z = 1; z < g.q_parts; ++z) {
-#pragma unroll
-      for (int j = 0; j < NJ; ++j) {
-        const int c4 = lane + 64 * j;
-        if (c4 < D4) {
-          const float4 v = *reinterpret_cast<const float4*>(g.q + z * g.q_stride + (size_t)b * D + c4 * 4);
-          qv[j].x = add_rn(qv[j].x, v.x); qv[j].y = add_rn(qv[j].y, v.y);
-          qv[j].z = add_rn(qv[j].z, v.z); qv[j].w = add_rn(qv[j].w, v.w);
-        }
-      }
-    }
-  }
-  auto load_row = [&](int l, float4 (&r)[NJ]) {
-#pragma unroll
-    for (int j = 0; j < NJ; ++j) {
-      const int c4 = lane + 64 * j;
-      r[j] = (c4 < D4) ? *reinterpret_cast<const float4*>(mem + (size_t)l * D + c4 * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
-    }
-  };
-  auto dot_row = [&](const float4 (&r)[NJ]) {
-    float s = 0.f;
-#pragma unroll
-    for (int j = 0; j < NJ; ++j) {
-      s = fmaf(r[j].x, qv[j].x, s);
-      s = fmaf(r[j].y, qv[j].y, s);
-      s = fmaf(r[j].z, qv[j].z, s);
-      s = fmaf(r[j].w, qv[j].w, s);
-    }
-    return wave_sum(s);
-  };
-
-  const int chunk = (L + NW - 1) / NW;
-  const int l0 = wv * chunk;
-  const int l1 = (l0 + chunk < L) ? l0 + chunk : L;
-
-  float4 acc[NJ];
-#pragma unroll
-  for (int j = 0; j < NJ; ++j) acc[j] = make_float4(0.f, 0.f, 0.f, 0.f);
-
-  if (l0 < l1) {
-    float w1_prev = 0.f;  // w[l-1] * (1 - p0[l-1])   attention.py:120
-    if (l0 > 0) {
-      float4 r[NJ];
-      load_row(l0 - 1, r);
-      const float p0 = isru_sigmoid(dot_row(r));  // l0-1 < L-1, never the overridden column
-      w1_prev = mul_rn(wprev[l0 - 1], sub_rn(1.0f, p0));
-    }
-    constexpr int G = 4;  // rows in flight per wave (8 measured slower, 17.2 vs 15.2 us; all 15 rows of a wave at once 18.2 vs 15.6 us at
-                          // B = 256 and no faster at B = 1: the pass runs at the Infinity-Cache rate, not at a latency chain's)
-    for (int lb = l0; lb < l1; lb += G) {
-      float4 r[G][NJ];
-      float e[G];
-#pragma unroll
-      for (int i = 0; i < G; ++i)
-        if (lb + i < l1) load_row(lb + i, r[i]);
-#pragma unroll
-      for (int i = 0; i < G; ++i)
-        if (lb + i < l1) e[i] = dot_row(r[i]);
-#pragma unroll
-      for (int i = 0; i < G; ++i) {
-        const int l = lb + i;
-        if (l < l1) {
-          const float en = (l == L - 1) ? 1e4f : e[i];  // attention.py:117
-          const float p0 = isru_sigmoid(en);            // attention.py:118
-          const float wl = wprev[l];
-          const float w0 = mul_rn(wl, p0);                      // :119
-          float wn = (l > 0) ? add_rn(w0, w1_prev) : w0;        // :122-123
-          w1_prev = mul_rn(wl, sub_rn(1.0f, p0));               // :120
-          if (g.ctx_only) wn = wl;
-          if (lane == 0 && !g.ctx_only) {
-            wnew[l] = wn;
-            if (wout) wout[l] = wn;
-          }
-#pragma unroll
-          for (int j = 0; j < NJ; ++j) {
-            acc[j].x = fmaf(wn, r[i][j].x, acc[j].x);
-            acc[j].y = fmaf(wn, r[i][j].y, acc[j].y);
-            acc[j].z = fmaf(wn, r[i][j].z, acc[j].z);
-            acc[j].w = fmaf(wn, r[i][j].w, acc[j].w);
-          }
-        }
-      }
-    }
-  }
-  // cross-wave sum of the context partials in a fixed order (deterministic)
-#pragma unroll
-  for (int j = 0; j < NJ; ++j)
-    *reinterpret_cast<float4*>(part + ((wv * NJ + j) * 64 + lane) * 4) = acc[j];
-  __syncthreads();
-  for (int d = threadIdx.x; d < D; d += kAttnThreads) {
-    const int c4 = d >> 2, comp = d & 3;
-    const int j = c4 >> 6, ln = c4 & 63;
-    float s = 0.f;
-#pragma unroll
-    for (int w = 0; w < NW; ++w) s += part[((w * NJ + j) * 64 + ln) * 4 + comp];
-    g.ctx[(size_t)b * D + d] = s;
-    if (g.ctx_h != nullptr) split_f16_checked(s, g.ctx_h[(size_t)b * D + d], g.ctx_l[(size_t)b * D + d], g.ctrl);
-  }
+  __shared__ __attribute__((aligned(16))) float part[attn_lds_floats<NJ>()];
+  attn_body<NJ>(g, part, blockIdx.x);
 }
 
 void launch_attn(const AttnArgs& a, hipStream_t st) {
@@ -675,18 +419,27 @@ __global__ void init_state_kernel(InitArgs g) {
   if (i < nHa) {
     g.h_att[i] = g.h0_att[i % g.Ha];
     g.c_att[i] = g.c0_att[i % g.Ha];
-    if (g.h_att_h != nullptr) split_f16(g.h0_att[i % g.Ha], g.h_att_h[i], g.h_att_l[i]);
+    if (g.h_att_h != nullptr) {
+      const size_t o = g.out_mpad > 0 ? chunk_idx((int)(i / g.Ha), (int)(i % g.Ha), g.out_mpad) : i;
+      split_f16(g.h0_att[i % g.Ha], g.h_att_h[o], g.h_att_l[o]);
+    }
   }
   if (i < nHd) {
     g.h_dec[i] = g.h0_dec[i % g.Hd];
     g.c_dec[i] = g.c0_dec[i % g.Hd];
-    if (g.h_dec_h != nullptr) split_f16(g.h0_dec[i % g.Hd], g.h_dec_h[i], g.h_dec_l[i]);
+    if (g.h_dec_h != nullptr) {
+      const size_t o = g.out_mpad > 0 ? chunk_idx((int)(i / g.Hd), (int)(i % g.Hd), g.out_mpad) : i;
+      split_f16(g.h0_dec[i % g.Hd], g.h_dec_h[o], g.h_dec_l[o]);
+    }
   }
   if (i < (size_t)g.B * g.D) {
     // w_0 is one-hot at position 0, so bmm(w_0, memory) is memory[:, 0, :]
     const float c0 = g.memory ? g.memory[(i / g.D) * (size_t)g.L * g.D + (i % g.D)] : 0.f;
     g.ctx[i] = c0;
-    if (g.ctx_h != nullptr) split_f16(c0, g.ctx_h[i], g.ctx_l[i]);
+    if (g.ctx_h != nullptr) {
+      const size_t o = g.out_mpad > 0 ? chunk_idx((int)(i / g.D), (int)(i % g.D), g.out_mpad) : i;
+      split_f16(c0, g.ctx_h[o], g.ctx_l[o]);
+    }
   }
   if (i < (size_t)g.B * g.L) g.w[i] = (i % g.L == 0) ? 1.0f : 0.f;
   if (i < (size_t)g.B * g.d_mel) g.ynext[i] = 0.f;
@@ -707,7 +460,7 @@ __global__ void finish_kernel(Ctrl* ctrl, int32_t* T_out) {
   ctrl->steps_done = done;
   if (T_out) {
     T_out[0] = done;
-    T_out[1] = fired | (ctrl->range_err ? 2 : 0);
+    T_out[1] = fired | ((ctrl->range_err & 1) ? 2 : 0) | ((ctrl->range_err & 2) ? 4 : 0);
   }
 }
 
@@ -732,6 +485,9 @@ __global__ void set_call_kernel(Ctrl* c, CallArgs a) {
   c->y = a.y;
   c->s = a.s;
   c->w = a.w;
+  c->dep_frame = 0;
+  c->dep_attn = 0;
+  c->stamps = a.stamps;
 }
 void launch_set_call(Ctrl* ctrl, const CallArgs& a, hipStream_t st) {
   hipLaunchKernelGGL(set_call_kernel, dim3(1), dim3(1), 0, st, ctrl, a);
@@ -769,6 +525,33 @@ __global__ void split_kernel(const float* src, f16* hi, f16* lo, size_t n) {
 void launch_split(const float* src, f16* hi, f16* lo, size_t n, hipStream_t st) {
   if (n == 0 || src == nullptr) return;
   hipLaunchKernelGGL(split_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, src, hi, lo, n);
+}
+
+__global__ void split_chunked_kernel(const float* src, f16* hi, f16* lo, int M, int K, int mpad) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= (size_t)M * K) return;
+  const int m = (int)(i / K), k = (int)(i % K);
+  const size_t o = chunk_idx(m, k, mpad);
+  split_f16(src[i], hi[o], lo[o]);
+}
+void launch_split_chunked(const float* src, f16* hi, f16* lo, int M, int K, int mpad, hipStream_t st) {
+  const size_t n = (size_t)M * K;
+  if (n == 0 || src == nullptr) return;
+  hipLaunchKernelGGL(split_chunked_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, src, hi, lo, M, K, mpad);
+}
+
+__global__ void pack_lstm_chunked_kernel(const float* src, f16* hi, f16* lo, int H, int K) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= (size_t)4 * H * K) return;
+  const int row = (int)(i / K), k = (int)(i % K);
+  const int gate = row / H, u = row % H;
+  const size_t o = (((size_t)(u >> 4) * (K >> 5) + (k >> 5)) * 64 + gate * 16 + (u & 15)) * kChunkK + (k & 31);
+  split_f16(src[i], hi[o], lo[o]);
+}
+void launch_pack_lstm_chunked(const float* src, f16* hi, f16* lo, int H, int K, hipStream_t st) {
+  const size_t n = (size_t)4 * H * K;
+  if (n == 0 || src == nullptr) return;
+  hipLaunchKernelGGL(pack_lstm_chunked_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, src, hi, lo, H, K);
 }
 
 // max |x| over a tensor, folded into *out (a non-negative float's bits order like an unsigned int)

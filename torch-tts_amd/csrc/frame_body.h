@@ -1,0 +1,354 @@
+// Frame kernel body: the row-local chain between two decoder LSTM launches (see frame_kernel.hip for the
+// description).  A device function so that it can also run as one role of a two-role launch (fused_kernels.hip).
+#pragma once
+#include "kernels.h"
+
+namespace ttsdec {
+
+constexpr int kFrameThreads = 512;
+constexpr int kFrameRows = 32;
+constexpr int kFrameCols = 64;
+
+typedef __attribute__((address_space(1))) const f32x4 gf32x4;
+typedef __attribute__((address_space(1))) const f16x8 gf16x8;
+
+constexpr int kFrameMaxNI = 12;  // projection columns per thread in phase F: r*d_mel + r <= 16 * kFrameMaxNI
+
+// LDS layout of one frame workgroup (floats): A operands (fp32 rows padded by 4 floats, or two fp16 planes
+// padded by 8 halfs), the layer-1 reduction tile, the Philox keep bits
+template <int K0H, int PH, int PREC>
+struct FrameLds {
+  static constexpr bool F16 = PREC == PREC_F16S;
+  static constexpr int K0 = 2 * K0H;
+  static constexpr int RS = 33;
+  static constexpr int XS = F16 ? (K0 + 8) / 2 : K0 + 4;  // row strides in floats
+  static constexpr int HS = F16 ? (PH + 8) / 2 : PH + 4;
+  static constexpr int NPL = F16 ? 2 : 1;
+  static constexpr int G0 = (PH + 127) / 128;  // Philox groups (128 keep bits each) of a hidden row
+  static constexpr int kXs = 0;
+  static constexpr int kH0 = kXs + NPL * kFrameRows * XS;
+  static constexpr int kRed = kH0 + NPL * kFrameRows * HS;
+  static constexpr int kPm0 = kRed + 8 * 32 * RS;
+  static constexpr int kPm1 = kPm0 + kFrameRows * G0 * 4;
+  static constexpr int kFloats = (kPm1 + kFrameRows * 4 + 3) & ~3;
+};
+
+// K0H = d_mel / 2, PH = hidden width of the PreNet, PREC = PREC_F32 (exact fp32 MFMA) or PREC_F16S
+// (split-fp16 planes, 3 f16 MFMA products per k16 step, fp32 accumulate: see gemm_tile.h).
+// NI: projection columns per thread in phase F (r*d_mel + r <= 16 * NI); the two-role launch uses 6 to stay within 128 VGPRs.
+// lds: FrameLds<...>::kFloats floats (16-byte aligned) of the calling kernel's ONE shared array;
+// (bx, by): column block / row block of this workgroup.
+template <int K0H, int PH, int PREC, int NI = kFrameMaxNI>
+__device__ __forceinline__ void frame_body(FrameArgs g, float* lds, int bx, int by) {
+  using LD = FrameLds<K0H, PH, PREC>;
+  constexpr bool F16 = PREC == PREC_F16S;
+  constexpr int K0 = 2 * K0H;
+  constexpr int KQ = PH / 4;   // layer 1: K range of one wave
+  constexpr int K1H = KQ / 2;  //          and of one lane half
+  constexpr int RS = LD::RS, XS = LD::XS, HS = LD::HS, G0 = LD::G0;
+  static_assert(K0H % 8 == 0 && K1H % 8 == 0 && PH % 32 == 0 && PH <= 256, "unsupported PreNet shape");
+  float* const xs = lds + LD::kXs;
+  float* const h0s = lds + LD::kH0;
+  float* const red = lds + LD::kRed;
+  uint32_t* const pm0 = reinterpret_cast<uint32_t*>(lds + LD::kPm0);  // layer-0 keep bits [row][unit >> 5]
+  uint32_t* const pm1 = reinterpret_cast<uint32_t*>(lds + LD::kPm1);  // layer-1 keep bits of this workgroup's 64 columns' group
+  f16* const xs_h = reinterpret_cast<f16*>(xs);
+  f16* const xs_l = xs_h + kFrameRows * XS * 2;
+  f16* const h0_h = reinterpret_cast<f16*>(h0s);
+  f16* const h0_l = h0_h + kFrameRows * HS * 2;
+
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, l32 = lane & 31, half = lane >> 5;
+  const int m0 = by * kFrameRows, n0 = bx * kFrameCols;
+  const bool writer = bx == 0;
+
+  // ---- weight fragments (independent of the control block) ----
+  // lane (n = l32, half) holds a contiguous K run of weight row n: [half*K0H, +K0H) for layer 0,
+  // [wave's quarter + half*K1H, +K1H) for layer 1
+  const bool p0_wave = wave * 32 < PH;
+  constexpr int NW0 = F16 ? K0H / 8 : K0H / 4, NW1 = F16 ? K1H / 8 : K1H / 4;
+  f32x4 w0[F16 ? 1 : NW0], w1[F16 ? 1 : NW1];
+  f16x8 w0h[F16 ? NW0 : 1], w0l[F16 ? NW0 : 1], w1h[F16 ? NW1 : 1], w1l[F16 ? NW1 : 1];
+  float b0v = 0.f;
+  const int n1 = n0 + (wave & 1) * 32 + l32;
+  if (!g.only_finalize) {
+    if (p0_wave) {
+      const size_t o = (size_t)(wave * 32 + l32) * K0 + half * K0H;
+      if constexpr (F16) {
+        gf16x8 *sh = (gf16x8*)(g.W0h + o), *sl = (gf16x8*)(g.W0l + o);
+#pragma unroll
+        for (int j = 0; j < NW0; ++j) { w0h[j] = sh[j]; w0l[j] = sl[j]; }
+      } else {
+        gf32x4* src = (gf32x4*)(g.W0 + o);
+#pragma unroll
+        for (int j = 0; j < NW0; ++j) w0[j] = src[j];
+      }
+      b0v = g.b0[wave * 32 + l32];
+    }
+    const size_t o1 = (size_t)(n1 < g.P ? n1 : 0) * PH + (wave >> 1) * KQ + half * K1H;
+    if constexpr (F16) {
+      gf16x8 *sh = (gf16x8*)(g.W1h + o1), *sl = (gf16x8*)(g.W1l + o1);
+#pragma unroll
+      for (int j = 0; j < NW1; ++j) { w1h[j] = sh[j]; w1l[j] = sl[j]; }
+    } else {
+      gf32x4* src = (gf32x4*)(g.W1 + o1);
+#pragma unroll
+      for (int j = 0; j < NW1; ++j) w1[j] = src[j];
+    }
+  }
+
+  // ---- projection partial sums of the previous step (addresses independent of the control
+  // block too; harmless when it then turns out there is nothing to finish) ----
+  // thread -> (row = tid / 16, columns (tid % 16) + 16 i)
+  const int nm = g.r * g.d_mel, NJ = nm + g.r;
+  const int frow = tid >> 4, fm = m0 + frow;
+  // (every load below is unconditional - out-of-range lanes read element 0 and slabs past n_parts are
+  // discarded after the fact - so the compiler issues them all back to back instead of one dependent
+  // load per branch)
+  constexpr int kMaxParts = 4;
+  float pv[NI];
+  if (g.parts != nullptr) {
+    float pz[NI][kMaxParts], pbias[NI];
+#pragma unroll
+    for (int i = 0; i < NI; ++i) {
+      const int n = (tid & 15) + 16 * i;
+      const bool ok = fm < g.M && n < NJ;
+      const size_t idx = ok ? (size_t)fm * g.ldp + n : 0;
+#pragma unroll
+      for (int z = 0; z < kMaxParts; ++z) pz[i][z] = g.parts[z * g.part_stride + idx];
+      pbias[i] = g.proj_bias[ok ? n : 0];
+    }
+#pragma unroll
+    for (int i = 0; i < NI; ++i) {
+      float v = pz[i][0];
+#pragma unroll
+      for (int z = 1; z < kMaxParts; ++z) v = add_rn(v, z < g.n_parts ? pz[i][z] : 0.f);
+      pv[i] = add_rn(v, pbias[i]);
+    }
+  } else {
+#pragma unroll
+    for (int i = 0; i < NI; ++i) pv[i] = 0.f;
+  }
+
+  // ---- "now" ----
+  int t = g.t, t_rel = g.t_rel, finalize = g.finalize;
+  if (g.ctrl != nullptr) {
+    const Ctrl* c = g.ctrl;
+    bool live;
+    if (g.only_finalize) {  // after the last step of the call: the frame of step t_end - 1
+      t = c->t_end;
+      live = c->t_end > c->t_call && c->t_end - 1 <= c->stop_t;
+    } else {
+      // This launch finishes step t-1's frame, and its writer workgroups may lower stop_t to t-1
+      // while others are still reading it.  Gate on t-1 <= stop_t: that atomicMin cannot change it,
+      // so every wave of every workgroup takes the same decision and all rows of the firing step
+      // get written.  (When the rule fires here the PreNet below runs on a dead step: harmless.)
+      t = c->t_cur + g.slot;
+      live = t < c->t_end && t - 1 <= c->stop_t;
+    }
+    if (!live) return;
+    t_rel = t - c->t_call;
+    finalize = t > c->t_call;  // (the frame a call starts from was finished by the call before it)
+    g.t_stride = c->t_stride;
+    g.dropout_mode = c->dropout_mode;
+    g.seed = c->seed;
+    g.masks = c->masks ? c->masks + (size_t)t_rel * g.mask_step_stride : nullptr;
+    g.teacher = c->teacher;
+    g.teacher_T = c->teacher_T;
+    g.teacher_flags = c->teacher_flags;
+    g.y_out = c->y;
+    g.s_out = c->s;
+    g.stop_thr = c->stop_thr;
+    g.check_stop = c->check_stop;
+  }
+
+  // ---- epilogue operands of both PreNet layers, requested early ----
+  uint8_t mk0[16], mk1[4];
+  float b1v[4];
+#pragma unroll
+  for (int r = 0; r < 16; ++r) mk0[r] = 1;
+#pragma unroll
+  for (int j = 0; j < 4; ++j) { mk1[j] = 1; b1v[j] = 0.f; }
+  if (!g.only_finalize) {
+    if (g.dropout_mode == TTSDEC_DROPOUT_MASKS && p0_wave) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int m = m0 + (r & 3) + 8 * (r >> 2) + 4 * half;
+        if (m < g.M) mk0[r] = g.masks[(size_t)m * PH + wave * 32 + l32];
+      }
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int e = tid + j * kFrameThreads;
+      const int m = m0 + e / kFrameCols, n = n0 + e % kFrameCols;
+      if (m < g.M && n < g.P) {
+        b1v[j] = g.b1[n];
+        if (g.dropout_mode == TTSDEC_DROPOUT_MASKS) mk1[j] = g.masks[(size_t)g.M * PH + (size_t)m * g.P + n];
+      }
+    }
+  }
+
+  if (!g.only_finalize && g.dropout_mode == TTSDEC_DROPOUT_PHILOX && tid < kFrameRows * (G0 + 1)) {
+    // one Philox call per (row, 128 units): 32 x (G0 + 1) calls per workgroup instead of one per unit
+    const int row = tid % kFrameRows, grp = tid / kFrameRows;
+    const bool l1 = grp == G0;
+    const Philox4 k = philox_keep_group(g.seed, (uint32_t)t, l1 ? 1u : 0u, (uint32_t)(m0 + row), l1 ? (uint32_t)(n0 >> 7) : (uint32_t)grp);
+    uint32_t* dst = l1 ? pm1 + row * 4 : pm0 + (row * G0 + grp) * 4;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) dst[i] = k.w[i];
+  }
+
+  // store one element of the input frame as the layer-0 A operand
+  auto put_x = [&](int row, int c, float v) {
+    if constexpr (F16) split_f16_checked(v, xs_h[row * (XS * 2) + c], xs_l[row * (XS * 2) + c], g.ctrl);
+    else xs[row * XS + c] = v;
+  };
+
+  // ---- phase F: the input frame of step t ----
+  const bool teach = g.teacher != nullptr && t > 0 && g.teacher_flags[t - 1] != 0;
+  if (finalize) {
+    const size_t fr = (size_t)fm * g.t_stride * g.r + (size_t)(t_rel - 1) * g.r;
+#pragma unroll
+    for (int i = 0; i < NI; ++i) {
+      const int n = (tid & 15) + 16 * i;
+      if (n >= NJ) continue;
+      const bool last = n >= nm - g.d_mel && n < nm;  // decoder.py:48 y_t[:, -1, :]
+      if (fm >= g.M) {
+        if (last) put_x(frow, n - (nm - g.d_mel), 0.f);
+        continue;
+      }
+      float v = pv[i];
+      if (n < nm) {
+        v = v > 0.f ? v : mul_rn(v, 0.01f);  // decoder.py:53-54
+        if (writer) g.y_out[fr * g.d_mel + n] = v;  // [B, t_stride*r, d_mel]: frame jf, channel c = fr*d_mel + n
+        if (last) {
+          put_x(frow, n - (nm - g.d_mel), v);
+          if (writer) g.ynext[(size_t)fm * g.d_mel + n - (nm - g.d_mel)] = v;
+        }
+      } else if (writer) {
+        g.s_out[fr + (n - nm)] = v;  // decoder.py:52
+        if (g.check_stop && g.ctrl != nullptr && v < g.stop_thr) atomicMin(&g.ctrl->stop_t, t - 1);  // decoder.py:68
+      }
+    }
+  }
+  if (g.only_finalize) return;
+  if (!finalize || teach) {
+    if (teach) __syncthreads();  // the teacher frame replaces what phase F put there
+    for (int c = tid & 15; c < K0; c += 16) {
+      float v = 0.f;
+      if (fm < g.M)
+        v = teach ? g.teacher[((size_t)fm * g.teacher_T + (size_t)t * g.r - 1) * g.d_mel + c]  // decoder.py:65-66
+                  : g.ynext[(size_t)fm * g.d_mel + c];
+      put_x(frow, c, v);
+    }
+  }
+  __syncthreads();
+
+  // ---- PreNet layer 0: h0 = dropout(relu(x W0^T + b0)), one 32-column tile per wave ----
+  if (p0_wave) {
+    f32x16 acc = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    if (!(g.dbg & 2)) {
+      if constexpr (F16) {
+        f32x16 acc2 = acc;
+        const f16* ah = xs_h + l32 * (XS * 2) + half * K0H;
+        const f16* al = xs_l + l32 * (XS * 2) + half * K0H;
+#pragma unroll
+        for (int j = 0; j < NW0; ++j) {
+          const f16x8 a_h = *reinterpret_cast<const f16x8*>(ah + 8 * j), a_l = *reinterpret_cast<const f16x8*>(al + 8 * j);
+          acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(a_h, w0h[j], acc, 0, 0, 0);
+          acc2 = __builtin_amdgcn_mfma_f32_32x32x16_f16(a_h, w0l[j], acc2, 0, 0, 0);
+          acc2 = __builtin_amdgcn_mfma_f32_32x32x16_f16(a_l, w0h[j], acc2, 0, 0, 0);
+        }
+#pragma unroll
+        for (int i = 0; i < 16; ++i) acc[i] = fmaf(acc2[i], 1.0f / kSplitScale, acc[i]);
+      } else {
+        const float* arow = xs + l32 * XS + half * K0H;
+#pragma unroll
+        for (int j = 0; j < NW0; ++j) {
+          const f32x4 a4 = *reinterpret_cast<const f32x4*>(arow + 4 * j);
+#pragma unroll
+          for (int e = 0; e < 4; ++e) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a4[e], w0[j][e], acc, 0, 0, 0);
+        }
+      }
+    }
+    const int col = wave * 32 + l32;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int row = (r & 3) + 8 * (r >> 2) + 4 * half;
+      float v = add_rn(acc[r], b0v);
+      v = v > 0.f ? v : 0.f;
+      if (g.dropout_mode == TTSDEC_DROPOUT_MASKS) v = mk0[r] ? mul_rn(v, g.keep_scale) : 0.f;
+      else if (g.dropout_mode == TTSDEC_DROPOUT_PHILOX)
+        v = ((pm0[row * G0 * 4 + wave] >> l32) & 1u) ? mul_rn(v, g.keep_scale) : 0.f;  // unit = 32*wave + l32
+      if constexpr (F16) split_f16_checked(v, h0_h[row * (HS * 2) + col], h0_l[row * (HS * 2) + col], g.ctrl);
+      else h0s[row * HS + col] = v;
+    }
+  }
+  __syncthreads();
+
+  // ---- PreNet layer 1: 2 column tiles x 4 K quarters over the 8 waves ----
+  {
+    f32x16 acc = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    if (!(g.dbg & 4)) {
+      if constexpr (F16) {
+        f32x16 acc2 = acc;
+        const f16* ah = h0_h + l32 * (HS * 2) + (wave >> 1) * KQ + half * K1H;
+        const f16* al = h0_l + l32 * (HS * 2) + (wave >> 1) * KQ + half * K1H;
+#pragma unroll
+        for (int j = 0; j < NW1; ++j) {
+          const f16x8 a_h = *reinterpret_cast<const f16x8*>(ah + 8 * j), a_l = *reinterpret_cast<const f16x8*>(al + 8 * j);
+          acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(a_h, w1h[j], acc, 0, 0, 0);
+          acc2 = __builtin_amdgcn_mfma_f32_32x32x16_f16(a_h, w1l[j], acc2, 0, 0, 0);
+          acc2 = __builtin_amdgcn_mfma_f32_32x32x16_f16(a_l, w1h[j], acc2, 0, 0, 0);
+        }
+#pragma unroll
+        for (int i = 0; i < 16; ++i) acc[i] = fmaf(acc2[i], 1.0f / kSplitScale, acc[i]);
+      } else {
+        const float* arow = h0s + l32 * HS + (wave >> 1) * KQ + half * K1H;
+#pragma unroll
+        for (int j = 0; j < NW1; ++j) {
+          const f32x4 a4 = *reinterpret_cast<const f32x4*>(arow + 4 * j);
+#pragma unroll
+          for (int e = 0; e < 4; ++e) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a4[e], w1[j][e], acc, 0, 0, 0);
+        }
+      }
+    }
+    float* out = red + wave * 32 * RS;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) out[((r & 3) + 8 * (r >> 2) + 4 * half) * RS + l32] = acc[r];
+  }
+  __syncthreads();
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const int e = tid + j * kFrameThreads;
+    const int row = e / kFrameCols, col = e % kFrameCols;
+    const int m = m0 + row, n = n0 + col;
+    if (m >= g.M || n >= g.P) continue;
+    const float* pr = red + (col >> 5) * 32 * RS + row * RS + (col & 31);
+    float v = pr[0];
+#pragma unroll
+    for (int q = 1; q < 4; ++q) v = add_rn(v, pr[q * 2 * 32 * RS]);  // K quarters in order
+    v = add_rn(v, b1v[j]);
+    v = v > 0.f ? v : 0.f;
+    if (g.dropout_mode == TTSDEC_DROPOUT_MASKS) v = mk1[j] ? mul_rn(v, g.keep_scale) : 0.f;
+    else if (g.dropout_mode == TTSDEC_DROPOUT_PHILOX)
+      v = ((pm1[row * 4 + ((n >> 5) & 3)] >> (n & 31)) & 1u) ? mul_rn(v, g.keep_scale) : 0.f;
+    const size_t o = (size_t)m * g.P + n;
+    const size_t oc = g.out_mpad > 0 ? chunk_idx(m, n, g.out_mpad) : o;
+    if (g.dep_signal) {  // handed to the attention LSTM of this very launch: write-through (see role_signal)
+      store_wt(g.xpre + o, v);
+      if (g.xpre_h != nullptr) {
+        f16 hi, lo;
+        split_f16_checked(v, hi, lo, g.ctrl);
+        store_wt(g.xpre_h + oc, hi);
+        store_wt(g.xpre_l + oc, lo);
+      }
+    } else {
+      g.xpre[o] = v;
+      if (g.xpre_h != nullptr) split_f16_checked(v, g.xpre_h[oc], g.xpre_l[oc], g.ctrl);
+    }
+  }
+  if (g.dep_signal && g.ctrl != nullptr) role_signal(&g.ctrl->dep_frame);  // the attention LSTM of this launch waits for x_pre
+}
+
+
+}  // namespace ttsdec

@@ -48,6 +48,9 @@ namespace ttsdec {
 // MFMAs of the 64x64 tile (the large GEMMs are bound by the per-CU ingest rate, not by the matrix
 // pipe).  HK = 1 halves the K depth of a stage (64-byte rows) so that four such stages still fit LDS.
 // Big tiles read their fragments single-buffered, right after the barrier that publishes the tile.
+// HK = 1 with TM = TN = 1 is the "lean" 64x64 tile (16 KiB stages of 32 k, fragments still read one tile
+// ahead: <= 80 KiB of LDS and <= 128 VGPRs), built so that TWO workgroups fit a CU - the tile of the LSTMs
+// that run beside another role's workgroups in one launch (fused_kernels.hip).
 template <int WM, int WN, int WK, int S, int PREC = PREC_F32, int AUXB = 0, int TM = 1, int TN = 1, int HK = 0>
 struct TileCfg {
   static constexpr int kAuxB = AUXB;  // cache-policy bits of the B (weight) operand's LDS-DMA: 2 = nt (streamed once)
@@ -57,6 +60,7 @@ struct TileCfg {
   static_assert(NMW == 4 || NMW == 2, "2 or 4 active MFMA waves per workgroup");
   static_assert(kBig || S >= 3, "ring needs at least 3 stages (fragment reads run one tile ahead of the MFMAs)");
   static_assert(!kBig || (PREC != PREC_F32 && WK == 1 && NMW == 4 && S >= 2), "big tiles: 16-bit modes, no intra-workgroup split-K");
+  static_assert(!HK || PREC != PREC_F32, "half-depth stages: 16-bit modes");
   static_assert(!HK || WK == 1, "half-depth stages have no K slices");
   static constexpr int kPrec = PREC;
   static constexpr int EB = (PREC == PREC_F32) ? 4 : 2;      // element bytes
@@ -105,6 +109,8 @@ __device__ __forceinline__ void wait_vmcnt() {
 //   bool  row_ok(r)                tile row r (0 <= r < BM or BN) exists
 //   gbyte* row_ptr(r, s, plane)    address of element k = 0 of segment s in tile row r
 //                                  (plane 0 = fp32 or fp16 hi, plane 1 = fp16 lo)
+//   long  col_off(c16)             byte offset of the row's 16-byte column c16 (c16 * 16 for row-major operands)
+//   long  tile_inc(rowb)           pointer advance from one K tile to the next (rowb for row-major operands)
 //   kRange / k_lo(r) / k_hi(r)     optional per-row valid k window in elements (conv padding)
 // The K loop walks the segments tile by tile (each segment zero-padded up to a multiple of
 // KT), so per tile a lane's source address is just "previous + ROWB": one 64-bit add per
@@ -121,9 +127,20 @@ __device__ __forceinline__ void wait_vmcnt() {
 //
 // After the call `smem` holds the BM x BN result, row-major with leading dimension
 // Cfg::LDO, summed over the WK slices, visible to all threads.
-template <class Cfg, class LoaderA, class LoaderB>
+// Gate (optional): gate.seg is the index of a K segment whose A operand is produced by OTHER workgroups of the
+// same launch.  Right before the first tile of that segment is issued, ONE wave (the first loader wave) calls
+// gate.wait() - poll + acquire, which invalidates this CU's vector L1 for everybody - and the whole workgroup
+// crosses one extra barrier, so no wave loads the segment earlier.  (One poller per workgroup: 1024 waves
+// polling one counter saturated its memory channel and slowed the producers - 110 vs 88 us per step.)
+// gate.seg = -1: no gate.
+struct NoGate {
+  int seg = -1;
+  __device__ __forceinline__ void wait() const {}
+};
+
+template <class Cfg, class LoaderA, class LoaderB, class Gate = NoGate>
 __device__ __forceinline__ void gemm_tile(const LoaderA& la, const LoaderB& lb, float* smem, bool live = true,
-                                          int dbg = 0) {
+                                          int dbg = 0, const Gate gate = Gate()) {
   // `live` (does this launch have anything to do?) typically comes from a control-block load
   // that is still in flight: it is first looked at AFTER the loader waves have issued their
   // prologue DMAs, so its latency hides under theirs.  A dead launch drains and falls through.
@@ -144,6 +161,13 @@ __device__ __forceinline__ void gemm_tile(const LoaderA& la, const LoaderB& lb, 
   const int len0 = la.seglen(0), len1 = la.seglen(1), len2 = la.seglen(2);
   const int nt0 = (len0 + KT - 1) / KT, nt1 = (len1 + KT - 1) / KT, nt2 = (len2 + KT - 1) / KT;
   const int nk = nt0 + (nseg > 1 ? nt1 : 0) + (nseg > 2 ? nt2 : 0);
+  // first tile of the gated segment (uniform), or -1
+  const int gate_tile = (!live || gate.seg < 0 || gate.seg >= nseg) ? -1 : (gate.seg == 0 ? 0 : (gate.seg == 1 ? nt0 : nt0 + nt1));
+  auto gate_sync = [&]() {  // every wave of the workgroup, at the same point of the tile sequence
+    if (wave8 == 4) gate.wait();
+    __builtin_amdgcn_s_barrier();
+  };
+  if (gate_tile >= 0 && gate_tile < S - 1) gate_sync();  // (the segment starts inside the prologue tiles)
 
   f32x16 acc, acc2;
 #pragma unroll
@@ -163,7 +187,8 @@ __device__ __forceinline__ void gemm_tile(const LoaderA& la, const LoaderB& lb, 
     // (w*NA + i)*RPI + lane/C16; this lane's 16-byte column is (lane % C16) ^ swz(row).
     gbyte *qa0[NP][NA], *qa1[NP][NA], *qa2[NP][NA], *cura[NP][NA];
     gbyte *qb0[NP][NB], *qb1[NP][NB], *qb2[NP][NB], *curb[NP][NB];
-    int ca[NA], cb[NB], inca[NA], incb[NB];  // element offset of the lane's column; byte increment per tile
+    int ca[NA], cb[NB];      // element offset of the lane's column
+    long inca[NA], incb[NB];  // byte increment per tile
     int aklo[NA], akhi[NA];
 #pragma unroll
     for (int i = 0; i < NA; ++i) {
@@ -171,12 +196,12 @@ __device__ __forceinline__ void gemm_tile(const LoaderA& la, const LoaderB& lb, 
       const bool ok = la.row_ok(row) && dbg != 1;
       const int c16 = (lane % C16) ^ Cfg::swz(row);
       ca[i] = c16 * EPC;
-      inca[i] = ok ? ROWB : 0;
+      inca[i] = ok ? la.tile_inc(ROWB) : 0;
 #pragma unroll
       for (int p = 0; p < NP; ++p) {
-        qa0[p][i] = ok ? la.row_ptr(row, 0, p) + c16 * 16 : zero_addr();
-        qa1[p][i] = ok ? la.row_ptr(row, 1, p) + c16 * 16 : zero_addr();
-        qa2[p][i] = ok ? la.row_ptr(row, 2, p) + c16 * 16 : zero_addr();
+        qa0[p][i] = ok ? la.row_ptr(row, 0, p) + la.col_off(c16) : zero_addr();
+        qa1[p][i] = ok ? la.row_ptr(row, 1, p) + la.col_off(c16) : zero_addr();
+        qa2[p][i] = ok ? la.row_ptr(row, 2, p) + la.col_off(c16) : zero_addr();
         cura[p][i] = qa0[p][i];
       }
       if (LoaderA::kRange) {
@@ -190,12 +215,12 @@ __device__ __forceinline__ void gemm_tile(const LoaderA& la, const LoaderB& lb, 
       const bool ok = lb.row_ok(row) && dbg != 1;
       const int c16 = (lane % C16) ^ Cfg::swz(row);
       cb[i] = c16 * EPC;
-      incb[i] = ok ? ROWB : 0;
+      incb[i] = ok ? lb.tile_inc(ROWB) : 0;
 #pragma unroll
       for (int p = 0; p < NP; ++p) {
-        qb0[p][i] = ok ? lb.row_ptr(row, 0, p) + c16 * 16 : zero_addr();
-        qb1[p][i] = ok ? lb.row_ptr(row, 1, p) + c16 * 16 : zero_addr();
-        qb2[p][i] = ok ? lb.row_ptr(row, 2, p) + c16 * 16 : zero_addr();
+        qb0[p][i] = ok ? lb.row_ptr(row, 0, p) + lb.col_off(c16) : zero_addr();
+        qb1[p][i] = ok ? lb.row_ptr(row, 1, p) + lb.col_off(c16) : zero_addr();
+        qb2[p][i] = ok ? lb.row_ptr(row, 2, p) + lb.col_off(c16) : zero_addr();
         curb[p][i] = qb0[p][i];
       }
     }
@@ -272,6 +297,7 @@ __device__ __forceinline__ void gemm_tile(const LoaderA& la, const LoaderB& lb, 
       // big tiles: tile t has landed (fragments are read right after this barrier)
       wait_vmcnt<Cfg::kWaitCnt>();
       __builtin_amdgcn_s_barrier();       // the MFMA waves are done reading the stage tile t-1 occupied
+      if (t + S - 1 == gate_tile) gate_sync();
       if (dbg != 3) issue_tile();         // tile t+S-1 into that stage (dbg 3: measurement ablation)
     }
     wait_vmcnt<0>();  // trailing zero-block loads must land before the ring is reused
@@ -283,7 +309,10 @@ __device__ __forceinline__ void gemm_tile(const LoaderA& la, const LoaderB& lb, 
       // spare wave of a 2-MFMA-wave tile: only keeps the workgroup barriers balanced
       if (live) {
         __builtin_amdgcn_s_barrier();
-        for (int t = 0; t < nk; ++t) __builtin_amdgcn_s_barrier();
+        for (int t = 0; t < nk; ++t) {
+          __builtin_amdgcn_s_barrier();
+          if (t + S - 1 == gate_tile) gate_sync();
+        }
       }
     } else if constexpr (Cfg::kBig) {
       // TM x TN accumulators per wave, 16-bit planes; fragments single-buffered
@@ -313,6 +342,7 @@ __device__ __forceinline__ void gemm_tile(const LoaderA& la, const LoaderB& lb, 
       const int nk_run = live ? nk : 0;
       for (int t = 0; t < nk_run; ++t) {
         __builtin_amdgcn_s_barrier();  // tile t is in LDS
+        if (t + S - 1 == gate_tile) gate_sync();
         const char* st = lds + rstage * Cfg::kStageBytes;
         rstage = (rstage + 1 == S) ? 0 : rstage + 1;
         f16x8 ah[TM][NS], al[TM][NS], bh[TN][NS], bl[TN][NS];
@@ -378,9 +408,10 @@ __device__ __forceinline__ void gemm_tile(const LoaderA& la, const LoaderB& lb, 
           fb[buf][q] = *reinterpret_cast<const f32x4*>(st + boff[q]);
         }
       };
-      auto tile_step = [&](auto cur_c) {
+      auto tile_step = [&](auto cur_c, int t) {
         constexpr int cur = decltype(cur_c)::value;
         __builtin_amdgcn_s_barrier();        // B(t+1): tile t+1 is in LDS
+        if (t + S - 1 == gate_tile) gate_sync();
         // tile t's fragments were requested a whole tile ago: retire them here (no stall), in a
         // form the compiler's wait-count model sees, so it does not later drain the next reads
         __builtin_amdgcn_s_waitcnt(0xC07F);  // lgkmcnt(0) only
@@ -401,25 +432,26 @@ __device__ __forceinline__ void gemm_tile(const LoaderA& la, const LoaderB& lb, 
         read_frags(std::integral_constant<int, 0>{});
       }
       for (int t = 0; t < nk_run; t += 2) {
-        tile_step(std::integral_constant<int, 0>{});
-        if (t + 1 < nk_run) tile_step(std::integral_constant<int, 1>{});
+        tile_step(std::integral_constant<int, 0>{}, t);
+        if (t + 1 < nk_run) tile_step(std::integral_constant<int, 1>{}, t + 1);
       }
     } else {
       // 16-bit planes: per k16-step s one 16-byte fragment of A_hi (, A_lo), B_hi (, B_lo)
-      int aoff[4], boff[4];
+      constexpr int NS = Cfg::NS16;  // k16 steps per tile: 4, or 2 for half-depth stages
+      int aoff[NS], boff[NS];
 #pragma unroll
-      for (int s = 0; s < 4; ++s) {
+      for (int s = 0; s < NS; ++s) {
         const int c16 = wk * 8 + s * 2 + half;
         aoff[s] = arow * ROWB + ((c16 ^ Cfg::swz(arow)) << 4);
         boff[s] = NP * Cfg::kPlaneABytes + brow * ROWB + ((c16 ^ Cfg::swz(brow)) << 4);
       }
-      f16x8 ah[2][4], al[2][4], bh[2][4], bl[2][4];  // (bf16 data travels in the same 16-byte registers)
+      f16x8 ah[2][NS], al[2][NS], bh[2][NS], bl[2][NS];  // (bf16 data travels in the same 16-byte registers)
       auto read_frags = [&](auto buf_c) {
         constexpr int buf = decltype(buf_c)::value;
         const char* st = lds + rstage * Cfg::kStageBytes;
         rstage = (rstage + 1 == S) ? 0 : rstage + 1;
 #pragma unroll
-        for (int s = 0; s < 4; ++s) {
+        for (int s = 0; s < NS; ++s) {
           ah[buf][s] = *reinterpret_cast<const f16x8*>(st + aoff[s]);
           bh[buf][s] = *reinterpret_cast<const f16x8*>(st + boff[s]);
           if constexpr (NP == 2) {
@@ -428,15 +460,35 @@ __device__ __forceinline__ void gemm_tile(const LoaderA& la, const LoaderB& lb, 
           }
         }
       };
-      auto tile_step = [&](auto cur_c) {
+      auto tile_step = [&](auto cur_c, int t) {
         constexpr int cur = decltype(cur_c)::value;
         __builtin_amdgcn_s_barrier();
+        if (t + S - 1 == gate_tile) gate_sync();
         __builtin_amdgcn_s_waitcnt(0xC07F);  // lgkmcnt(0) only (see the fp32 path)
         read_frags(std::integral_constant<int, cur ^ 1>{});
-        __builtin_amdgcn_sched_barrier(0);
-        if (dbg != 4) {
+        // Interleave the next tile's fragment reads with this tile's MFMAs (two ds_read_b128 per MFMA gap are
+        // nearly free, MI355X_MICROARCH.md LDS section).  With all reads pinned in front of the chain the
+        // MFMA waves spent 16 read-issue slots + 12 MFMAs in series per tile: 0.31 us per tile with no DMA at
+        // all (round 1 ablation), more than the operand stream itself needs.
+        if constexpr (Cfg::kPrec == PREC_F16S) {
 #pragma unroll
-          for (int s = 0; s < 4; ++s) {
+          for (int s = 0; s < NS; ++s) {
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+            __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+            __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+          }
+        } else {
+#pragma unroll
+          for (int s = 0; s < NS; ++s) {
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+            __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
+          }
+        }
+        {  // (no runtime branch here: reads and MFMAs must sit in ONE basic block to be interleaved)
+#pragma unroll
+          for (int s = 0; s < NS; ++s) {
             if constexpr (Cfg::kPrec == PREC_F16S) {
               acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[cur][s], bh[cur][s], acc, 0, 0, 0);
               acc2 = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[cur][s], bl[cur][s], acc2, 0, 0, 0);
@@ -454,8 +506,8 @@ __device__ __forceinline__ void gemm_tile(const LoaderA& la, const LoaderB& lb, 
         read_frags(std::integral_constant<int, 0>{});
       }
       for (int t = 0; t < nk_run; t += 2) {
-        tile_step(std::integral_constant<int, 0>{});
-        if (t + 1 < nk_run) tile_step(std::integral_constant<int, 1>{});
+        tile_step(std::integral_constant<int, 0>{}, t);
+        if (t + 1 < nk_run) tile_step(std::integral_constant<int, 1>{}, t + 1);
       }
       if constexpr (Cfg::kPrec == PREC_F16S) {
 #pragma unroll

@@ -78,6 +78,7 @@ struct LstmArgs {
   Seg3 a_lo, w_lo;  // fp16 lo planes (prec = 1 only)
   int prec;         // 0 = exact fp32 MFMA, 1 = split-fp16 MFMA
   f16 *h_out_h, *h_out_l;  // optional split planes of h_out
+  int out_mpad;            // > 0: those planes are in the chunked layout with this many rows per chunk (common.h Seg3)
   const float* bsum;    // [4H] = b_ih + b_hh
   const float* h_prev;  // [M, H]
   float* c;             // [M, H] updated in place
@@ -104,6 +105,10 @@ struct LstmArgs {
   int slot;
   int dbg;  // measurement ablations (ttsdec_profile_step only): 1 = every load reads the zero block
   int tag;  // 1 = the decoder LSTM of a decode step (separate kernel symbol for profilers), else 0
+  int live_lag;  // 1: this cell runs in the same launch as the frame kernel of its step (see lstm_body)
+  // Two-role launch: K segment dep_seg of the A operand is produced by the other role's dep_n workgroups of this
+  // very launch (dep_which 0: frame kernel -> Ctrl::dep_frame, 1: attention -> Ctrl::dep_attn); dep_n = 0: no gate.
+  int dep_n, dep_seg, dep_which;
 };
 void launch_lstm(const LstmArgs& a, hipStream_t st);
 void launch_lstm_pair(const LstmArgs& a0, const LstmArgs& a1, hipStream_t st);  // two same-shape fp32 cells, one launch
@@ -119,7 +124,9 @@ struct AttnArgs {
   float* w_out;         // [B, t_stride, L] (row t_rel) or nullptr
   float* ctx;           // [B, D]
   f16 *ctx_h, *ctx_l;   // optional split-fp16 planes of ctx
+  int out_mpad;         // > 0: chunked layout of those planes (common.h Seg3)
   int ctx_only;         // 1: no weight update, just ctx = sum_l w_prev[l] * memory[l] (decoder_cell.py:118)
+  int dep_signal;       // 1: two-role launch - every workgroup signals Ctrl::dep_attn after its last store
   int B, L, D, t_rel, t_stride;
   Ctrl* ctrl;  // != nullptr: memory, w_out, t_rel, t_stride come from *ctrl
   int slot;
@@ -160,14 +167,25 @@ struct FrameArgs {
   float keep_scale;
   float* xpre;           // [M, P]
   f16 *xpre_h, *xpre_l;  // optional split-fp16 planes
+  int out_mpad;          // > 0: chunked layout of those planes (common.h Seg3)
   int M;
   Ctrl* ctrl;
   int slot;
   int t;    // ctrl == nullptr
   int dbg;  // measurement ablations (ttsdec_profile_step only): bit 1 = no layer-0 MFMAs, bit 2 = no layer-1 MFMAs
+  int dep_signal;  // 1: two-role launch - every workgroup signals Ctrl::dep_frame after its last store
 };
 bool frame_supported(int d_mel, int r, int Ph, int P);
 void launch_frame(const FrameArgs& a, hipStream_t st);
+
+// ---- two-role launches (fused_kernels.hip): a latency-bound kernel and the early part of the next LSTM ----
+// The LstmArgs must be a split-fp16 cell with M >= 192 whose gated K segment (dep_seg) comes last; its gate GEMM
+// runs on the lean tile.
+bool fused_supported(int d_mel, int r, int Ph, int P, int D);
+int frame_grid_size(int M, int P);                                              // workgroups of the frame role
+void launch_frame_lstm(const FrameArgs& f, const LstmArgs& l, hipStream_t st);  // frame kernel || attention LSTM
+void launch_attn_lstm(const AttnArgs& a, const LstmArgs& l, hipStream_t st);    // attention || decoder LSTM
+void launch_lstm_lean(const LstmArgs& l, hipStream_t st);                       // an LSTM on the lean tile alone (profiling)
 
 // ---- state init / bookkeeping ----
 struct InitArgs {
@@ -178,6 +196,7 @@ struct InitArgs {
   float* w;                                        // [B, L]
   float* ynext;                                    // [B, d_mel]
   f16 *h_att_h, *h_att_l, *h_dec_h, *h_dec_l, *ctx_h, *ctx_l;  // split planes of the initial state
+  int out_mpad;  // > 0: chunked layout of those planes (common.h Seg3)
   const float* memory;  // != nullptr: ctx_0 = bmm(w_0, memory) = memory[:, 0, :] (Taco2DecoderCell, decoder_cell.py:118)
   int B, L, D, Ha, Hd, d_mel;
 };
@@ -192,6 +211,7 @@ struct CallArgs {  // copied into *ctrl by launch_set_call at the start of every
   const float* teacher;
   const uint8_t* teacher_flags;
   float *y, *s, *w;
+  unsigned long long* stamps;  // measurement only
 };
 void launch_set_call(Ctrl* ctrl, const CallArgs& a, hipStream_t st);
 void launch_advance(Ctrl* ctrl, int n_slots, hipStream_t st);
@@ -200,6 +220,11 @@ void launch_advance(Ctrl* ctrl, int n_slots, hipStream_t st);
 void launch_add_vec(const float* a, const float* b, float* out, int n, hipStream_t st);
 void launch_copy(const float* src, float* dst, size_t n, hipStream_t st);
 void launch_split(const float* src, f16* hi, f16* lo, size_t n, hipStream_t st);
+// src [M, K] row-major -> split-fp16 planes in the chunked layout [K / 32][mpad][32] (common.h Seg3)
+void launch_split_chunked(const float* src, f16* hi, f16* lo, int M, int K, int mpad, hipStream_t st);
+// LSTM weight matrix src [4H, K] (PyTorch gate blocks i,f,g,o) -> chunked split-fp16 planes
+// [H / 16][K / 32][gate * 16 + unit % 16][32]  (step_bodies.h LoaderWLstm); needs H % 16 == 0, K % 32 == 0
+void launch_pack_lstm_chunked(const float* src, f16* hi, f16* lo, int H, int K, hipStream_t st);
 void launch_to_bf16(const float* src, void* dst, size_t n, hipStream_t st);
 // *out = max(*out, max |src[i]|)  (*out must hold a non-negative float, e.g. 0)
 void launch_absmax(const float* src, size_t n, float* out, hipStream_t st);

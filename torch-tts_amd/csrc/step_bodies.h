@@ -1,0 +1,362 @@
+// Device-side bodies of the decode step's big kernels, shared by their stand-alone launches
+// (decode_kernels.hip) and by the launches that run two independent roles side by side (fused_kernels.hip).
+// Each body takes its LDS as a pointer into the calling kernel's ONE __shared__ array and its tile
+// coordinates as arguments, so a kernel can give different workgroups different roles.
+#pragma once
+#include "gemm_tile.h"
+#include "kernels.h"
+
+namespace ttsdec {
+
+// rows m0.. of an [M, K] activation made of up to three K segments; EB-byte elements,
+// plane 1 (fp16 lo) comes from a second Seg3 of identical shape
+template <int EB>
+struct LoaderPlain {
+  Seg3 s, s_lo;
+  int m0, M;
+  static constexpr bool kRange = false;
+  __device__ __forceinline__ int nseg() const { return seg_count(s); }
+  __device__ __forceinline__ int seglen(int i) const { return seg_len(s, i); }
+  __device__ __forceinline__ bool row_ok(int r) const { return m0 + r < M; }
+  __device__ __forceinline__ gbyte* row_ptr(int r, int i, int plane) const {
+    return seg_row_ptr<EB>(plane == 0 ? s : s_lo, m0 + r, i);
+  }
+  __device__ __forceinline__ int k_lo(int) const { return 0; }
+  __device__ __forceinline__ int k_hi(int) const { return 0; }
+  __device__ __forceinline__ long col_off(int c16) const { return seg_col_off(s, c16); }
+  __device__ __forceinline__ long tile_inc(int rowb) const { return seg_tile_inc(s, rowb); }
+};
+
+// ===========================================================================
+// LSTMZoneoutCell (eval), tacotron/modules/rnn.py:24-39.  A workgroup owns BU hidden
+// units x BM batch rows and computes all four gates of those units (B-tile rows are
+// gathered from the i/f/g/o row blocks of the PyTorch-layout weights), so the cell
+// update happens in the epilogue without another pass.
+// ===========================================================================
+template <int BU, int EB>
+struct LoaderWLstm {
+  Seg3 w, w_lo;
+  int u0, H;
+  static constexpr bool kRange = false;
+  __device__ __forceinline__ int nseg() const { return seg_count(w); }
+  __device__ __forceinline__ int seglen(int i) const { return seg_len(w, i); }
+  __device__ __forceinline__ bool row_ok(int r) const { return u0 + (r % BU) < H; }
+  __device__ __forceinline__ gbyte* row_ptr(int r, int i, int plane) const {
+    const Seg3& s = plane == 0 ? w : w_lo;
+    if (s.mpad != 0) {
+      // chunked weights (pack_lstm_chunked_kernel): [16-unit block][chunk][gate * 16 + unit % 16][32 k]; the segment
+      // pointer is chunk 0 of the segment in unit block 0, ld the matrix's chunks per unit block
+      const void* p = i == 0 ? s.p0 : (i == 1 ? s.p1 : s.p2);
+      const int nch = i == 0 ? s.ld0 : (i == 1 ? s.ld1 : s.ld2);
+      const int u = u0 + (r % BU);
+      return as_global(p) + ((long)(u >> 4) * nch * 64 + (r / BU) * 16 + (u & 15)) * kChunkBytes;
+    }
+    return seg_row_ptr<EB>(s, (r / BU) * H + u0 + (r % BU), i);  // PyTorch gate blocks i,f,g,o
+  }
+  __device__ __forceinline__ long col_off(int c16) const { return w.mpad != 0 ? (long)(c16 >> 2) * 64 * kChunkBytes + (c16 & 3) * 16 : (long)c16 * 16; }
+  __device__ __forceinline__ long tile_inc(int rowb) const { return w.mpad != 0 ? (long)(rowb / kChunkBytes) * 64 * kChunkBytes : (long)rowb; }
+};
+
+// smem: Cfg::kLdsFloats floats of LDS (the caller's ONE shared array); (bx, by): unit block / row block.
+struct RoleGate {
+  int seg;
+  const unsigned int* counter;
+  unsigned int target;
+  Ctrl* ctrl;
+  int kind;
+  __device__ __forceinline__ void wait() const {
+    stamp(ctrl, kind, 3, now_rt());
+    role_wait(counter, target, ctrl);
+    stamp(ctrl, kind, 4, now_rt());
+  }
+};
+
+// kEarlyEpi: request the cell-update operands before the K loop (their latency hides under it); the lean tile
+// requests them after it instead - 20 live registers fewer across the loop, to stay within 128 VGPRs.
+template <class Cfg, bool kEarlyEpi = true>
+__device__ __forceinline__ void lstm_body(LstmArgs g, float* smem, int bx, int by) {
+  bool live = true;
+  if (g.ctrl != nullptr) {
+    // live_lag: this launch also holds the frame kernel's workgroups, which may lower stop_t to t-1 while it is
+    // being read here; t-1 <= stop_t cannot be changed by that, so every wave takes the same decision (a wave
+    // that disagreed with its workgroup about `live` would miss the tile loop's barriers)
+    const int t = g.ctrl->t_cur + g.slot;
+    live = t < g.ctrl->t_end && t - (g.live_lag ? 1 : 0) <= g.ctrl->stop_t;
+  }
+  constexpr int BM = Cfg::BM, BN = Cfg::BN, LDO = Cfg::LDO, BU = BN / 4, EB = Cfg::EB;
+  constexpr int EPT = (BM * BU + kGemmThreads - 1) / kGemmThreads;  // (row, unit) pairs per thread
+  const int m0 = by * BM;
+  const int u0 = bx * BU;
+  const int H = g.H;
+
+  float pb[EPT][4], pc[EPT], ph[EPT], pp[EPT][4];
+  auto load_epi = [&]() {
+#pragma unroll
+  for (int j = 0; j < EPT; ++j) {
+    const int e = threadIdx.x + j * kGemmThreads;
+    const int m = m0 + e / BU, unit = u0 + e % BU;
+    const bool ok = live && e < BM * BU && m < g.M && unit < H && g.mode != 1;
+    const size_t idx = (size_t)m * H + unit;
+    size_t pidx = (size_t)m * 4 * H + unit;
+    const float* part = g.partial;
+    bool pok = ok && g.mode == 2;
+    if (g.seq_lens != nullptr && ok) {  // packed-sequence step: this row's input projection at its own position
+      const int len = g.seq_lens[m];
+      const int pos = g.seq_reverse ? len - 1 - g.seq_t : g.seq_t;
+      pok = g.seq_t < len;
+      part = g.gx;
+      pidx = ((size_t)m * g.seq_L + (pok ? pos : 0)) * g.gx_ld + g.gx_off + unit;
+    }
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      pb[j][k] = (ok && g.bsum != nullptr) ? g.bsum[k * H + unit] : 0.f;
+      pp[j][k] = pok ? part[pidx + (size_t)k * H] : 0.f;
+    }
+    pc[j] = ok ? g.c[idx] : 0.f;
+    ph[j] = ok ? g.h_prev[idx] : 0.f;
+  }
+  };
+  if constexpr (kEarlyEpi) load_epi();
+
+  const LoaderPlain<EB> la{g.a, g.a_lo, m0, g.M};
+  const LoaderWLstm<BU, EB> lb{g.w, g.w_lo, u0, g.H};
+  RoleGate gate;
+  gate.seg = -1; gate.counter = nullptr; gate.target = 0; gate.ctrl = g.ctrl; gate.kind = g.dep_which;
+  if (g.dep_n > 0 && threadIdx.x == 0) {
+    stamp(g.ctrl, g.dep_which, 0, (1ull << 32) | __builtin_amdgcn_s_getreg((4 << 0) | (0 << 6) | (31 << 11)));
+    stamp(g.ctrl, g.dep_which, 1, __builtin_amdgcn_s_getreg((20 << 0) | (0 << 6) | (3 << 11)));
+    stamp(g.ctrl, g.dep_which, 2, now_rt());
+  }
+  if (g.dep_n > 0) {
+    gate.seg = g.dep_seg;
+    if (g.ctrl != nullptr) {  // (no control block = profiling: the producers' data is whatever the last launch left)
+      gate.counter = g.dep_which ? &g.ctrl->dep_attn : &g.ctrl->dep_frame;
+      gate.target = (unsigned int)(g.ctrl->t_cur + g.slot - g.ctrl->t_call + 1) * (unsigned int)g.dep_n;
+    }
+  }
+  gemm_tile<Cfg>(la, lb, smem, live, g.dbg, gate);
+  if (!live) return;
+  if constexpr (!kEarlyEpi) load_epi();
+
+#pragma unroll
+  for (int j = 0; j < EPT; ++j) {
+    const int e = threadIdx.x + j * kGemmThreads;
+    const int row = e / BU, u = e % BU;
+    const int m = m0 + row, unit = u0 + u;
+    if (e >= BM * BU || m >= g.M || unit >= H) continue;
+    const float* tr = smem + row * LDO;
+    float si = tr[0 * BU + u], sf = tr[1 * BU + u], sg = tr[2 * BU + u], so = tr[3 * BU + u];
+    const size_t pidx = (size_t)m * 4 * H + unit;
+    if (g.mode == 1) {  // early part: park the raw gate sums
+      g.partial[pidx] = si;
+      g.partial[pidx + H] = sf;
+      g.partial[pidx + 2 * H] = sg;
+      g.partial[pidx + 3 * H] = so;
+      continue;
+    }
+    const size_t idx = (size_t)m * H + unit;
+    int seq_pos = 0;
+    if (g.seq_lens != nullptr) {
+      const int len = g.seq_lens[m];
+      if (g.seq_t >= len) {  // this utterance has ended: state is carried unchanged, nothing is emitted
+        g.h_out[idx] = ph[j];
+        continue;
+      }
+      seq_pos = g.seq_reverse ? len - 1 - g.seq_t : g.seq_t;
+    }
+    if (g.mode == 2) {  // finishing part: early sums + the late segments (fixed order: deterministic)
+      si = add_rn(pp[j][0], si);
+      sf = add_rn(pp[j][1], sf);
+      sg = add_rn(pp[j][2], sg);
+      so = add_rn(pp[j][3], so);
+    }
+    const float gi = add_rn(si, pb[j][0]);
+    const float gf = add_rn(sf, pb[j][1]);
+    const float gg = add_rn(sg, pb[j][2]);
+    const float go = add_rn(so, pb[j][3]);
+    const float c_prev = pc[j];
+    const float h_prev = ph[j];
+    // nn.LSTMCell: c' = sigmoid(f)*c + sigmoid(i)*tanh(g); h' = sigmoid(o)*tanh(c')
+    const float c_new = add_rn(mul_rn(sigmoid_f(gf), c_prev), mul_rn(sigmoid_f(gi), tanhf(gg)));
+    const float h_new = mul_rn(sigmoid_f(go), tanhf(c_new));
+    // rnn.py:36-38 eval-mode zoneout: p*prev + (1-p)*new
+    const float q = sub_rn(1.0f, g.pz);
+    const float h = add_rn(mul_rn(g.pz, h_prev), mul_rn(q, h_new));
+    g.h_out[idx] = h;
+    if (g.h_out_h != nullptr) {
+      const size_t o = g.out_mpad > 0 ? chunk_idx(m, unit, g.out_mpad) : idx;
+      split_f16(h, g.h_out_h[o], g.h_out_l[o]);
+    }
+    if (g.seq_out != nullptr) g.seq_out[((size_t)m * g.seq_Lout + seq_pos) * g.seq_out_ld + g.seq_out_off + unit] = h;
+    g.c[idx] = add_rn(mul_rn(g.pz, c_prev), mul_rn(q, c_new));
+  }
+  if (g.dep_n > 0 && threadIdx.x == 0) stamp(g.ctrl, g.dep_which, 5, now_rt());
+}
+
+// ===========================================================================
+// StepwiseMonotonicAttention + context (tacotron/modules/attention.py:104-126,
+// tacotron/decoder_cell.py:189).  One workgroup per utterance, 8 waves; a wave
+// owns a contiguous range of memory rows and makes ONE pass over them: each row
+// is loaded once (float4 per lane, coalesced), dotted with q (wave butterfly),
+// turned into p0 and the new weight, and accumulated into the context while it
+// is still in registers.  Row l needs p0[l-1], so a wave recomputes the energy
+// of the row just before its range.
+// ===========================================================================
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int off = 32; off >= 1; off >>= 1) v += __shfl_xor(v, off, 64);
+  return v;
+}
+
+// part: kAttnThreads / 64 * NJ * 256 floats of LDS (the caller's ONE shared array); b: the utterance.
+template <int NJ>
+__device__ __forceinline__ void attn_body(AttnArgs g, float* part, int b) {
+  if (g.ctrl != nullptr) {
+    const Ctrl* c = g.ctrl;
+    const StepNow now = step_now(c, g.slot);
+    if (!now.live) return;
+    g.memory = c->memory;
+    g.w_out = c->w;
+    g.t_rel = now.t_rel;
+    g.t_stride = c->t_stride;
+  }
+  constexpr int NW = kAttnThreads / 64;
+  if (g.dep_signal && threadIdx.x == 0) {
+    stamp(g.ctrl, 1, 0, __builtin_amdgcn_s_getreg((4 << 0) | (0 << 6) | (31 << 11)));
+    stamp(g.ctrl, 1, 1, __builtin_amdgcn_s_getreg((20 << 0) | (0 << 6) | (3 << 11)));
+    stamp(g.ctrl, 1, 2, now_rt());
+  }
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const int L = g.L, D = g.D, D4 = D >> 2;
+  const float* mem = g.memory + (size_t)b * L * D;
+  const float* wprev = g.w_prev + (size_t)b * L;
+  float* wnew = g.w_new + (size_t)b * L;
+  float* wout = g.w_out ? g.w_out + ((size_t)b * g.t_stride + g.t_rel) * L : nullptr;
+
+  float4 qv[NJ];
+#pragma unroll
+  for (int j = 0; j < NJ; ++j) {
+    const int c4 = lane + 64 * j;
+    qv[j] = (c4 < D4 && !g.ctx_only) ? *reinterpret_cast<const float4*>(g.q + (size_t)b * D + c4 * 4)
+                                     : make_float4(0.f, 0.f, 0.f, 0.f);  // ctx_only: no query, energies unused
+  }
+  if (!g.ctx_only) {  // split-K query: add the partial slabs in index order
+    for (int z = 1; z < g.q_parts; ++z) {
+#pragma unroll
+      for (int j = 0; j < NJ; ++j) {
+        const int c4 = lane + 64 * j;
+        if (c4 < D4) {
+          const float4 v = *reinterpret_cast<const float4*>(g.q + z * g.q_stride + (size_t)b * D + c4 * 4);
+          qv[j].x = add_rn(qv[j].x, v.x); qv[j].y = add_rn(qv[j].y, v.y);
+          qv[j].z = add_rn(qv[j].z, v.z); qv[j].w = add_rn(qv[j].w, v.w);
+        }
+      }
+    }
+  }
+  auto load_row = [&](int l, float4 (&r)[NJ]) {
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) {
+      const int c4 = lane + 64 * j;
+      r[j] = (c4 < D4) ? *reinterpret_cast<const float4*>(mem + (size_t)l * D + c4 * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+  };
+  auto dot_row = [&](const float4 (&r)[NJ]) {
+    float s = 0.f;
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) {
+      s = fmaf(r[j].x, qv[j].x, s);
+      s = fmaf(r[j].y, qv[j].y, s);
+      s = fmaf(r[j].z, qv[j].z, s);
+      s = fmaf(r[j].w, qv[j].w, s);
+    }
+    return wave_sum(s);
+  };
+
+  const int chunk = (L + NW - 1) / NW;
+  const int l0 = wv * chunk;
+  const int l1 = (l0 + chunk < L) ? l0 + chunk : L;
+
+  float4 acc[NJ];
+#pragma unroll
+  for (int j = 0; j < NJ; ++j) acc[j] = make_float4(0.f, 0.f, 0.f, 0.f);
+
+  if (l0 < l1) {
+    float w1_prev = 0.f;  // w[l-1] * (1 - p0[l-1])   attention.py:120
+    if (l0 > 0) {
+      float4 r[NJ];
+      load_row(l0 - 1, r);
+      const float p0 = isru_sigmoid(dot_row(r));  // l0-1 < L-1, never the overridden column
+      w1_prev = mul_rn(wprev[l0 - 1], sub_rn(1.0f, p0));
+    }
+    constexpr int G = 4;  // rows in flight per wave (8 measured slower, 17.2 vs 15.2 us; all 15 rows of a wave at once 18.2 vs 15.6 us at
+                          // B = 256 and no faster at B = 1: the pass runs at the Infinity-Cache rate, not at a latency chain's)
+    for (int lb = l0; lb < l1; lb += G) {
+      float4 r[G][NJ];
+      float e[G];
+#pragma unroll
+      for (int i = 0; i < G; ++i)
+        if (lb + i < l1) load_row(lb + i, r[i]);
+#pragma unroll
+      for (int i = 0; i < G; ++i)
+        if (lb + i < l1) e[i] = dot_row(r[i]);
+#pragma unroll
+      for (int i = 0; i < G; ++i) {
+        const int l = lb + i;
+        if (l < l1) {
+          const float en = (l == L - 1) ? 1e4f : e[i];  // attention.py:117
+          const float p0 = isru_sigmoid(en);            // attention.py:118
+          const float wl = wprev[l];
+          const float w0 = mul_rn(wl, p0);                      // :119
+          float wn = (l > 0) ? add_rn(w0, w1_prev) : w0;        // :122-123
+          w1_prev = mul_rn(wl, sub_rn(1.0f, p0));               // :120
+          if (g.ctx_only) wn = wl;
+          if (lane == 0 && !g.ctx_only) {
+            wnew[l] = wn;
+            if (wout) wout[l] = wn;
+          }
+#pragma unroll
+          for (int j = 0; j < NJ; ++j) {
+            acc[j].x = fmaf(wn, r[i][j].x, acc[j].x);
+            acc[j].y = fmaf(wn, r[i][j].y, acc[j].y);
+            acc[j].z = fmaf(wn, r[i][j].z, acc[j].z);
+            acc[j].w = fmaf(wn, r[i][j].w, acc[j].w);
+          }
+        }
+      }
+    }
+  }
+  // cross-wave sum of the context partials in a fixed order (deterministic)
+#pragma unroll
+  for (int j = 0; j < NJ; ++j)
+    *reinterpret_cast<float4*>(part + ((wv * NJ + j) * 64 + lane) * 4) = acc[j];
+  __syncthreads();
+  for (int d = threadIdx.x; d < D; d += kAttnThreads) {
+    const int c4 = d >> 2, comp = d & 3;
+    const int j = c4 >> 6, ln = c4 & 63;
+    float s = 0.f;
+#pragma unroll
+    for (int w = 0; w < NW; ++w) s += part[((w * NJ + j) * 64 + ln) * 4 + comp];
+    const size_t o = g.out_mpad > 0 ? chunk_idx(b, d, g.out_mpad) : (size_t)b * D + d;
+    if (g.dep_signal) {  // handed to the decoder LSTM of this very launch: write-through (see role_signal)
+      store_wt(g.ctx + (size_t)b * D + d, s);
+      if (g.ctx_h != nullptr) {
+        f16 hi, lo;
+        split_f16_checked(s, hi, lo, g.ctrl);
+        store_wt(g.ctx_h + o, hi);
+        store_wt(g.ctx_l + o, lo);
+      }
+    } else {
+      g.ctx[(size_t)b * D + d] = s;
+      if (g.ctx_h != nullptr) split_f16_checked(s, g.ctx_h[o], g.ctx_l[o], g.ctrl);
+    }
+  }
+  if (g.dep_signal && g.ctrl != nullptr) {
+    role_signal(&g.ctrl->dep_attn);  // the decoder LSTM of this launch waits for ctx
+    if (threadIdx.x == 0) stamp(g.ctrl, 1, 5, now_rt());
+  }
+}
+
+template <int NJ>
+constexpr int attn_lds_floats() { return kAttnThreads / 64 * NJ * 256; }
+
+}  // namespace ttsdec

@@ -127,6 +127,8 @@ class Decoder(PackedWeightsMixin, nn.Module):
             )
             done, flags = (int(v) for v in t_out.tolist())  # the one host sync of this chunk
             fired = flags & 1
+            if flags & 4:
+                raise RuntimeError("decode step: a two-role launch timed out waiting for its producer role (GPU shared or stalled); results discarded")
             if flags & 2:
                 raise RuntimeError(
                     "split_f16 precision: an activation (input/teacher frame, PreNet output or context) exceeded the fp16 "
