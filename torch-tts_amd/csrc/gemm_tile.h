@@ -359,6 +359,17 @@ __device__ __forceinline__ void gemm_tile(const LoaderA& la, const LoaderB& lb, 
             if constexpr (NP == 2) bl[j][s] = *reinterpret_cast<const f16x8*>(st + Cfg::kPlaneBBytes + boff[j][s]);
           }
         }
+        // k16 step 0's fragments first, then step 1's reads ride in the gaps of step 0's MFMAs (one per gap)
+        {
+          constexpr int kReads = (TM + TN) * NP, kMfma = TM * TN * (Cfg::kPrec == PREC_F16S ? 3 : 1);
+          __builtin_amdgcn_sched_group_barrier(0x100, kReads, 0);
+          if constexpr (NS > 1) {
+            static_for<(kReads < kMfma ? kReads : kMfma)>([&](auto) {
+              __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+              __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+            });
+          }
+        }
 #pragma unroll
         for (int s = 0; s < NS; ++s)
 #pragma unroll
