@@ -1,9 +1,10 @@
 #!/usr/bin/env python3
 """Golden vectors for the VITS2 path, produced by importing the reference's
-own building blocks (vits2/attentions.py, modules.py, commons.py) on CPU.  vits2/models.py is NOT
-imported (it needs the unbuilt monotonic_align extension); the glue of TextEncoder.forward and of the
-reverse coupling layer is composed HERE from the reference blocks, following models.py:369-380,
-506-531 and 803-810, and is marked as such in the fixture's meta.
+own modules (vits2/attentions.py, modules.py, commons.py, models.py) on CPU.  The vectors are first composed step
+by step from the reference blocks following models.py:369-380, 506-531 and 803-810 (that also gives intermediate
+vectors), and then reproduced bit for bit by models.TextEncoder / models.ResidualCouplingTransformersBlock
+themselves: models.py is importable once monotonic_align/core.pyx - the reference's own source - is compiled into a
+scratch directory (done below; Cython is in the image).
 
     PYTHONDONTWRITEBYTECODE=1 python tests/golden/make_golden_vits2.py
 
@@ -142,9 +143,67 @@ with torch.no_grad():
         out[f"short{Ts}/ids"] = ids_s.numpy(); out[f"short{Ts}/lengths"] = len_s.numpy()
         out[f"short{Ts}/x"] = enc(xs * ms, ms).numpy()
 
+
+
+# ---- the same through vits2/models.py ITSELF ----
+# models.py:12 imports monotonic_align, whose __init__ wants the compiled extension monotonic_align.monotonic_align.core.
+# Build exactly that from the reference's own core.pyx (Cython is in the image) into a scratch directory - nothing is
+# written under /root/reference, nothing of the reference is copied into this repository - and register it under the
+# name the package asks for.  Then models.TextEncoder and models.ResidualCouplingTransformersBlock are instantiated,
+# given the weights above, and must reproduce the composed vectors bit for bit: the te/* and flow/* arrays of the
+# fixture ARE outputs of models.py.
+def import_reference_models():
+    import importlib.machinery
+    import importlib.util
+    import subprocess
+    import sysconfig
+    import tempfile
+    import types
+
+    scratch = tempfile.mkdtemp(prefix="vits2_ma_")
+    c_file = os.path.join(scratch, "core.c")
+    subprocess.run([sys.executable, "-m", "cython", "-3", "-o", c_file, os.path.join(REF, "monotonic_align", "core.pyx")], check=True)
+    so = os.path.join(scratch, "core" + sysconfig.get_config_var("EXT_SUFFIX"))
+    subprocess.run(["gcc", "-O2", "-shared", "-fPIC", "-I" + sysconfig.get_paths()["include"], "-I" + np.get_include(), c_file, "-o", so],
+                   check=True)
+    sub = types.ModuleType("monotonic_align.monotonic_align")  # (the directory setup.py build_ext --inplace would make)
+    sub.__path__ = [scratch]
+    sys.modules["monotonic_align.monotonic_align"] = sub
+    loader = importlib.machinery.ExtensionFileLoader("monotonic_align.monotonic_align.core", so)
+    spec = importlib.util.spec_from_loader("monotonic_align.monotonic_align.core", loader)
+    core = importlib.util.module_from_spec(spec)
+    loader.exec_module(core)
+    sys.modules["monotonic_align.monotonic_align.core"] = core
+    import models  # the reference's vits2/models.py
+
+    return models
+
+
+models = import_reference_models()
+with torch.no_grad():
+    te_ref = models.TextEncoder(D["n_vocab"], I, H, D["filter_channels"], D["n_heads"], D["n_layers"], D["kernel_size"], 0.1).eval()
+    te_ref.load_state_dict({k[len("w/enc_p."):]: torch.from_numpy(v) for k, v in out.items() if k.startswith("w/enc_p.")})
+    rx, rm, rlogs, rmask = te_ref(ids, lengths)                                   # models.py:369-380
+    fl_ref = models.ResidualCouplingTransformersBlock(I, Fh, D["flow_kernel"], 1, D["flow_wn_layers"], n_flows=D["n_flows"],
+                                                      use_transformer_flows=True, transformer_flow_type="pre_conv").eval()
+    missing, unexpected = fl_ref.load_state_dict({k[len("w/flow."):]: torch.from_numpy(v) for k, v in out.items() if k.startswith("w/flow.")},
+                                                 strict=False)
+    assert not unexpected and all("post_transformer" in k for k in missing), (missing, unexpected)  # (unused by forward, models.py:513-515)
+    rflow = fl_ref(z, y_mask, reverse=True)                                        # models.py:803-810
+via_models = {
+    "te/x": float((rx - xe).abs().max()), "te/m": float((rm - m).abs().max()), "te/logs": float((rlogs - logs).abs().max()),
+    "flow/out": float((rflow - xx).abs().max()),
+}
+print("models.py vs the composition (max abs diff):", via_models)
+assert all(v == 0.0 for v in via_models.values()), via_models
+assert torch.equal(rmask, x_mask)
+
 np.savez_compressed(os.path.join(HERE, "vits2_small.npz"), **out)
-json.dump({"dims": D, "reference": "kgoba/torch-tts @ 2024_10_08, vits2/{attentions,modules,commons}.py imported on CPU",
-           "glue": "TextEncoder.forward and the reverse coupling layer are composed in make_golden_vits2.py from the reference blocks "
-                   "(models.py is not importable here: monotonic_align is an unbuilt extension)",
+json.dump({"dims": D, "reference": "kgoba/torch-tts @ 2024_10_08, vits2/{attentions,modules,commons,models}.py imported on CPU",
+           "glue": "te/* and flow/* equal, bit for bit, the outputs of models.TextEncoder.forward and "
+                   "models.ResidualCouplingTransformersBlock.forward(reverse=True) themselves (vits2/models.py imported with "
+                   "monotonic_align/core.pyx compiled into a scratch directory); the step-by-step composition in "
+                   "make_golden_vits2.py is kept because it also yields the intermediate vectors (flow/wn_out_first, unit/*)",
+           "models_py_vs_composition_maxabs": via_models,
            "torch": torch.__version__}, open(os.path.join(HERE, "vits2_meta.json"), "w"), indent=1)
 print("wrote", len(out), "arrays")

@@ -100,7 +100,13 @@ def test_flow_reverse_default_dims_vs_oracle(B, T, lengths):
     fl = _flow({**d.__dict__}, wts)
     with torch.no_grad():
         out = fl(z.cuda(), ymask.cuda(), reverse=True)
-    _close(out, ref, "flow out", rtol=2e-4, atol=2e-4)
+    # north_star's bar (1e-4 relative, 1e-5 absolute floor).  Through 4 coupling layers the fp32 ORACLE's own rounding
+    # noise is 0.6 of that bar (measured against its fp64 run, tools/vits2_error_probe.py: 6.9e-6 on values near zero),
+    # the HIP path's 0.3 - so the HIP path is held to the bar against the oracle evaluated in fp64, and to 2x the bar
+    # against the fp32 oracle (two fp32 evaluations of the same function).
+    ref64 = V.flow_reverse(z.double(), ymask.double(), {k: v.double() for k, v in wts.items()}, d).float()
+    _close(out, ref64, "flow out vs fp64 oracle", rtol=1e-4, atol=1e-5)
+    _close(out, ref, "flow out", rtol=2e-4, atol=2e-5)
     # reverse flow only ever subtracts from x1: the x0 half of the last layer passes through bit-exactly
     assert torch.equal(out.cpu()[:, : d.inter_channels // 2] != 0, ref[:, : d.inter_channels // 2] != 0)
 
@@ -134,8 +140,8 @@ def test_flow_reverse_long_sequence_uses_the_scalar_attention_fallback():
     z = torch.randn(B, d.inter_channels, T, generator=g)
     lens = torch.tensor([T - 37])
     ymask = V.sequence_mask(lens, T).unsqueeze(1).float()
-    ref = V.flow_reverse(z, ymask, wts, d)
+    ref64 = V.flow_reverse(z.double(), ymask.double(), {k: v.double() for k, v in wts.items()}, d).float()
     fl = _flow({**d.__dict__}, wts)
     with torch.no_grad():
         out = fl(z.cuda(), ymask.cuda(), reverse=True)
-    _close(out, ref, "flow out (T=1300)", rtol=2e-4, atol=2e-4)
+    _close(out, ref64, "flow out (T=1300)", rtol=1e-4, atol=1e-5)

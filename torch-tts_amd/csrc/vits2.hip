@@ -8,6 +8,7 @@
 // reference's [B, C, T] is transposed once at the boundary by the host module.  GEMMs run in the
 // split-fp16 mode of the GEMM core (fp32-class accuracy, gemm_tile.h); everything else is fp32.
 #include <math.h>
+#include <stdlib.h>
 #include <string.h>
 
 #include <new>
@@ -694,7 +695,7 @@ StackWs carve_stack(float*& p, const StackDims& sd, size_t M) {
   w.cx.planes = reinterpret_cast<f16*>(take(M * (sd.C > sd.F ? sd.C : sd.F)));  // hi + lo planes of one A operand (fallback)
   w.x_p = reinterpret_cast<f16*>(take(M * sd.C)); w.xm_p = reinterpret_cast<f16*>(take(M * sd.C));
   w.att_p = reinterpret_cast<f16*>(take(M * sd.C)); w.f_p = reinterpret_cast<f16*>(take(M * sd.F));
-  w.cx.split = true;
+  w.cx.split = !getenv("TTSVITS_F32");  // (measurement switch: exact fp32 MFMAs for every GEMM)
   return w;
 }
 
@@ -899,7 +900,7 @@ int ttsvits_flow_reverse(ttsvits_handle* h, const float* z, const int32_t* lengt
   float* rs = take((size_t)M * 2 * Fh);
   GemmCtx fcx;
   fcx.planes = reinterpret_cast<f16*>(take((size_t)M * (Fh > half ? Fh : half)));
-  fcx.split = true;
+  fcx.split = !getenv("TTSVITS_F32");
   f16* hx_p = reinterpret_cast<f16*>(take((size_t)M * Fh));  // planes of hx / acts / ho, written by their producers
   f16* acts_p = reinterpret_cast<f16*>(take((size_t)M * Fh));
   f16* ho_p = reinterpret_cast<f16*>(take((size_t)M * Fh));
