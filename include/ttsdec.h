@@ -129,7 +129,8 @@ enum {
                              * reference's value, modules.py:25); other p: TTSDEC_ERR_INVALID_ARG, use MASKS   */
 };
 
-/* Arithmetic of the two LSTM gate GEMMs (95 % of the step's FLOPs). */
+/* Arithmetic of the step's GEMMs: the two LSTM gate GEMMs (95 % of the step's FLOPs), the PreNet, the query and the
+ * mel/stop projection. */
 enum {
   TTSDEC_PREC_F32 = 0,       /* exact fp32 on the fp32-input matrix instruction (default)             */
   TTSDEC_PREC_SPLIT_F16 = 1  /* split-fp16: x = hi + lo*2^-11 (two fp16 planes, 22 significand bits),
@@ -216,7 +217,9 @@ size_t ttsdec_workspace_bytes(const ttsdec_handle* h, int B, int L);
  *                 outputs of this call, step t stored at row (t - t_begin)
  *   T_out         device int32[2]: [0] = total number of steps produced so far
  *                 (= stop step + 1 if the rule fired, else t_begin+n_steps),
- *                 [1] = bit 0: the stop rule has fired; bit 1 (split-fp16 mode only): an activation
+ *                 [1] = bit 0: the stop rule has fired; bit 2: a two-role launch of the step gave up waiting
+ *                 for its producer role (bounded spin, only possible on a stalled or over-subscribed GPU):
+ *                 the outputs of the call are invalid; bit 1 (split-fp16 mode only): an activation
  *                 entering a 16-bit GEMM (input / teacher frame, PreNet output, context) had
  *                 |x| > 65504, the fp16 range - it was SATURATED, never inf/NaN, so outputs stay
  *                 finite but those rows are not fp32-accurate: rerun with TTSDEC_PREC_F32.

@@ -83,3 +83,18 @@ def assert_close(a, b, rtol=1e-4, atol=1e-5, what=""):
     tol = atol + rtol * b.abs()
     bad = err > tol
     assert not bool(bad.any()), f"{what}: max abs err {float(err.max()):.3e}, {int(bad.sum())} of {bad.numel()} outside rtol={rtol} atol={atol}"
+
+
+def assert_argmax(w, ow, what="attention argmax", tie=2e-6):
+    """argmax(w) must equal argmax(ow) bit for bit - except on rows where the reference's own two largest weights
+    differ by less than `tie` (absolute; the weights of a row sum to 1): there any fp32 evaluation order decides the
+    index, the reference's included.  Prints what it tolerated."""
+    a, b = w.argmax(-1), ow.argmax(-1)
+    bad = a != b
+    if not bool(bad.any()):
+        return
+    top2 = ow[bad].topk(2, dim=-1).values
+    gap = (top2[:, 0] - top2[:, 1]).abs()
+    err = (w[bad] - ow[bad]).abs().max(dim=-1).values
+    print(f"{what}: {int(bad.sum())} of {bad.numel()} rows differ; reference top-2 gaps {gap.tolist()[:8]}, max |w - ow| there {err.tolist()[:8]}")
+    assert bool((gap < tie).all()), f"{what}: argmax differs on a row whose top-2 gap is {float(gap.max()):.3e}"

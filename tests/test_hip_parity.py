@@ -812,7 +812,8 @@ def test_frame_kernel_stop_teacher_and_chunks(H, prec, r, d_pre):
     assert not fired and y.shape == oy.shape
     H.assert_close(y, oy, RTOL, ATOL, "y")
     H.assert_close(s, os_, RTOL, ATOL, "s")
-    assert torch.equal(w.argmax(-1), ow.argmax(-1))
+    H.assert_close(w, ow, RTOL, ATOL, "w")
+    H.assert_argmax(w, ow)
     # (c) teacher forcing with per-step flags through graph replay
     g = torch.Generator().manual_seed(9)
     Tx = 41 * r + (r - 1)

@@ -81,8 +81,12 @@ def test_modules_refuse_cpu_tensors_loudly():
         dec(torch.zeros(2, 5, 32), None, None, 3)
     with pytest.raises(RuntimeError, match="HIP path only"):
         T.MelPostnet(8, 16, 5, 2).eval()(torch.zeros(1, 4, 8))
-    with pytest.raises(NotImplementedError):
+    # the sub-modules run as torch ops when called on their own - on a ROCm device only, like everything else
+    with pytest.raises(RuntimeError, match="no CPU path"):
         cell.pre_net(torch.zeros(1, 8))
+    # training mode / grad-enabled calls take the torch-op device path: CPU tensors are refused there too
+    with pytest.raises(RuntimeError, match="no CPU"):
+        dec.train()(torch.zeros(2, 5, 32), None, torch.zeros(2, 4, 8))
 
 
 def test_state_dict_keys_match_the_reference(golden):

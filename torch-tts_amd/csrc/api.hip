@@ -77,10 +77,11 @@ struct ttsdec_handle {
   const float* blob;
   std::string hip_err;
   bool use_graph;   // replay a captured hipGraph instead of launching every kernel
-  // Two-role launches (fused_kernels.hip) where they apply: 1 = frame || lstm_att (default: measured 28 us in the
-  // loop against 12.3 + 21.1 as two launches); 2 = also attention || lstm_dec (measured SLOWER, 50 against 15.3 + 27.4:
-  // the attention workgroups starve beside the LSTM's tile stream and the LSTM then waits for the slowest of them);
-  // 0 = off.  TTSDEC_OVERLAP=0/1/2 or TTSDEC_NO_OVERLAP=1 (measurement switches).
+  // Two-role launches (fused_kernels.hip) where they apply: 1 = frame || lstm_att; 2 = also attention || lstm_dec;
+  // 0 = off; -1 (default) = by batch size: level 2 up to 64 utterances (measured per step: B = 1 60.2 -> 55.0 -> 52.0 us,
+  // B = 64 64.6 -> 60.1 -> 58.1 for levels 0 / 1 / 2), level 1 above (B = 256: 87.4 -> 83.4 -> 91: there the 256
+  // attention workgroups starve beside the LSTM's tile stream and the LSTM then waits for the slowest of them).
+  // TTSDEC_OVERLAP=0/1/2 or TTSDEC_NO_OVERLAP=1 (measurement switches).
   int overlap;
   bool chunk_a, chunk_b;  // chunked layout of the activation planes / LSTM weight planes; TTSDEC_CHUNK_A/B=0 (measurement)
   hipStream_t cap_stream;
@@ -605,14 +606,15 @@ const StepOrder kOrderProdF = {6, {N_F, N_A, N_Q, N_T, N_D, N_J}, {"prenet", "ls
 const StepOrder kOrderTaco2F = {6, {N_F, N_A, N_D, N_Q, N_T, N_J}, {"prenet", "lstm_att", "lstm_dec", "query", "attention", "proj"}};
 const StepOrder kOrderProdO = {5, {N_FA, N_Q, N_T, N_D, N_J}, {"prenet+lstm_att", "query", "attention", "lstm_dec", "proj"}};
 const StepOrder kOrderProdO2 = {4, {N_FA, N_Q, N_TD, N_J}, {"prenet+lstm_att", "query", "attention+lstm_dec", "proj"}};
-// the two-role step: LJSpeech-type cell, split-fp16, batches that fill the chip with 64-row tiles
-bool use_overlap(const ttsdec_handle* h, int B) {
+// the two-role step: LJSpeech-type cell, split-fp16
+int overlap_level(const ttsdec_handle* h, int B) {
   const ttsdec_dims& d = h->d;
-  return h->overlap > 0 && !is_taco2(d) && lstm_prec(h) && B >= 192 && fused_supported(d.d_mel, d.r, pre_hidden(d), d.d_pre, d.d_ctx);
+  if (is_taco2(d) || !lstm_prec(h) || !fused_supported(d.d_mel, d.r, pre_hidden(d), d.d_pre, d.d_ctx)) return 0;
+  return h->overlap >= 0 ? h->overlap : (B <= 64 ? 2 : 1);
 }
 const StepOrder& step_order(const ttsdec_handle* h, int B) {
   const ttsdec_dims& d = h->d;
-  if (use_overlap(h, B)) return h->overlap >= 2 ? kOrderProdO2 : kOrderProdO;
+  if (const int lv = overlap_level(h, B)) return lv >= 2 ? kOrderProdO2 : kOrderProdO;
   if (use_frame(d)) return is_taco2(d) ? kOrderTaco2F : kOrderProdF;
   return is_taco2(d) ? kOrderTaco2 : kOrderProd;
 }
@@ -717,7 +719,7 @@ int ttsdec_create(const ttsdec_dims* dims, ttsdec_handle** out) {
   const char* e2 = getenv("TTSDEC_NO_GRAPH");
   h->use_graph = !(e2 && atoi(e2));
   const char *e3 = getenv("TTSDEC_NO_OVERLAP"), *e3b = getenv("TTSDEC_OVERLAP");
-  h->overlap = (e3 && atoi(e3)) ? 0 : (e3b ? atoi(e3b) : 1);
+  h->overlap = (e3 && atoi(e3)) ? 0 : (e3b ? atoi(e3b) : -1);
   const char *e4 = getenv("TTSDEC_CHUNK_A"), *e5 = getenv("TTSDEC_CHUNK_B");
   h->chunk_a = !(e4 && !atoi(e4));
   h->chunk_b = !(e5 && !atoi(e5));

@@ -1,4 +1,4 @@
-// Two-role launches of the decode step (B >= 192, split-fp16).
+// Two-role launches of the decode step (split-fp16).
 //
 // The step is a serial chain  frame -> lstm_att -> query -> attention -> lstm_dec -> proj  in which the
 // two LSTMs are bound by what a CU can take in per microsecond and the other four launches by latency:
@@ -25,45 +25,60 @@
 
 namespace ttsdec {
 
-// 64 rows x 16 units, 16 KiB stages (32 k each) x 5 = 80 KiB
+// 64 rows x 16 units, 16 KiB stages (32 k each) x 5 = 80 KiB.  Small batches use the same tile: rows past the batch
+// read the 16-byte zero block (L1-resident), so only the weight stream is real traffic - 64 workgroups at B <= 64.
 using LeanCfg = TileCfg<2, 2, 1, 5, PREC_F16S, 0, 1, 1, 1>;
+// Batches of <= 64 utterances: 64 rows x 8 units on two MFMA waves (12 KiB stages x 5 + the dummy slots = 64 KiB),
+// so the weight stream is spread over 128 workgroups instead of 64 (at B = 1 the 64x64 tile took 16.5 us for the
+// attention LSTM against 10.9 us for the stand-alone small-batch kernel).
+using Lean8Cfg = TileCfg<2, 1, 1, 5, PREC_F16S, 0, 1, 1, 1>;
 constexpr int kLeanLds = LeanCfg::kLdsFloats;
+static_assert(Lean8Cfg::kLdsFloats <= kLeanLds, "one LDS size serves both lean tiles");
+constexpr int kLean8MaxRows = 64;
+// Batches of <= 32 utterances: both roles together are fewer workgroups than the chip has CUs, so nothing has to
+// share a CU and the LSTM keeps the stand-alone small-batch tile (32 rows x 8 units, 128-element K tiles, 128 KiB of
+// LDS: three 32-KiB tiles in flight - a batch-1 LSTM is a pure weight stream and lives on bytes in flight; the lean
+// tiles' 48 KiB took 16.4 us for the attention LSTM at B = 1 against 10.9 us).
+using SmallFatCfg = TileCfg<1, 1, 2, 4, PREC_F16S>;
+constexpr int kSmallFatMaxRows = 32;
 
 template <int A, int B>
 constexpr int cmax() { return A > B ? A : B; }
 
 // ---- role A = frame kernel (finish proj(t-1), PreNet), role B = early part of the attention LSTM ----
-template <int K0H, int PH>
-__global__ __launch_bounds__(kGemmThreads, 4) void frame_lstm_kernel(FrameArgs f, LstmArgs l, int n_frame, int frame_cols, int lstm_cols) {
-  __shared__ __attribute__((aligned(16))) float smem[cmax<kLeanLds, FrameLds<K0H, PH, PREC_F16S>::kFloats>()];
+// WPE: waves per SIMD the register budget must allow (4 = two 512-thread workgroups per CU, 2 = one)
+template <int K0H, int PH, class Cfg, int WPE>
+__global__ __launch_bounds__(kGemmThreads, WPE) void frame_lstm_kernel(FrameArgs f, LstmArgs l, int n_frame, int frame_cols, int lstm_cols) {
+  __shared__ __attribute__((aligned(16))) float smem[cmax<Cfg::kLdsFloats, FrameLds<K0H, PH, PREC_F16S>::kFloats>()];
   const int id = blockIdx.x;
   if (id < n_frame) {
     __builtin_amdgcn_s_setprio(3);  // the producer role is the launch's critical path: it wins issue arbitration
     frame_body<K0H, PH, PREC_F16S, 6>(f, smem, id % frame_cols, id / frame_cols);
   } else {
     const int j = id - n_frame;
-    lstm_body<LeanCfg, false>(l, smem, j % lstm_cols, j / lstm_cols);
+    lstm_body<Cfg, WPE == 2>(l, smem, j % lstm_cols, j / lstm_cols);
   }
 }
 
 // ---- role A = attention + context, role B = early part of the decoder LSTM ----
-template <int NJ>
-__global__ __launch_bounds__(kGemmThreads, 4) void attn_lstm_kernel(AttnArgs a, LstmArgs l, int n_attn, int lstm_cols) {
-  __shared__ __attribute__((aligned(16))) float smem[cmax<kLeanLds, attn_lds_floats<NJ>()>()];
+template <int NJ, class Cfg, int WPE>
+__global__ __launch_bounds__(kGemmThreads, WPE) void attn_lstm_kernel(AttnArgs a, LstmArgs l, int n_attn, int lstm_cols) {
+  __shared__ __attribute__((aligned(16))) float smem[cmax<Cfg::kLdsFloats, attn_lds_floats<NJ>()>()];
   const int id = blockIdx.x;
   if (id < n_attn) {
     __builtin_amdgcn_s_setprio(3);  // (as above: the decoder LSTM's last segment waits for every one of these)
     attn_body<NJ>(a, smem, id);
   } else {
     const int j = id - n_attn;
-    lstm_body<LeanCfg, false>(l, smem, j % lstm_cols, j / lstm_cols);
+    lstm_body<Cfg, WPE == 2>(l, smem, j % lstm_cols, j / lstm_cols);
   }
 }
 
 // the early part on its own (profiling / ablation: what the role costs without a partner)
+template <class Cfg>
 __global__ __launch_bounds__(kGemmThreads, 4) void lstm_lean_kernel(LstmArgs l) {
   __shared__ __attribute__((aligned(16))) float smem[kLeanLds];
-  lstm_body<LeanCfg, false>(l, smem, blockIdx.x, blockIdx.y);
+  lstm_body<Cfg, false>(l, smem, blockIdx.x, blockIdx.y);
 }
 
 static_assert(kFrameThreads == kGemmThreads && kAttnThreads == kGemmThreads, "roles share one block size");
@@ -75,27 +90,53 @@ bool fused_supported(int d_mel, int r, int Ph, int P, int D) {
 
 int frame_grid_size(int M, int P) { return ((P + kFrameCols - 1) / kFrameCols) * ((M + kFrameRows - 1) / kFrameRows); }
 
-void launch_frame_lstm(const FrameArgs& f, const LstmArgs& l, hipStream_t st) {
-  if (f.M <= 0) return;
-  const int fcols = (f.P + kFrameCols - 1) / kFrameCols, frows = (f.M + kFrameRows - 1) / kFrameRows;
-  const int lcols = (l.H + 15) / 16, lrows = (l.M + 63) / 64;
-  const int n_frame = fcols * frows;
-  dim3 grid(n_frame + lcols * lrows), block(kGemmThreads);
-  if (f.Ph == 256) hipLaunchKernelGGL((frame_lstm_kernel<40, 256>), grid, block, 0, st, f, l, n_frame, fcols, lcols);
-  else hipLaunchKernelGGL((frame_lstm_kernel<40, 128>), grid, block, 0, st, f, l, n_frame, fcols, lcols);
+// which tile the LSTM role runs on, by batch size (see the three configurations above)
+enum LeanKind { LEAN_64x16, LEAN_64x8, SMALL_FAT };
+static LeanKind lean_kind(int M, int n_producer, int H) {
+  if (M <= kSmallFatMaxRows && n_producer + (H + 7) / 8 <= 224) return SMALL_FAT;
+  return M <= kLean8MaxRows ? LEAN_64x8 : LEAN_64x16;
 }
 
+template <int K0H, int PH>
+static void launch_frame_lstm_ph(const FrameArgs& f, const LstmArgs& l, hipStream_t st) {
+  const int fcols = (f.P + kFrameCols - 1) / kFrameCols, frows = (f.M + kFrameRows - 1) / kFrameRows;
+  const int n_frame = fcols * frows;
+  const LeanKind kind = lean_kind(l.M, n_frame, l.H);
+  const int lcols = kind == LEAN_64x16 ? (l.H + 15) / 16 : (l.H + 7) / 8;
+  const int lrows = kind == SMALL_FAT ? (l.M + 31) / 32 : (l.M + 63) / 64;
+  dim3 grid(n_frame + lcols * lrows), block(kGemmThreads);
+  if (kind == SMALL_FAT) hipLaunchKernelGGL((frame_lstm_kernel<K0H, PH, SmallFatCfg, 2>), grid, block, 0, st, f, l, n_frame, fcols, lcols);
+  else if (kind == LEAN_64x8) hipLaunchKernelGGL((frame_lstm_kernel<K0H, PH, Lean8Cfg, 4>), grid, block, 0, st, f, l, n_frame, fcols, lcols);
+  else hipLaunchKernelGGL((frame_lstm_kernel<K0H, PH, LeanCfg, 4>), grid, block, 0, st, f, l, n_frame, fcols, lcols);
+}
+void launch_frame_lstm(const FrameArgs& f, const LstmArgs& l, hipStream_t st) {
+  if (f.M <= 0) return;
+  if (f.Ph == 256) launch_frame_lstm_ph<40, 256>(f, l, st);
+  else launch_frame_lstm_ph<40, 128>(f, l, st);
+}
+
+template <int NJ>
+static void launch_attn_lstm_nj(const AttnArgs& a, const LstmArgs& l, hipStream_t st) {
+  const LeanKind kind = lean_kind(l.M, a.B, l.H);
+  const int lcols = kind == LEAN_64x16 ? (l.H + 15) / 16 : (l.H + 7) / 8;
+  const int lrows = kind == SMALL_FAT ? (l.M + 31) / 32 : (l.M + 63) / 64;
+  dim3 grid(a.B + lcols * lrows), block(kGemmThreads);
+  if (kind == SMALL_FAT) hipLaunchKernelGGL((attn_lstm_kernel<NJ, SmallFatCfg, 2>), grid, block, 0, st, a, l, a.B, lcols);
+  else if (kind == LEAN_64x8) hipLaunchKernelGGL((attn_lstm_kernel<NJ, Lean8Cfg, 4>), grid, block, 0, st, a, l, a.B, lcols);
+  else hipLaunchKernelGGL((attn_lstm_kernel<NJ, LeanCfg, 4>), grid, block, 0, st, a, l, a.B, lcols);
+}
 void launch_attn_lstm(const AttnArgs& a, const LstmArgs& l, hipStream_t st) {
   if (a.B <= 0) return;
-  const int lcols = (l.H + 15) / 16, lrows = (l.M + 63) / 64;
-  dim3 grid(a.B + lcols * lrows), block(kGemmThreads);
-  if (a.D / 4 <= 64) hipLaunchKernelGGL((attn_lstm_kernel<1>), grid, block, 0, st, a, l, a.B, lcols);
-  else hipLaunchKernelGGL((attn_lstm_kernel<2>), grid, block, 0, st, a, l, a.B, lcols);
+  if (a.D / 4 <= 64) launch_attn_lstm_nj<1>(a, l, st);
+  else launch_attn_lstm_nj<2>(a, l, st);
 }
 
 void launch_lstm_lean(const LstmArgs& l, hipStream_t st) {
   if (l.M <= 0) return;
-  hipLaunchKernelGGL(lstm_lean_kernel, dim3((l.H + 15) / 16, (l.M + 63) / 64), dim3(kGemmThreads), 0, st, l);
+  if (l.M <= kLean8MaxRows)
+    hipLaunchKernelGGL((lstm_lean_kernel<Lean8Cfg>), dim3((l.H + 7) / 8, (l.M + 63) / 64), dim3(kGemmThreads), 0, st, l);
+  else
+    hipLaunchKernelGGL((lstm_lean_kernel<LeanCfg>), dim3((l.H + 15) / 16, (l.M + 63) / 64), dim3(kGemmThreads), 0, st, l);
 }
 
 }  // namespace ttsdec

@@ -72,8 +72,12 @@ struct TileCfg {
   static constexpr int KT = ROWB / EB;                       // K elements per tile
   static constexpr int C16 = ROWB / 16;                      // 16-byte columns per tile row
   static constexpr int ROWS_PER_INST = 64 / C16;             // tile rows one wave instruction covers
-  static constexpr int NA = BM * ROWB / 4096;                // LDS-DMA instructions per loader wave per A plane tile
-  static constexpr int NB = BN * ROWB / 4096;
+  // LDS-DMA instructions per loader wave per A / B plane tile.  A plane tile smaller than 4 KiB (2 KiB: 32 rows of
+  // 64 bytes) still costs every loader wave one instruction - the vmcnt arithmetic wants the same count in every
+  // wave - but the waves beyond the tile read the zero block into a dummy slot behind the ring.
+  static constexpr int NA = BM * ROWB >= 4096 ? BM * ROWB / 4096 : 1;
+  static constexpr int NB = BN * ROWB >= 4096 ? BN * ROWB / 4096 : 1;
+  static constexpr bool kDummy = BM * ROWB < 4096 || BN * ROWB < 4096;
   static constexpr int NLOADS = NP * (NA + NB);              // per loader wave per tile
   static constexpr int STAGES = S;
   static constexpr int kPlaneABytes = BM * ROWB;
@@ -82,7 +86,9 @@ struct TileCfg {
   static constexpr int LDO = BN + 1;
   static constexpr int kOutBytes = WK * BM * LDO * 4;
   static constexpr int kRingBytes = S * kStageBytes;
-  static constexpr int kLdsBytes = kRingBytes > kOutBytes ? kRingBytes : kOutBytes;
+  static constexpr int kDummyOff = kRingBytes;  // 4 x 1 KiB dummy slots (one per loader wave) when kDummy
+  static constexpr int kRingAll = kRingBytes + (kDummy ? 4096 : 0);
+  static constexpr int kLdsBytes = kRingAll > kOutBytes ? kRingAll : kOutBytes;
   static constexpr int kLdsFloats = kLdsBytes / 4;
   // loads left in flight when the tile whose fragments are read NEXT (one ahead of the MFMAs) has landed
   static constexpr int kWaitCnt = (kBig ? S - 2 : S - 3) * NLOADS;
@@ -193,7 +199,7 @@ __device__ __forceinline__ void gemm_tile(const LoaderA& la, const LoaderB& lb, 
 #pragma unroll
     for (int i = 0; i < NA; ++i) {
       const int row = (wave * NA + i) * RPI + lane / C16;
-      const bool ok = la.row_ok(row) && dbg != 1;
+      const bool ok = row < BM && la.row_ok(row) && dbg != 1;
       const int c16 = (lane % C16) ^ Cfg::swz(row);
       ca[i] = c16 * EPC;
       inca[i] = ok ? la.tile_inc(ROWB) : 0;
@@ -212,7 +218,7 @@ __device__ __forceinline__ void gemm_tile(const LoaderA& la, const LoaderB& lb, 
 #pragma unroll
     for (int i = 0; i < NB; ++i) {
       const int row = (wave * NB + i) * RPI + lane / C16;
-      const bool ok = lb.row_ok(row) && dbg != 1;
+      const bool ok = row < BN && lb.row_ok(row) && dbg != 1;
       const int c16 = (lane % C16) ^ Cfg::swz(row);
       cb[i] = c16 * EPC;
       incb[i] = ok ? lb.tile_inc(ROWB) : 0;
@@ -238,8 +244,9 @@ __device__ __forceinline__ void gemm_tile(const LoaderA& la, const LoaderB& lb, 
             ptr = (kpos + ca[i] >= aklo[i] && kpos + ca[i] < akhi[i] && kpos + ca[i] < seg_len) ? ptr : zero_addr();
           else
             ptr = (partial && kpos + ca[i] >= seg_len) ? zero_addr() : ptr;
-          __builtin_amdgcn_global_load_lds((global_void*)ptr,
-                                           (lds_void*)(st + p * Cfg::kPlaneABytes + (wave * NA + i) * 1024), 16, 0, 0);
+          char* dst = st + p * Cfg::kPlaneABytes + (wave * NA + i) * 1024;
+          if (Cfg::kDummy && (wave * NA + i) * 1024 >= Cfg::kPlaneABytes) dst = lds + Cfg::kDummyOff + wave * 1024;
+          __builtin_amdgcn_global_load_lds((global_void*)ptr, (lds_void*)dst, 16, 0, 0);
           cura[p][i] += inca[i];
         }
       }
@@ -248,7 +255,9 @@ __device__ __forceinline__ void gemm_tile(const LoaderA& la, const LoaderB& lb, 
 #pragma unroll
         for (int i = 0; i < NB; ++i) {
           gbyte* ptr = (partial && kpos + cb[i] >= seg_len) ? zero_addr() : curb[p][i];
-          lds_void* dst = (lds_void*)(st + NP * Cfg::kPlaneABytes + p * Cfg::kPlaneBBytes + (wave * NB + i) * 1024);
+          char* dstc = st + NP * Cfg::kPlaneABytes + p * Cfg::kPlaneBBytes + (wave * NB + i) * 1024;
+          if (Cfg::kDummy && (wave * NB + i) * 1024 >= Cfg::kPlaneBBytes) dstc = lds + Cfg::kDummyOff + wave * 1024;
+          lds_void* dst = (lds_void*)dstc;
           // (size and cache-policy arguments of the builtin must be literals)
           if constexpr (Cfg::kAuxB == 2) __builtin_amdgcn_global_load_lds((global_void*)ptr, dst, 16, 0, 2);
           else __builtin_amdgcn_global_load_lds((global_void*)ptr, dst, 16, 0, 0);

@@ -58,11 +58,12 @@ class Decoder(PackedWeightsMixin, nn.Module):
             raise RuntimeError(
                 "Decoder runs on the HIP path only: move the model and its inputs to a ROCm device (no CPU fallback)"
             )
-        if torch.is_grad_enabled() and (memory.requires_grad or any(p.requires_grad for p in self.parameters())):
-            raise NotImplementedError(
-                "autograd through the decode loop is outside the HIP hot path (forward only); "
-                "call under torch.no_grad() - teacher-forced forward passes are supported there"
-            )
+        if self.training or (torch.is_grad_enabled() and (memory.requires_grad or any(p.requires_grad for p in self.parameters()))):
+            # training semantics (zoneout sampling, energy noise) or a graph to differentiate: composable torch ops on
+            # the device (autograd_path.py); the HIP library is the forward-only, eval-mode hot path
+            from . import autograd_path
+
+            return autograd_path.decoder_forward(self, memory, mmask, x, max_steps, p_no_forcing)
         device = memory.device
         memory = memory.detach().to(torch.float32).contiguous()
         B, L, _ = memory.shape

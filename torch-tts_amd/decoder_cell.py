@@ -1,7 +1,8 @@
 """Drop-in for the reference's ``decoder_cell.Taco2ProdDecoderCell``
 (tacotron/decoder_cell.py:143-195): same constructor, attributes, parameter tree
 (state-dict keys) and ``initial_state`` / ``forward`` signatures; one step runs as
-HIP kernels through libttsdec (``ttsdec_cell_step``)."""
+HIP kernels through libttsdec (``ttsdec_cell_step``); training mode and grad-enabled calls run as torch ops on the
+device (autograd_path.py)."""
 from __future__ import annotations
 
 from typing import List, Optional, Sequence
@@ -13,14 +14,16 @@ from . import _lib
 from .engine import EngineCache, EngineDims, PackedWeightsMixin
 
 
-def _fused_only(name: str):
-    raise NotImplementedError(
-        f"{name} holds parameters only: on the HIP path it runs fused inside Taco2ProdDecoderCell / Decoder"
-    )
+def _needs_autograd(module, *tensors) -> bool:
+    """training-mode semantics, or a graph to differentiate -> the torch-op device path (autograd_path.py)"""
+    if module.training:
+        return True
+    return torch.is_grad_enabled() and (any(t.requires_grad for t in tensors) or any(p.requires_grad for p in module.parameters()))
 
 
 class PreNet(nn.Module):
-    """Parameter holder for tacotron/modules/modules.py:15-41 (keys layers.{0,1}.{weight,bias})."""
+    """tacotron/modules/modules.py:15-41 (keys layers.{0,1}.{weight,bias}).  Inside Decoder / the cells it runs fused in
+    the frame kernel; called on its own it runs as torch ops on the device (always-on dropout from the device generator)."""
 
     def __init__(self, dim_input, dim_output, dim_hidden=256, p_dropout=0.5, always_dropout=False):
         super().__init__()
@@ -29,23 +32,31 @@ class PreNet(nn.Module):
         self.layers = nn.ModuleList([nn.Linear(dim_input, dim_hidden), nn.Linear(dim_hidden, dim_output)])
 
     def forward(self, x):
-        _fused_only("PreNet")
+        from . import autograd_path
+
+        autograd_path._require_device(x, "x")
+        return autograd_path.prenet(self, x)
 
 
 class LSTMZoneoutCell(nn.LSTMCell):
-    """Parameter holder for tacotron/modules/rnn.py:19-39 (nn.LSTMCell keys and default init)."""
+    """tacotron/modules/rnn.py:19-39 (nn.LSTMCell keys and default init).  Fused into the LSTM kernels inside
+    Decoder / the cells; called on its own it runs as torch ops on the device (eval blend / training zoneout masks)."""
 
     def __init__(self, input_size, hidden_size, bias=True, p_zoneout=None):
         super().__init__(input_size, hidden_size, bias=bias)
         self.p_zoneout = p_zoneout
 
     def forward(self, x, hidden):
-        _fused_only("LSTMZoneoutCell")
+        from . import autograd_path
+
+        autograd_path._require_device(x, "x")
+        return autograd_path.lstm_zoneout(self, x, hidden, self.training)
 
 
 class StepwiseMonotonicAttention(nn.Module):
-    """Parameter holder for tacotron/modules/attention.py:96-126 (keys query_layer.weight, bias;
-    ``bias`` is unused by the reference's forward, kept for checkpoint compatibility)."""
+    """tacotron/modules/attention.py:96-126 (keys query_layer.weight, bias; ``bias`` is unused by the reference's forward,
+    kept for checkpoint compatibility).  Fused into the attention kernel inside Decoder / the cells; called on its own
+    it runs as torch ops on the device."""
 
     def __init__(self, dim_input, dim_context, sigmoid_noise=1.0):
         super().__init__()
@@ -54,7 +65,10 @@ class StepwiseMonotonicAttention(nn.Module):
         self.bias = nn.Parameter(torch.Tensor([1.0]))
 
     def forward(self, x, w, memory, cmask=None):
-        _fused_only("StepwiseMonotonicAttention")
+        from . import autograd_path
+
+        autograd_path._require_device(memory, "memory")
+        return autograd_path.monotonic_attention(self, x, w, memory, self.training)
 
 
 class Taco2ProdDecoderCell(PackedWeightsMixin, nn.Module):
@@ -123,10 +137,11 @@ class Taco2ProdDecoderCell(PackedWeightsMixin, nn.Module):
         Returns (x_dec, ctx_att, dec_state) like decoder_cell.py:180-195.  Inference only."""
         if not memory.is_cuda:
             raise RuntimeError("Taco2ProdDecoderCell runs on the HIP path only: move the module and inputs to a ROCm device")
-        if torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters()):
-            raise NotImplementedError(
-                "autograd through the decoder cell is outside the HIP hot path (forward only): call under torch.no_grad()"
-            )
+        if _needs_autograd(self, x, memory):
+            from . import autograd_path
+
+            xin = x.flatten(1, 2)[:, -self.dim_mel :] if x.dim() == 3 else x
+            return autograd_path.prod_cell_step(self, xin, (dec_state[0], dec_state[1], dec_state[2]), memory)
         w_att, ctx_att, (hc_att, hc_dec) = dec_state[0], dec_state[1], dec_state[2]
         B = memory.shape[0]
         eng = self._engines.get(self.engine_dims(), memory.device)
@@ -216,10 +231,11 @@ class Taco2DecoderCell(PackedWeightsMixin, nn.Module):
         """Returns (x_dec, ctx_att, (w, h_dec)) like decoder_cell.py:110-140.  Inference only."""
         if not memory.is_cuda:
             raise RuntimeError("Taco2DecoderCell runs on the HIP path only: move the module and inputs to a ROCm device")
-        if torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters()):
-            raise NotImplementedError(
-                "autograd through the decoder cell is outside the HIP hot path (forward only): call under torch.no_grad()"
-            )
+        if _needs_autograd(self, x, memory):
+            from . import autograd_path
+
+            xin = x.flatten(1, 2)[:, -self.dim_mel :] if x.dim() == 3 else x
+            return autograd_path.taco2_cell_step(self, xin, (dec_state[0], dec_state[1]), memory)
         w_in, h_dec = dec_state[0], dec_state[1]
         B = memory.shape[0]
         eng = self._engines.get(self.engine_dims(), memory.device)

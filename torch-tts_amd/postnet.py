@@ -57,10 +57,10 @@ class MelPostnet(PackedWeightsMixin, nn.Module):
     def forward(self, x):
         if not x.is_cuda:
             raise RuntimeError("MelPostnet runs on the HIP path only: move the module and input to a ROCm device")
-        if self.training:
-            raise NotImplementedError("MelPostnet on the HIP path is eval-mode only (BatchNorm running stats, no dropout)")
-        if torch.is_grad_enabled() and (x.requires_grad or any(p.requires_grad for p in self.parameters())):
-            raise NotImplementedError("autograd through the postnet is outside the HIP hot path: call under torch.no_grad()")
+        if self.training or (torch.is_grad_enabled() and (x.requires_grad or any(p.requires_grad for p in self.parameters()))):
+            from . import autograd_path  # training semantics (batch-statistics BatchNorm, dropout) or a graph: torch ops on the device
+
+            return autograd_path.mel_postnet(self, x)
         prec = {"f32": _lib.POSTNET_F32, "bf16": _lib.POSTNET_BF16, "split_f16": _lib.POSTNET_SPLIT_F16}[self.precision]
         return self.engine(x.device).postnet(x.detach().to(torch.float32).contiguous(), prec)
 
@@ -81,7 +81,9 @@ class Conv1dFix(nn.Module):
             self.register_parameter("bias", None)
 
     def forward(self, x):
-        raise NotImplementedError("Conv1dFix holds parameters only: it runs fused inside MelPostnet2 on the HIP path")
+        from . import autograd_path  # (inside MelPostnet2's eval forward it runs fused on the HIP path instead)
+
+        return autograd_path.conv1d_fix(self, x)
 
 
 class MelPostnet2(PackedWeightsMixin, nn.Module):
@@ -139,9 +141,9 @@ class MelPostnet2(PackedWeightsMixin, nn.Module):
     def forward(self, x):
         if not x.is_cuda:
             raise RuntimeError("MelPostnet2 runs on the HIP path only: move the module and input to a ROCm device")
-        if self.training:
-            raise NotImplementedError("MelPostnet2 on the HIP path is eval-mode only (BatchNorm running stats, no dropout)")
-        if torch.is_grad_enabled() and (x.requires_grad or any(p.requires_grad for p in self.parameters())):
-            raise NotImplementedError("autograd through the postnet is outside the HIP hot path: call under torch.no_grad()")
+        if self.training or (torch.is_grad_enabled() and (x.requires_grad or any(p.requires_grad for p in self.parameters()))):
+            from . import autograd_path
+
+            return autograd_path.mel_postnet2(self, x)
         prec = {"f32": _lib.POSTNET_F32, "bf16": _lib.POSTNET_BF16, "split_f16": _lib.POSTNET_SPLIT_F16}[self.precision]
         return self.engine(x.device).postnet(x.detach().to(torch.float32).contiguous(), prec)
