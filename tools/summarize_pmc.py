@@ -27,6 +27,7 @@ STEP_KERNELS = [
 
 
 def short(name):
+    name = name.replace("(anonymous namespace)::", "").replace("void ", "")
     for key, label in STEP_KERNELS:
         if key in name:
             return label
