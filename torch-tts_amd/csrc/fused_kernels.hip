@@ -1,4 +1,4 @@
-// Two-role launches of the decode step (split-fp16).
+// Two-role launches of the decode step.
 //
 // The step is a serial chain  frame -> lstm_att -> query -> attention -> lstm_dec -> proj  in which the
 // two LSTMs are bound by what a CU can take in per microsecond and the other four launches by latency:
@@ -25,22 +25,34 @@
 
 namespace ttsdec {
 
-// 64 rows x 16 units, 16 KiB stages (32 k each) x 5 = 80 KiB.  Small batches use the same tile: rows past the batch
-// read the 16-byte zero block (L1-resident), so only the weight stream is real traffic - 64 workgroups at B <= 64.
-using LeanCfg = TileCfg<2, 2, 1, 5, PREC_F16S, 0, 1, 1, 1>;
-// Batches of <= 64 utterances: 64 rows x 8 units on two MFMA waves (12 KiB stages x 5 + the dummy slots = 64 KiB),
-// so the weight stream is spread over 128 workgroups instead of 64 (at B = 1 the 64x64 tile took 16.5 us for the
-// attention LSTM against 10.9 us for the stand-alone small-batch kernel).
-using Lean8Cfg = TileCfg<2, 1, 1, 5, PREC_F16S, 0, 1, 1, 1>;
-constexpr int kLeanLds = LeanCfg::kLdsFloats;
-static_assert(Lean8Cfg::kLdsFloats <= kLeanLds, "one LDS size serves both lean tiles");
+// The LSTM role's tiles, per arithmetic mode (PREC_F16S / PREC_F32):
+//   Lean64x16: 64 rows x 16 units, 16-KiB stages x 5 = 80 KiB (split-fp16: 32 k per stage on chunked planes; exact fp32:
+//              32 k per stage, 128-byte rows).  Two workgroups per CU.
+//   Lean64x8:  batches of <= 64 utterances: 64 rows x 8 units on two MFMA waves (12-KiB stages x 5), so the weight
+//              stream is spread over 128 workgroups instead of 64.  Rows past the batch read the 16-byte zero block.
+//   SmallFat:  batches of <= 32 utterances: both roles together are fewer workgroups than the chip has CUs, so nothing
+//              has to share a CU and the LSTM keeps the stand-alone small-batch tile (128 KiB of LDS, three tiles in
+//              flight - a batch-1 LSTM is a pure weight stream and lives on bytes in flight; the lean tiles' 48 KiB
+//              took 16.4 us for the attention LSTM at B = 1 against 10.9 us).
+template <int PREC>
+struct LeanTiles;
+template <>
+struct LeanTiles<PREC_F16S> {
+  using Lean64x16 = TileCfg<2, 2, 1, 5, PREC_F16S, 0, 1, 1, 1>;
+  using Lean64x8 = TileCfg<2, 1, 1, 5, PREC_F16S, 0, 1, 1, 1>;
+  using SmallFat = TileCfg<1, 1, 2, 4, PREC_F16S>;
+};
+template <>
+struct LeanTiles<PREC_F32> {
+  using Lean64x16 = TileCfg<2, 2, 1, 5, PREC_F32>;
+  using Lean64x8 = TileCfg<2, 1, 1, 5, PREC_F32>;
+  using SmallFat = TileCfg<1, 1, 4, 4, PREC_F32>;
+};
 constexpr int kLean8MaxRows = 64;
-// Batches of <= 32 utterances: both roles together are fewer workgroups than the chip has CUs, so nothing has to
-// share a CU and the LSTM keeps the stand-alone small-batch tile (32 rows x 8 units, 128-element K tiles, 128 KiB of
-// LDS: three 32-KiB tiles in flight - a batch-1 LSTM is a pure weight stream and lives on bytes in flight; the lean
-// tiles' 48 KiB took 16.4 us for the attention LSTM at B = 1 against 10.9 us).
-using SmallFatCfg = TileCfg<1, 1, 2, 4, PREC_F16S>;
 constexpr int kSmallFatMaxRows = 32;
+static_assert(LeanTiles<PREC_F16S>::Lean64x16::kLdsBytes <= 80 * 1024 && LeanTiles<PREC_F32>::Lean64x16::kLdsBytes <= 80 * 1024 &&
+                  LeanTiles<PREC_F16S>::Lean64x8::kLdsBytes <= 80 * 1024 && LeanTiles<PREC_F32>::Lean64x8::kLdsBytes <= 80 * 1024,
+              "lean tiles: two workgroups per CU");
 
 template <int A, int B>
 constexpr int cmax() { return A > B ? A : B; }
@@ -49,11 +61,12 @@ constexpr int cmax() { return A > B ? A : B; }
 // WPE: waves per SIMD the register budget must allow (4 = two 512-thread workgroups per CU, 2 = one)
 template <int K0H, int PH, class Cfg, int WPE>
 __global__ __launch_bounds__(kGemmThreads, WPE) void frame_lstm_kernel(FrameArgs f, LstmArgs l, int n_frame, int frame_cols, int lstm_cols) {
-  __shared__ __attribute__((aligned(16))) float smem[cmax<Cfg::kLdsFloats, FrameLds<K0H, PH, PREC_F16S>::kFloats>()];
+  constexpr int PREC = Cfg::kPrec;
+  __shared__ __attribute__((aligned(16))) float smem[cmax<Cfg::kLdsFloats, FrameLds<K0H, PH, PREC>::kFloats>()];
   const int id = blockIdx.x;
   if (id < n_frame) {
     __builtin_amdgcn_s_setprio(3);  // the producer role is the launch's critical path: it wins issue arbitration
-    frame_body<K0H, PH, PREC_F16S, 6>(f, smem, id % frame_cols, id / frame_cols);
+    frame_body<K0H, PH, PREC, 6>(f, smem, id % frame_cols, id / frame_cols);
   } else {
     const int j = id - n_frame;
     lstm_body<Cfg, WPE == 2>(l, smem, j % lstm_cols, j / lstm_cols);
@@ -77,7 +90,7 @@ __global__ __launch_bounds__(kGemmThreads, WPE) void attn_lstm_kernel(AttnArgs a
 // the early part on its own (profiling / ablation: what the role costs without a partner)
 template <class Cfg>
 __global__ __launch_bounds__(kGemmThreads, 4) void lstm_lean_kernel(LstmArgs l) {
-  __shared__ __attribute__((aligned(16))) float smem[kLeanLds];
+  __shared__ __attribute__((aligned(16))) float smem[Cfg::kLdsFloats];
   lstm_body<Cfg, false>(l, smem, blockIdx.x, blockIdx.y);
 }
 
@@ -97,46 +110,55 @@ static LeanKind lean_kind(int M, int n_producer, int H) {
   return M <= kLean8MaxRows ? LEAN_64x8 : LEAN_64x16;
 }
 
-template <int K0H, int PH>
+template <int K0H, int PH, int PREC>
 static void launch_frame_lstm_ph(const FrameArgs& f, const LstmArgs& l, hipStream_t st) {
+  using TL = LeanTiles<PREC>;
   const int fcols = (f.P + kFrameCols - 1) / kFrameCols, frows = (f.M + kFrameRows - 1) / kFrameRows;
   const int n_frame = fcols * frows;
   const LeanKind kind = lean_kind(l.M, n_frame, l.H);
   const int lcols = kind == LEAN_64x16 ? (l.H + 15) / 16 : (l.H + 7) / 8;
   const int lrows = kind == SMALL_FAT ? (l.M + 31) / 32 : (l.M + 63) / 64;
   dim3 grid(n_frame + lcols * lrows), block(kGemmThreads);
-  if (kind == SMALL_FAT) hipLaunchKernelGGL((frame_lstm_kernel<K0H, PH, SmallFatCfg, 2>), grid, block, 0, st, f, l, n_frame, fcols, lcols);
-  else if (kind == LEAN_64x8) hipLaunchKernelGGL((frame_lstm_kernel<K0H, PH, Lean8Cfg, 4>), grid, block, 0, st, f, l, n_frame, fcols, lcols);
-  else hipLaunchKernelGGL((frame_lstm_kernel<K0H, PH, LeanCfg, 4>), grid, block, 0, st, f, l, n_frame, fcols, lcols);
+  if (kind == SMALL_FAT) hipLaunchKernelGGL((frame_lstm_kernel<K0H, PH, typename TL::SmallFat, 2>), grid, block, 0, st, f, l, n_frame, fcols, lcols);
+  else if (kind == LEAN_64x8) hipLaunchKernelGGL((frame_lstm_kernel<K0H, PH, typename TL::Lean64x8, 4>), grid, block, 0, st, f, l, n_frame, fcols, lcols);
+  else hipLaunchKernelGGL((frame_lstm_kernel<K0H, PH, typename TL::Lean64x16, 4>), grid, block, 0, st, f, l, n_frame, fcols, lcols);
 }
 void launch_frame_lstm(const FrameArgs& f, const LstmArgs& l, hipStream_t st) {
   if (f.M <= 0) return;
-  if (f.Ph == 256) launch_frame_lstm_ph<40, 256>(f, l, st);
-  else launch_frame_lstm_ph<40, 128>(f, l, st);
+  const bool f16 = l.prec == 1;
+  if (f.Ph == 256) { if (f16) launch_frame_lstm_ph<40, 256, PREC_F16S>(f, l, st); else launch_frame_lstm_ph<40, 256, PREC_F32>(f, l, st); }
+  else { if (f16) launch_frame_lstm_ph<40, 128, PREC_F16S>(f, l, st); else launch_frame_lstm_ph<40, 128, PREC_F32>(f, l, st); }
 }
 
-template <int NJ>
+template <int NJ, int PREC>
 static void launch_attn_lstm_nj(const AttnArgs& a, const LstmArgs& l, hipStream_t st) {
+  using TL = LeanTiles<PREC>;
   const LeanKind kind = lean_kind(l.M, a.B, l.H);
   const int lcols = kind == LEAN_64x16 ? (l.H + 15) / 16 : (l.H + 7) / 8;
   const int lrows = kind == SMALL_FAT ? (l.M + 31) / 32 : (l.M + 63) / 64;
   dim3 grid(a.B + lcols * lrows), block(kGemmThreads);
-  if (kind == SMALL_FAT) hipLaunchKernelGGL((attn_lstm_kernel<NJ, SmallFatCfg, 2>), grid, block, 0, st, a, l, a.B, lcols);
-  else if (kind == LEAN_64x8) hipLaunchKernelGGL((attn_lstm_kernel<NJ, Lean8Cfg, 4>), grid, block, 0, st, a, l, a.B, lcols);
-  else hipLaunchKernelGGL((attn_lstm_kernel<NJ, LeanCfg, 4>), grid, block, 0, st, a, l, a.B, lcols);
+  if (kind == SMALL_FAT) hipLaunchKernelGGL((attn_lstm_kernel<NJ, typename TL::SmallFat, 2>), grid, block, 0, st, a, l, a.B, lcols);
+  else if (kind == LEAN_64x8) hipLaunchKernelGGL((attn_lstm_kernel<NJ, typename TL::Lean64x8, 4>), grid, block, 0, st, a, l, a.B, lcols);
+  else hipLaunchKernelGGL((attn_lstm_kernel<NJ, typename TL::Lean64x16, 4>), grid, block, 0, st, a, l, a.B, lcols);
 }
 void launch_attn_lstm(const AttnArgs& a, const LstmArgs& l, hipStream_t st) {
   if (a.B <= 0) return;
-  if (a.D / 4 <= 64) launch_attn_lstm_nj<1>(a, l, st);
-  else launch_attn_lstm_nj<2>(a, l, st);
+  const bool f16 = l.prec == 1;
+  if (a.D / 4 <= 64) { if (f16) launch_attn_lstm_nj<1, PREC_F16S>(a, l, st); else launch_attn_lstm_nj<1, PREC_F32>(a, l, st); }
+  else { if (f16) launch_attn_lstm_nj<2, PREC_F16S>(a, l, st); else launch_attn_lstm_nj<2, PREC_F32>(a, l, st); }
 }
 
 void launch_lstm_lean(const LstmArgs& l, hipStream_t st) {
   if (l.M <= 0) return;
-  if (l.M <= kLean8MaxRows)
-    hipLaunchKernelGGL((lstm_lean_kernel<Lean8Cfg>), dim3((l.H + 7) / 8, (l.M + 63) / 64), dim3(kGemmThreads), 0, st, l);
-  else
-    hipLaunchKernelGGL((lstm_lean_kernel<LeanCfg>), dim3((l.H + 15) / 16, (l.M + 63) / 64), dim3(kGemmThreads), 0, st, l);
+  const bool small = l.M <= kLean8MaxRows;
+  dim3 grid(small ? (l.H + 7) / 8 : (l.H + 15) / 16, (l.M + 63) / 64), block(kGemmThreads);
+  if (l.prec == 1) {
+    if (small) hipLaunchKernelGGL((lstm_lean_kernel<LeanTiles<PREC_F16S>::Lean64x8>), grid, block, 0, st, l);
+    else hipLaunchKernelGGL((lstm_lean_kernel<LeanTiles<PREC_F16S>::Lean64x16>), grid, block, 0, st, l);
+  } else {
+    if (small) hipLaunchKernelGGL((lstm_lean_kernel<LeanTiles<PREC_F32>::Lean64x8>), grid, block, 0, st, l);
+    else hipLaunchKernelGGL((lstm_lean_kernel<LeanTiles<PREC_F32>::Lean64x16>), grid, block, 0, st, l);
+  }
 }
 
 }  // namespace ttsdec
