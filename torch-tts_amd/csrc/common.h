@@ -51,7 +51,7 @@ struct Ctrl {
 // stamps[(kind * 1024 + block) * 8 + k]; kind 0 = frame || lstm_att, 1 = attention || lstm_dec;
 // k: 0 = role << 32 | HW_ID, 1 = XCC_ID, 2 = start, 3 = gate reached, 4 = gate passed, 5 = end (s_memrealtime, 10 ns units)
 __device__ __forceinline__ void stamp(const Ctrl* c, int kind, int k, unsigned long long v) {
-  if (c != nullptr && c->stamps != nullptr && (threadIdx.x & 63) == 0) c->stamps[((size_t)kind * 1024 + blockIdx.x) * 8 + k] = v;
+  if (c != nullptr && c->stamps != nullptr && (threadIdx.x & 63) == 0 && blockIdx.x < 1024) c->stamps[((size_t)kind * 1024 + blockIdx.x) * 8 + k] = v;
 }
 __device__ __forceinline__ unsigned long long now_rt() { return __builtin_amdgcn_s_memrealtime(); }
 
