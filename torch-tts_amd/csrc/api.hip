@@ -127,6 +127,16 @@ inline int split_of(int K, int want) {  // split-K factor: slices must be whole 
 }
 
 inline int query_split(const ttsdec_dims& d) { return split_of(query_k(d), query_k(d) >= 2048 ? kQuerySplit : 2); }
+// The mel/stop projection on the register-weight kernel (frame_kernel.hip proj_kernel) in split-fp16 mode where it
+// covers the shape: whole 8-element groups in every K segment, K slices of whole 128-element blocks; else the LDS-staged
+// split-K GEMM.  Measured, proj launch / step in the loop: B = 256 5.0 / 83.6 us against 6.7 / 84.1, B = 1 4.3 / 46.9
+// against 5.5 / 47.9; exact fp32 (64-cycle MFMAs, 8 per k16 step) 7.0 against 6.4 - so split-fp16 only.
+// TTSDEC_PROJ_REGW=0: measurement switch.
+inline bool proj_regw(const ttsdec_dims& d) {
+  static const bool off = [] { const char* e = getenv("TTSDEC_PROJ_REGW"); return e && !atoi(e); }();
+  return !off && use_frame(d) && !((d.h_att | d.h_dec | d.d_ctx) & 7) && proj_split(proj_k(d)) > 0 && proj_n(d) <= 192;
+}
+inline int proj_parts(const ttsdec_dims& d, int prec) { return prec && proj_regw(d) ? proj_split(proj_k(d)) : split_of(proj_k(d), kProjSplit); }
 
 BlobLayout make_blob_layout(const ttsdec_dims& d) {
   BlobLayout L;
@@ -378,7 +388,7 @@ void launch_node(const ttsdec_handle* h, const StepBufs& sb, const StepIo& io, N
     FrameArgs f;
     memset(&f, 0, sizeof(f));
     const int Ph = pre_hidden(d);
-    f.parts = sb.jparts; f.n_parts = split_of(proj_k(d), kProjSplit); f.ldp = proj_ldp(d);
+    f.parts = sb.jparts; f.n_parts = proj_parts(d, prec); f.ldp = proj_ldp(d);
     f.part_stride = (size_t)B * proj_ldp(d);
     f.proj_bias = blob + bl.proj_b;
     f.y_out = io.y; f.s_out = io.s; f.ynext = sb.ynext;
@@ -583,6 +593,15 @@ void launch_node(const ttsdec_handle* h, const StepBufs& sb, const StepIo& io, N
           g.a = act(make_seg2(sb.h_dec_h[1 - p], Hd, Hd, sb.ctx_h, D, D));
           g.a_lo = act(make_seg2(sb.h_dec_l[1 - p], Hd, Hd, sb.ctx_l, D, D));
         }
+      }
+      if (prec && proj_regw(d)) {  // (same slabs, from the kernel that keeps its weight fragments in registers)
+        ProjArgs pa;
+        memset(&pa, 0, sizeof(pa));
+        pa.a = g.a; pa.a_lo = g.a_lo; pa.W = g.W; pa.W_lo = g.W_lo; pa.ldw = g.ldw; pa.prec = g.prec;
+        pa.M = B; pa.N = g.N; pa.K = g.K; pa.ksplit = proj_parts(d, prec); pa.split_stride = (size_t)B * proj_ldp(d);
+        pa.out = sb.jparts; pa.ldo = proj_ldp(d); pa.ctrl = ctrl; pa.slot = io.slot;
+        launch_proj(pa, st);
+        break;
       }
       if (use_frame(d)) {
         // raw split-K partial sums; bias, leaky-ReLU, y / s / stop rule happen in the next frame kernel

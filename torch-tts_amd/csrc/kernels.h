@@ -178,6 +178,26 @@ struct FrameArgs {
 bool frame_supported(int d_mel, int r, int Ph, int P);
 void launch_frame(const FrameArgs& a, hipStream_t st);
 
+// ---- the mel/stop projection GEMM with its weights in registers (frame_kernel.hip) ----
+// out[z][M, ldo] (+ z * split_stride) = A[M, K slice z] * W[N, K slice z]^T, raw partial sums for the frame kernel.
+// 32 x 32 outputs per workgroup; the K slice is cut over its 8 waves and every lane HALF holds one contiguous K run of
+// its weight row in registers (the frame kernel's permuted-K trick), requested before the control block is read.
+// For N = r*d_mel + r <= 96 this beats the LDS-staged tile (5.5 against 6.7 us per step at B = 256, 4.7 / 5.6 at B = 1).
+struct ProjArgs {
+  Seg3 a, a_lo;          // [M, K] in up to three K segments (multiples of 8): fp32, or the fp16 hi / lo planes (prec = PREC_F16S)
+  const void *W, *W_lo;  // [N, ldw] row-major: fp32, or fp16 hi / lo planes
+  int ldw, prec;
+  int M, N, K;
+  int ksplit;            // K slices: proj_split(K); K % (128 * ksplit) == 0 and K / (128 * ksplit) <= 4
+  size_t split_stride;
+  float* out;
+  int ldo;
+  Ctrl* ctrl;            // != nullptr: the launch does nothing unless step ctrl->t_cur + slot is live
+  int slot;
+};
+int proj_split(int K);  // the ksplit of this kernel for K, or 0 when it does not cover K
+void launch_proj(const ProjArgs& a, hipStream_t st);
+
 // ---- two-role launches (fused_kernels.hip): a latency-bound kernel and the early part of the next LSTM ----
 // The LstmArgs must be a split-fp16 cell with M >= 192 whose gated K segment (dep_seg) comes last; its gate GEMM
 // runs on the lean tile.
