@@ -1061,3 +1061,43 @@ def test_argument_rejection_through_the_c_abi(H):
     bad[0, 0] = -1
     with pytest.raises(IndexError), torch.no_grad():
         te(bad, torch.tensor([7, 7]).cuda())
+
+
+# --------------------------------------------------------------------------
+# every step order the library can run (the defaults pick one per batch size / mode; the rest are reachable through
+# the measurement switches read at handle creation) must give the reference's results
+# --------------------------------------------------------------------------
+_STEP_SWITCHES = [
+    {}, {"TTSDEC_OVERLAP": "0"}, {"TTSDEC_OVERLAP": "1"}, {"TTSDEC_OVERLAP": "2"}, {"TTSDEC_NO_GRAPH": "1"},
+    {"TTSDEC_OVERLAP": "2", "TTSDEC_NO_GRAPH": "1"}, {"TTSDEC_CHUNK_A": "0"}, {"TTSDEC_CHUNK_B": "0"},
+    {"TTSDEC_CHUNK_A": "0", "TTSDEC_CHUNK_B": "0", "TTSDEC_OVERLAP": "2"}, {"TTSDEC_PROJ_REGW": "0"},
+]
+
+
+@pytest.mark.parametrize("prec", ["f32", "split_f16"])
+def test_all_step_orders_and_layouts_vs_oracle(H, prec, monkeypatch):
+    dims = O.DecoderDims(d_mel=80, d_pre=128, d_ctx=64, h_att=128, h_dec=192)  # (fused launches, chunked planes and the
+    wts = O.random_decoder_weights(dims, seed=21, nonzero_init_state=True)    #  register-weight projection all apply)
+    T_ = 18  # >= 15 steps: the captured-graph path (unless switched off)
+    for B in (3, 40, 70):  # stand-alone small tile / 64x8 lean tile / 64x16 lean tile of the two-role launches
+        mem = O.synthetic_memory(B, 11, dims.d_ctx, lengths=[11] * (B - 1) + [4], seed=7)
+        masks = O.synthetic_masks(T_, B, dims.d_pre, seed=9)
+        oy, os_, ow = O.decode(wts, dims, mem, max_steps=T_ - 1, masks=masks)
+        for env in _STEP_SWITCHES:
+            with monkeypatch.context() as mp:
+                for k, v in env.items():
+                    mp.setenv(k, v)
+                dec = H.make_decoder(dims, wts)  # a new module = a new handle, which reads the switches
+                dec.precision = prec
+                y, s, w, fired = H.run_decoder_with_masks(dec, mem, masks, max_steps=T_ - 1)
+                if "TTSDEC_OVERLAP" in env and "TTSDEC_CHUNK_A" not in env:  # the switch really selects the launch sequence
+                    from torch_tts_amd import _lib
+                    names = set(dec.engine(torch.device("cuda:0")).profile_step(mem.cuda(), 1, _lib.DROPOUT_OFF, None, 0))
+                    lv = int(env["TTSDEC_OVERLAP"])
+                    assert ("prenet+lstm_att" in names) == (lv >= 1) and ("attention+lstm_dec" in names) == (lv >= 2), (env, names)
+            what = f"B={B} {prec} {env}"
+            assert not fired and y.shape == oy.shape, what
+            H.assert_close(y, oy, RTOL, ATOL, "y " + what)
+            H.assert_close(s, os_, RTOL, ATOL, "s " + what)
+            H.assert_close(w, ow, RTOL, ATOL, "w " + what)
+            H.assert_argmax(w, ow, "argmax " + what)

@@ -86,6 +86,7 @@ struct ttsdec_handle {
   // TTSDEC_OVERLAP=0/1/2 or TTSDEC_NO_OVERLAP=1 (measurement switches).
   int overlap;
   bool chunk_a, chunk_b;  // chunked layout of the activation planes / LSTM weight planes; TTSDEC_CHUNK_A/B=0 (measurement)
+  bool proj_regw;         // mel/stop projection on the register-weight kernel where it applies; TTSDEC_PROJ_REGW=0 (measurement)
   hipStream_t cap_stream;
   bool streams_ready;
   // one cached graph: valid for exactly this (workspace, blob, B, L, precision)
@@ -131,12 +132,13 @@ inline int query_split(const ttsdec_dims& d) { return split_of(query_k(d), query
 // covers the shape: whole 8-element groups in every K segment, K slices of whole 128-element blocks; else the LDS-staged
 // split-K GEMM.  Measured, proj launch / step in the loop: B = 256 5.0 / 83.6 us against 6.7 / 84.1, B = 1 4.3 / 46.9
 // against 5.5 / 47.9; exact fp32 (64-cycle MFMAs, 8 per k16 step) 7.0 against 6.4 - so split-fp16 only.
-// TTSDEC_PROJ_REGW=0: measurement switch.
-inline bool proj_regw(const ttsdec_dims& d) {
-  static const bool off = [] { const char* e = getenv("TTSDEC_PROJ_REGW"); return e && !atoi(e); }();
-  return !off && use_frame(d) && !((d.h_att | d.h_dec | d.d_ctx) & 7) && proj_split(proj_k(d)) > 0 && proj_n(d) <= 192;
+inline bool proj_regw(const ttsdec_handle* h, int prec) {
+  const ttsdec_dims& d = h->d;
+  return prec && h->proj_regw && use_frame(d) && !((d.h_att | d.h_dec | d.d_ctx) & 7) && proj_split(proj_k(d)) > 0 && proj_n(d) <= 192;
 }
-inline int proj_parts(const ttsdec_dims& d, int prec) { return prec && proj_regw(d) ? proj_split(proj_k(d)) : split_of(proj_k(d), kProjSplit); }
+inline int proj_parts(const ttsdec_handle* h, int prec) {
+  return proj_regw(h, prec) ? proj_split(proj_k(h->d)) : split_of(proj_k(h->d), kProjSplit);
+}
 
 BlobLayout make_blob_layout(const ttsdec_dims& d) {
   BlobLayout L;
@@ -388,7 +390,7 @@ void launch_node(const ttsdec_handle* h, const StepBufs& sb, const StepIo& io, N
     FrameArgs f;
     memset(&f, 0, sizeof(f));
     const int Ph = pre_hidden(d);
-    f.parts = sb.jparts; f.n_parts = proj_parts(d, prec); f.ldp = proj_ldp(d);
+    f.parts = sb.jparts; f.n_parts = proj_parts(h, prec); f.ldp = proj_ldp(d);
     f.part_stride = (size_t)B * proj_ldp(d);
     f.proj_bias = blob + bl.proj_b;
     f.y_out = io.y; f.s_out = io.s; f.ynext = sb.ynext;
@@ -594,11 +596,11 @@ void launch_node(const ttsdec_handle* h, const StepBufs& sb, const StepIo& io, N
           g.a_lo = act(make_seg2(sb.h_dec_l[1 - p], Hd, Hd, sb.ctx_l, D, D));
         }
       }
-      if (prec && proj_regw(d)) {  // (same slabs, from the kernel that keeps its weight fragments in registers)
+      if (proj_regw(h, prec)) {  // (same slabs, from the kernel that keeps its weight fragments in registers)
         ProjArgs pa;
         memset(&pa, 0, sizeof(pa));
         pa.a = g.a; pa.a_lo = g.a_lo; pa.W = g.W; pa.W_lo = g.W_lo; pa.ldw = g.ldw; pa.prec = g.prec;
-        pa.M = B; pa.N = g.N; pa.K = g.K; pa.ksplit = proj_parts(d, prec); pa.split_stride = (size_t)B * proj_ldp(d);
+        pa.M = B; pa.N = g.N; pa.K = g.K; pa.ksplit = proj_parts(h, prec); pa.split_stride = (size_t)B * proj_ldp(d);
         pa.out = sb.jparts; pa.ldo = proj_ldp(d); pa.ctrl = ctrl; pa.slot = io.slot;
         launch_proj(pa, st);
         break;
@@ -749,6 +751,8 @@ int ttsdec_create(const ttsdec_dims* dims, ttsdec_handle** out) {
   const char *e4 = getenv("TTSDEC_CHUNK_A"), *e5 = getenv("TTSDEC_CHUNK_B");
   h->chunk_a = !(e4 && !atoi(e4));
   h->chunk_b = !(e5 && !atoi(e5));
+  const char* e6 = getenv("TTSDEC_PROJ_REGW");
+  h->proj_regw = !(e6 && !atoi(e6));
   h->device = current_device_or_minus1();
   *out = h;
   return TTSDEC_OK;
