@@ -25,6 +25,12 @@ for kind, name in ((0, "frame || lstm_att"), (1, "attention || lstm_dec")):
             continue
         st, en = us(2)[m], us(5)[m]
         print(f"  {rn:8s} n={m.sum():4d} start {st.min():6.2f}..{st.max():6.2f}  end {en.min():6.2f}..{en.max():6.2f} (mean {en.mean():6.2f})")
+        if r == 0 and kind == 0:  # frame role: 3 = previous step's frame finished, 4 = layer 0 done, 6 = x_pre stores issued
+            for col, what in ((3, "frame(t-1) finished"), (4, "layer 0 done"), (6, "x_pre stores issued")):
+                v = us(col)[m]
+                ok = s[:, col][m] > 0
+                if ok.any():
+                    print(f"           {what:20s} {v[ok].min():6.2f}..{v[ok].max():6.2f} (mean {v[ok].mean():6.2f})")
         if r == 1:
             gi, go = us(3)[m], us(4)[m]
             ok = s[:, 3][m] > 0

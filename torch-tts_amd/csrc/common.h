@@ -50,8 +50,12 @@ struct Ctrl {
 };
 // stamps[(kind * 1024 + block) * 8 + k]; kind 0 = frame || lstm_att, 1 = attention || lstm_dec;
 // k: 0 = role << 32 | HW_ID, 1 = XCC_ID, 2 = start, 3 = gate reached, 4 = gate passed, 5 = end (s_memrealtime, 10 ns units)
-__device__ __forceinline__ void stamp(const Ctrl* c, int kind, int k, unsigned long long v) {
-  if (c != nullptr && c->stamps != nullptr && (threadIdx.x & 63) == 0 && blockIdx.x < 1024) c->stamps[((size_t)kind * 1024 + blockIdx.x) * 8 + k] = v;
+// `st` = Ctrl::stamps, loaded ONCE by the caller (stamps_of): a load in front of every stamp is a vector-memory wait in the
+// middle of the code being measured - and was, in the gate of the two-role launches, a microsecond on their critical path.
+typedef __attribute__((address_space(1))) unsigned long long* stamp_ptr;
+__device__ __forceinline__ stamp_ptr stamps_of(const Ctrl* c) { return c != nullptr ? (stamp_ptr)c->stamps : (stamp_ptr) nullptr; }
+__device__ __forceinline__ void stamp(stamp_ptr st, int kind, int k, unsigned long long v) {
+  if (st != nullptr && (threadIdx.x & 63) == 0 && blockIdx.x < 1024) st[((size_t)kind * 1024 + blockIdx.x) * 8 + k] = v;
 }
 __device__ __forceinline__ unsigned long long now_rt() { return __builtin_amdgcn_s_memrealtime(); }
 
@@ -172,6 +176,14 @@ __host__ __device__ inline Seg3 make_seg1(const void* p0, int ld0, int k0) {
 // so every wait becomes vmcnt(0)); casting to address_space(1) gives global_load.
 typedef __attribute__((address_space(1))) const char gbyte;
 __device__ __forceinline__ gbyte* as_global(const void* p) { return (gbyte*)p; }
+// The same for typed accesses through pointers that were LOADED from memory (the per-call pointers of the control block: y,
+// s, w, masks, teacher, memory).  A flat store or load also counts in lgkmcnt, so every later wait for LDS data - the next
+// ds_read, a barrier - waits for it to complete as well: the frame kernel's layer-0 epilogue (it reads the Philox bits from
+// LDS) sat 2.5-3.9 us behind the flat stores of y / s (time stamps), the attention kernel's final LDS sum behind its w stores.
+template <class T>
+__device__ __forceinline__ __attribute__((address_space(1))) T* as_g(T* p) {
+  return (__attribute__((address_space(1))) T*)p;
+}
 
 // 16 zero bytes in device memory: out-of-range tile elements are loaded from here, so
 // a loader only ever selects an ADDRESS (every lane always issues its load).
@@ -238,6 +250,24 @@ __device__ __forceinline__ void split_f16(float x, f16& hi, f16& lo) {
   hi = h;
   lo = (f16)((x - (float)h) * kSplitScale);
 }
+// The same for loops: the saturation goes into a local flag, reported once (report_range).  A conditional atomic inside an
+// unrolled epilogue loop keeps the compiler from overlapping the iterations' LDS reads and writes: 16 elements of the frame
+// kernel's layer-0 epilogue took 2.5-3.9 us that way (time stamps), most of the role's critical path.
+__device__ __forceinline__ void split_f16_flag(float x, f16& hi, f16& lo, bool& over) {
+  over |= fabsf(x) > kSplitMax;
+  split_f16(x, hi, lo);
+}
+// split_f16 of a value known to be >= 0 and not NaN (a ReLU output): min instead of the sign-preserving clamp
+__device__ __forceinline__ void split_f16_pos(float x, f16& hi, f16& lo) {
+  x = fminf(x, kSplitMax);
+  f16 h = (f16)x;
+  if (x < 6.103515625e-05f) h = (f16)0.0f;
+  hi = h;
+  lo = (f16)((x - (float)h) * kSplitScale);
+}
+__device__ __forceinline__ void report_range(bool over, Ctrl* ctrl) {
+  if (over && ctrl != nullptr) atomicOr(&ctrl->range_err, 1);
+}
 __device__ __forceinline__ void split_f16_checked(float x, f16& hi, f16& lo, Ctrl* ctrl) {
   if (ctrl != nullptr && fabsf(x) > kSplitMax) atomicOr(&ctrl->range_err, 1);
   split_f16(x, hi, lo);
@@ -283,6 +313,12 @@ __device__ __forceinline__ void role_wait(const unsigned int* counter, unsigned 
   __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 }
+
+// Workgroup barrier for data exchanged through LDS: waits for this wave's LDS traffic only.  __syncthreads() also drains
+// the wave's outstanding GLOBAL loads and stores (s_waitcnt vmcnt(0)) - behind freshly issued stores that is a whole write
+// round trip, 1-2 us (time stamps: the frame kernel's barrier after its y / s stores, the attention kernel's after its
+// weight stores).  Not for data handed over through global memory.
+__device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 
 template <int N, class F>
 __device__ __forceinline__ void static_for(F&& f) {

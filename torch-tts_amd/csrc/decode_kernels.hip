@@ -113,7 +113,7 @@ __global__ __launch_bounds__(kGemmThreads) void gemm_rows_kernel(GemmArgs g) {
     pm = 1;
     pr = 0.f;
     prm = 1.0f;
-    if (EK == EPI_RELU_DROPOUT && ok && g.dropout_mode == TTSDEC_DROPOUT_MASKS) pm = g.masks[(size_t)m * g.N + n];
+    if (EK == EPI_RELU_DROPOUT && ok && g.dropout_mode == TTSDEC_DROPOUT_MASKS) pm = as_g(g.masks)[(size_t)m * g.N + n];
     if ((EK == EPI_BN_ISRU || EK == EPI_BN_LRELU || EK == EPI_BN_ISRLU) && ok) {
       pb = g.alpha[n];
       pr = g.beta[n];
@@ -142,7 +142,7 @@ __global__ __launch_bounds__(kGemmThreads) void gemm_rows_kernel(GemmArgs g) {
     gemm_tile<Cfg>(la, lb, smem, live);
   } else {
     Seg3 s = g.a, s_lo = g.a_lo;
-    if (g.teacher != nullptr && g.t > 0 && g.teacher_flags[g.t - 1] != 0) {
+    if (g.teacher != nullptr && g.t > 0 && as_g(g.teacher_flags)[g.t - 1] != 0) {
       // decoder.py:65-66: next input = last frame of teacher group t-1 = teacher frame t*r - 1 (fp32 path only)
       s = make_seg1(g.teacher + (size_t)(g.t * g.r - 1) * g.d_mel, g.teacher_T * g.d_mel, g.d_mel);
       s_lo = s;
@@ -202,12 +202,12 @@ __global__ __launch_bounds__(kGemmThreads) void gemm_rows_kernel(GemmArgs g) {
         // decoder.py:53-54: leaky_relu(fc_mel(d_t), 0.01) viewed as [B, r, d_mel]
         v = v > 0.f ? v : mul_rn(v, 0.01f);
         const int jf = n / g.d_mel, c = n - jf * g.d_mel;
-        g.y_out[((size_t)m * g.t_stride * g.r + (size_t)g.t_rel * g.r + jf) * g.d_mel + c] = v;
+        as_g(g.y_out)[((size_t)m * g.t_stride * g.r + (size_t)g.t_rel * g.r + jf) * g.d_mel + c] = v;
         if (jf == g.r - 1) g.ynext[(size_t)m * g.d_mel + c] = v;  // decoder.py:48 y_t[:, -1, :]
       } else {
         // decoder.py:52 stop logit; decoder.py:68 batch-global rule
         const int jf = n - nm;
-        g.s_out[(size_t)m * g.t_stride * g.r + (size_t)g.t_rel * g.r + jf] = v;
+        as_g(g.s_out)[(size_t)m * g.t_stride * g.r + (size_t)g.t_rel * g.r + jf] = v;
         if (g.check_stop && v < g.stop_thr) atomicMin(&g.ctrl->stop_t, g.t);
       }
     } else if (EK == EPI_BN_ISRU) {

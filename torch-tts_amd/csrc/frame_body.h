@@ -161,6 +161,12 @@ __device__ __forceinline__ void frame_body(FrameArgs g, float* lds, int bx, int 
     g.check_stop = c->check_stop;
   }
 
+  const stamp_ptr st = g.dep_signal ? stamps_of(g.ctrl) : (stamp_ptr) nullptr;  // measurement only (TTSDEC_STAMPS)
+  if (tid == 0) {  // role 0 of launch kind 0
+    stamp(st, 0, 0, __builtin_amdgcn_s_getreg((4 << 0) | (0 << 6) | (31 << 11)));
+    stamp(st, 0, 1, __builtin_amdgcn_s_getreg((20 << 0) | (0 << 6) | (3 << 11)));
+    stamp(st, 0, 2, now_rt());
+  }
   // ---- epilogue operands of both PreNet layers, requested early ----
   // split-fp16 consumers read x_pre's planes, never its fp32 form: 4 columns per thread, one 8-byte store per plane - when the
   // tile has rows enough to keep the threads busy (one valid row: 16 threads x 4 serial elements, 12.7 against 12.1 us at B = 1)
@@ -176,7 +182,7 @@ __device__ __forceinline__ void frame_body(FrameArgs g, float* lds, int bx, int 
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const int m = m0 + (r & 3) + 8 * (r >> 2) + 4 * half;
-        if (m < g.M) mk0[r] = g.masks[(size_t)m * PH + wave * 32 + l32];
+        if (m < g.M) mk0[r] = as_g(g.masks)[(size_t)m * PH + wave * 32 + l32];
       }
     }
 #pragma unroll
@@ -187,7 +193,7 @@ __device__ __forceinline__ void frame_body(FrameArgs g, float* lds, int bx, int 
       const int m = m0 + e / kFrameCols, n = n0 + e % kFrameCols;
       if (m < g.M && n < g.P) {
         b1v[j] = g.b1[n];
-        if (g.dropout_mode == TTSDEC_DROPOUT_MASKS) mk1[j] = g.masks[(size_t)g.M * PH + (size_t)m * g.P + n];
+        if (g.dropout_mode == TTSDEC_DROPOUT_MASKS) mk1[j] = as_g(g.masks)[(size_t)g.M * PH + (size_t)m * g.P + n];
       }
     }
   }
@@ -202,51 +208,90 @@ __device__ __forceinline__ void frame_body(FrameArgs g, float* lds, int bx, int 
     for (int i = 0; i < 4; ++i) dst[i] = k.w[i];
   }
 
+  // Retire every load issued so far HERE, before phase F issues its y / s stores.  vmcnt counts loads and stores in ONE
+  // in-order queue: the first use of an early load after those stores (b0v in layer 0's epilogue was the one) makes the
+  // compiler wait for the stores too - a write round trip of 2.5-3.9 us in the middle of the role's critical path (time
+  // stamps, and `s_waitcnt vmcnt(8)` in front of that add).  The loads themselves have long arrived by now.
+  {
+    asm volatile("" ::"v"(b0v), "v"(b1v[0]), "v"(b1v[1]), "v"(b1v[2]), "v"(b1v[3]), "v"(pv[NI - 1]));
+    if constexpr (F16) asm volatile("" ::"v"(w1h[NW1 - 1]), "v"(w1l[NW1 - 1]), "v"(w0h[NW0 - 1]), "v"(w0l[NW0 - 1]));
+    else asm volatile("" ::"v"(w1[NW1 - 1]), "v"(w0[NW0 - 1]));
+    const unsigned keep_bytes = mk1[0] | mk1[1] | mk1[2] | mk1[3] | mk0[15];
+    asm volatile("" ::"v"(keep_bytes));
+  }
+  bool over = false;  // a value left the fp16 range (split-fp16 planes saturate): reported once, report_range below
   // store one element of the input frame as the layer-0 A operand
   auto put_x = [&](int row, int c, float v) {
-    if constexpr (F16) split_f16_checked(v, xs_h[row * (XS * 2) + c], xs_l[row * (XS * 2) + c], g.ctrl);
+    if constexpr (F16) split_f16_flag(v, xs_h[row * (XS * 2) + c], xs_l[row * (XS * 2) + c], over);
     else xs[row * XS + c] = v;
   };
 
   // ---- phase F: the input frame of step t ----
-  const bool teach = g.teacher != nullptr && t > 0 && g.teacher_flags[t - 1] != 0;
+  const bool teach = g.teacher != nullptr && t > 0 && as_g(g.teacher_flags)[t - 1] != 0;
   if (finalize) {
+    // (row pointers and the row / writer predicates once, the stop rule as one flag per thread: written with the tests and
+    // the 64-bit index arithmetic inside the loop this phase was ~110 instructions per column)
+    const bool rowok = fm < g.M, store = rowok && writer;
     const size_t fr = (size_t)fm * g.t_stride * g.r + (size_t)(t_rel - 1) * g.r;
+    const int n_last = nm - g.d_mel;                       // first channel of the group's last frame (decoder.py:48 y_t[:, -1, :])
+    const auto yrow = as_g(g.y_out) + fr * g.d_mel;        // [B, t_stride*r, d_mel]: frame jf, channel c = yrow[jf*d_mel + c]
+    const auto ynrow = as_g(g.ynext) + (size_t)fm * g.d_mel - n_last;
+    const auto srow = as_g(g.s_out) + fr - nm;
+    bool fire = false;
+    if (g.r == 1) {
+      // one frame per step (every shipped config but one): columns [0, K0) are the frame, column K0 the stop logit - no
+      // per-column tests at all
+      static_assert(K0 % 16 == 0 && K0 / 16 + 1 <= NI, "phase F: columns per thread");
+#pragma unroll
+      for (int i = 0; i < K0 / 16; ++i) {
+        const int n = (tid & 15) + 16 * i;
+        const float lv = pv[i] > 0.f ? pv[i] : mul_rn(pv[i], 0.01f);  // decoder.py:53-54
+        put_x(frow, n, rowok ? lv : 0.f);
+        if (store) {
+          yrow[n] = lv;
+          ynrow[n] = lv;
+        }
+      }
+      if (store && (tid & 15) == 0) {
+        srow[K0] = pv[K0 / 16];  // decoder.py:52
+        fire = pv[K0 / 16] < g.stop_thr;
+      }
+    } else
 #pragma unroll
     for (int i = 0; i < NI; ++i) {
       const int n = (tid & 15) + 16 * i;
-      if (n >= NJ) continue;
-      const bool last = n >= nm - g.d_mel && n < nm;  // decoder.py:48 y_t[:, -1, :]
-      if (fm >= g.M) {
-        if (last) put_x(frow, n - (nm - g.d_mel), 0.f);
-        continue;
-      }
-      float v = pv[i];
-      if (n < nm) {
-        v = v > 0.f ? v : mul_rn(v, 0.01f);  // decoder.py:53-54
-        if (writer) g.y_out[fr * g.d_mel + n] = v;  // [B, t_stride*r, d_mel]: frame jf, channel c = fr*d_mel + n
-        if (last) {
-          put_x(frow, n - (nm - g.d_mel), v);
-          if (writer) g.ynext[(size_t)fm * g.d_mel + n - (nm - g.d_mel)] = v;
+      const float v = pv[i];
+      const bool mel = n < nm, last = mel && n >= n_last;
+      const float lv = v > 0.f ? v : mul_rn(v, 0.01f);  // decoder.py:53-54
+      if (last) put_x(frow, n - n_last, rowok ? lv : 0.f);
+      if (store) {
+        if (mel) {
+          yrow[n] = lv;
+          if (last) ynrow[n] = lv;
+        } else if (n < NJ) {
+          srow[n] = v;  // decoder.py:52
+          fire |= v < g.stop_thr;
         }
-      } else if (writer) {
-        g.s_out[fr + (n - nm)] = v;  // decoder.py:52
-        if (g.check_stop && g.ctrl != nullptr && v < g.stop_thr) atomicMin(&g.ctrl->stop_t, t - 1);  // decoder.py:68
       }
     }
+    if (fire && g.check_stop && g.ctrl != nullptr) atomicMin(&g.ctrl->stop_t, t - 1);  // decoder.py:68
   }
-  if (g.only_finalize) return;
+  if (g.only_finalize) {
+    report_range(over, g.ctrl);
+    return;
+  }
+  if (tid == 0) stamp(st, 0, 3, now_rt());  // the previous step's frame is finished
   if (!finalize || teach) {
     if (teach) __syncthreads();  // the teacher frame replaces what phase F put there
     for (int c = tid & 15; c < K0; c += 16) {
       float v = 0.f;
       if (fm < g.M)
-        v = teach ? g.teacher[((size_t)fm * g.teacher_T + (size_t)t * g.r - 1) * g.d_mel + c]  // decoder.py:65-66
-                  : g.ynext[(size_t)fm * g.d_mel + c];
+        v = teach ? as_g(g.teacher)[((size_t)fm * g.teacher_T + (size_t)t * g.r - 1) * g.d_mel + c]  // decoder.py:65-66
+                  : as_g(g.ynext)[(size_t)fm * g.d_mel + c];
       put_x(frow, c, v);
     }
   }
-  __syncthreads();
+  lds_barrier();
 
   // ---- PreNet layer 0: h0 = dropout(relu(x W0^T + b0)), one 32-column tile per wave ----
   if (p0_wave) {
@@ -276,20 +321,43 @@ __device__ __forceinline__ void frame_body(FrameArgs g, float* lds, int bx, int 
       }
     }
     const int col = wave * 32 + l32;
+    // Straight-line epilogue: the keep decisions of the 16 rows are gathered into one bit mask first (ONE branch on the
+    // dropout mode, the Philox words read from LDS in one batch), the range check is a running maximum (ReLU outputs are
+    // >= 0).  Written naively - mode branches, a conditional atomic and an LDS read per row - this loop was ~70
+    // instructions per row and 2-3 us of the role's critical path (time stamps).
+    unsigned keep_bits = 0xffffu;
+    if (g.dropout_mode == TTSDEC_DROPOUT_MASKS) {
+      keep_bits = 0;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) keep_bits |= (mk0[r] ? 1u : 0u) << r;
+    } else if (g.dropout_mode == TTSDEC_DROPOUT_PHILOX) {
+      uint32_t kb[16];
+#pragma unroll
+      for (int r = 0; r < 16; ++r) kb[r] = pm0[((r & 3) + 8 * (r >> 2) + 4 * half) * G0 * 4 + wave];
+      keep_bits = 0;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) keep_bits |= ((kb[r] >> l32) & 1u) << r;  // unit = 32*wave + l32
+    }
+    const float ks = g.dropout_mode == TTSDEC_DROPOUT_OFF ? 1.0f : g.keep_scale;  // (x * 1.0f is exact)
+    float vmax = 0.f;
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
       const int row = (r & 3) + 8 * (r >> 2) + 4 * half;
       float v = add_rn(acc[r], b0v);
       v = v > 0.f ? v : 0.f;
-      if (g.dropout_mode == TTSDEC_DROPOUT_MASKS) v = mk0[r] ? mul_rn(v, g.keep_scale) : 0.f;
-      else if (g.dropout_mode == TTSDEC_DROPOUT_PHILOX)
-        v = ((pm0[row * G0 * 4 + wave] >> l32) & 1u) ? mul_rn(v, g.keep_scale) : 0.f;  // unit = 32*wave + l32
-      if constexpr (F16) split_f16_checked(v, h0_h[row * (HS * 2) + col], h0_l[row * (HS * 2) + col], g.ctrl);
-      else h0s[row * HS + col] = v;
+      v = ((keep_bits >> r) & 1u) ? mul_rn(v, ks) : 0.f;
+      if constexpr (F16) {
+        vmax = fmaxf(vmax, v);
+        split_f16_pos(v, h0_h[row * (HS * 2) + col], h0_l[row * (HS * 2) + col]);
+      } else {
+        h0s[row * HS + col] = v;
+      }
     }
+    over |= vmax > kSplitMax;
   }
-  __syncthreads();
+  lds_barrier();
 
+  if (tid == 0) stamp(st, 0, 4, now_rt());  // layer 0 done
   // ---- PreNet layer 1: 2 column tiles x 4 K quarters over the 8 waves ----
   {
     f32x16 acc = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
@@ -321,20 +389,21 @@ __device__ __forceinline__ void frame_body(FrameArgs g, float* lds, int bx, int 
 #pragma unroll
     for (int r = 0; r < 16; ++r) out[((r & 3) + 8 * (r >> 2) + 4 * half) * RS + l32] = acc[r];
   }
-  __syncthreads();
+  lds_barrier();
   // element (row, col) of the layer-1 tile: sum of the K quarters, bias, relu, dropout
-  auto finish = [&](int row, int col, float bias, uint8_t keep) {
+  // (dropout mode resolved once, no branch per element: see layer 0's epilogue)
+  const int dmode1 = g.dropout_mode;
+  const float ks1 = dmode1 == TTSDEC_DROPOUT_OFF ? 1.0f : g.keep_scale;
+  auto finish = [&](int row, int col, float bias, uint8_t keep_byte) {
     const int n = n0 + col;
     const float* pr = red + (col >> 5) * 32 * RS + row * RS + (col & 31);
-    float v = pr[0];
-#pragma unroll
-    for (int q = 1; q < 4; ++q) v = add_rn(v, pr[q * 2 * 32 * RS]);  // K quarters in order
+    const float q0 = pr[0], q1 = pr[2 * 32 * RS], q2 = pr[4 * 32 * RS], q3 = pr[6 * 32 * RS];
+    const uint32_t kw = pm1[row * 4 + ((n >> 5) & 3)];
+    float v = add_rn(add_rn(add_rn(q0, q1), q2), q3);  // K quarters in order
     v = add_rn(v, bias);
     v = v > 0.f ? v : 0.f;
-    if (g.dropout_mode == TTSDEC_DROPOUT_MASKS) v = keep ? mul_rn(v, g.keep_scale) : 0.f;
-    else if (g.dropout_mode == TTSDEC_DROPOUT_PHILOX)
-      v = ((pm1[row * 4 + ((n >> 5) & 3)] >> (n & 31)) & 1u) ? mul_rn(v, g.keep_scale) : 0.f;
-    return v;
+    const bool keep = dmode1 == TTSDEC_DROPOUT_PHILOX ? ((kw >> (n & 31)) & 1u) != 0 : keep_byte != 0;  // (keep_byte is 1 unless injected)
+    return keep ? mul_rn(v, ks1) : 0.f;
   };
   if (planes_only) {
     // 4 consecutive columns per thread, ONE 8-byte store per plane - write-through when the attention LSTM of this very
@@ -343,8 +412,14 @@ __device__ __forceinline__ void frame_body(FrameArgs g, float* lds, int bx, int 
     const int m = m0 + row, n = n0 + col;
     if (m < g.M && n < g.P) {
       union { f16 h[4]; unsigned long long u; } hi, lo;
+      float vmax = 0.f;
 #pragma unroll
-      for (int c = 0; c < 4; ++c) split_f16_checked(finish(row, col + c, b1v[c], mk1[c]), hi.h[c], lo.h[c], g.ctrl);
+      for (int c = 0; c < 4; ++c) {
+        const float v = finish(row, col + c, b1v[c], mk1[c]);
+        vmax = fmaxf(vmax, v);
+        split_f16_pos(v, hi.h[c], lo.h[c]);
+      }
+      over |= vmax > kSplitMax;
       const size_t oc = g.out_mpad > 0 ? chunk_idx(m, n, g.out_mpad) : (size_t)m * g.P + n;
       if (g.dep_signal) {
         store_wt8(g.xpre_h + oc, hi.u);
@@ -368,17 +443,22 @@ __device__ __forceinline__ void frame_body(FrameArgs g, float* lds, int bx, int 
         store_wt(g.xpre + o, v);
         if (g.xpre_h != nullptr) {
           f16 hi, lo;
-          split_f16_checked(v, hi, lo, g.ctrl);
+          split_f16_flag(v, hi, lo, over);
           store_wt(g.xpre_h + oc, hi);
           store_wt(g.xpre_l + oc, lo);
         }
       } else {
         g.xpre[o] = v;
-        if (g.xpre_h != nullptr) split_f16_checked(v, g.xpre_h[oc], g.xpre_l[oc], g.ctrl);
+        if (g.xpre_h != nullptr) split_f16_flag(v, g.xpre_h[oc], g.xpre_l[oc], over);
       }
     }
   }
-  if (g.dep_signal && g.ctrl != nullptr) role_signal(&g.ctrl->dep_frame);  // the attention LSTM of this launch waits for x_pre
+  report_range(over, g.ctrl);
+  if (tid == 0) stamp(st, 0, 6, now_rt());  // x_pre stores issued
+  if (g.dep_signal && g.ctrl != nullptr) {
+    role_signal(&g.ctrl->dep_frame);  // the attention LSTM of this launch waits for x_pre
+    if (tid == 0) stamp(st, 0, 5, now_rt());
+  }
 }
 
 

@@ -17,10 +17,11 @@
 
 namespace ttsdec {
 
-template <int K0H, int PH, int PREC>
+// NI: projection columns per thread (16 * NI >= r*d_mel + r); 6 covers one frame per step with half the partial-sum loads
+template <int K0H, int PH, int PREC, int NI>
 __global__ __launch_bounds__(kFrameThreads) void frame_kernel(FrameArgs g) {
   __shared__ __attribute__((aligned(16))) float lds[FrameLds<K0H, PH, PREC>::kFloats];
-  frame_body<K0H, PH, PREC>(g, lds, blockIdx.x, blockIdx.y);
+  frame_body<K0H, PH, PREC, NI>(g, lds, blockIdx.x, blockIdx.y);
 }
 
 // ===========================================================================
@@ -147,13 +148,19 @@ void launch_frame(const FrameArgs& a, hipStream_t st) {
   if (a.M <= 0) return;
   const int cols = a.only_finalize ? 1 : (a.P + kFrameCols - 1) / kFrameCols;
   dim3 grid(cols, (a.M + kFrameRows - 1) / kFrameRows), block(kFrameThreads);
-  if (a.prec == PREC_F16S) {
-    if (a.Ph == 256) hipLaunchKernelGGL((frame_kernel<40, 256, PREC_F16S>), grid, block, 0, st, a);
-    else hipLaunchKernelGGL((frame_kernel<40, 128, PREC_F16S>), grid, block, 0, st, a);
-  } else {
-    if (a.Ph == 256) hipLaunchKernelGGL((frame_kernel<40, 256, PREC_F32>), grid, block, 0, st, a);
-    else hipLaunchKernelGGL((frame_kernel<40, 128, PREC_F32>), grid, block, 0, st, a);
-  }
+  const bool few = a.r * a.d_mel + a.r <= 16 * 6;
+  auto go = [&](auto ni) {
+    constexpr int NI = decltype(ni)::value;
+    if (a.prec == PREC_F16S) {
+      if (a.Ph == 256) hipLaunchKernelGGL((frame_kernel<40, 256, PREC_F16S, NI>), grid, block, 0, st, a);
+      else hipLaunchKernelGGL((frame_kernel<40, 128, PREC_F16S, NI>), grid, block, 0, st, a);
+    } else {
+      if (a.Ph == 256) hipLaunchKernelGGL((frame_kernel<40, 256, PREC_F32, NI>), grid, block, 0, st, a);
+      else hipLaunchKernelGGL((frame_kernel<40, 128, PREC_F32, NI>), grid, block, 0, st, a);
+    }
+  };
+  if (few) go(std::integral_constant<int, 6>{});
+  else go(std::integral_constant<int, kFrameMaxNI>{});
 }
 
 }  // namespace ttsdec

@@ -64,10 +64,11 @@ struct RoleGate {
   unsigned int target;
   Ctrl* ctrl;
   int kind;
+  stamp_ptr st;  // (loaded by the caller, once: see common.h stamp)
   __device__ __forceinline__ void wait() const {
-    stamp(ctrl, kind, 3, now_rt());
+    stamp(st, kind, 3, now_rt());
     role_wait(counter, target, ctrl);
-    stamp(ctrl, kind, 4, now_rt());
+    stamp(st, kind, 4, now_rt());
   }
 };
 
@@ -121,11 +122,12 @@ __device__ __forceinline__ void lstm_body(LstmArgs g, float* smem, int bx, int b
   const LoaderPlain<EB> la{g.a, g.a_lo, m0, g.M};
   const LoaderWLstm<BU, EB> lb{g.w, g.w_lo, u0, g.H};
   RoleGate gate;
-  gate.seg = -1; gate.counter = nullptr; gate.target = 0; gate.ctrl = g.ctrl; gate.kind = g.dep_which;
-  if (g.dep_n > 0 && threadIdx.x == 0) {
-    stamp(g.ctrl, g.dep_which, 0, (1ull << 32) | __builtin_amdgcn_s_getreg((4 << 0) | (0 << 6) | (31 << 11)));
-    stamp(g.ctrl, g.dep_which, 1, __builtin_amdgcn_s_getreg((20 << 0) | (0 << 6) | (3 << 11)));
-    stamp(g.ctrl, g.dep_which, 2, now_rt());
+  const stamp_ptr st = g.dep_n > 0 ? stamps_of(g.ctrl) : (stamp_ptr) nullptr;  // measurement only (TTSDEC_STAMPS)
+  gate.seg = -1; gate.counter = nullptr; gate.target = 0; gate.ctrl = g.ctrl; gate.kind = g.dep_which; gate.st = st;
+  if (threadIdx.x == 0) {
+    stamp(st, g.dep_which, 0, (1ull << 32) | __builtin_amdgcn_s_getreg((4 << 0) | (0 << 6) | (31 << 11)));
+    stamp(st, g.dep_which, 1, __builtin_amdgcn_s_getreg((20 << 0) | (0 << 6) | (3 << 11)));
+    stamp(st, g.dep_which, 2, now_rt());
   }
   if (g.dep_n > 0) {
     gate.seg = g.dep_seg;
@@ -190,7 +192,7 @@ __device__ __forceinline__ void lstm_body(LstmArgs g, float* smem, int bx, int b
     if (g.seq_out != nullptr) g.seq_out[((size_t)m * g.seq_Lout + seq_pos) * g.seq_out_ld + g.seq_out_off + unit] = h;
     g.c[idx] = add_rn(mul_rn(g.pz, c_prev), mul_rn(q, c_new));
   }
-  if (g.dep_n > 0 && threadIdx.x == 0) stamp(g.ctrl, g.dep_which, 5, now_rt());
+  if (threadIdx.x == 0) stamp(st, g.dep_which, 5, now_rt());
 }
 
 // ===========================================================================
@@ -221,17 +223,18 @@ __device__ __forceinline__ void attn_body(AttnArgs g, float* part, int b) {
     g.t_stride = c->t_stride;
   }
   constexpr int NW = kAttnThreads / 64;
-  if (g.dep_signal && threadIdx.x == 0) {
-    stamp(g.ctrl, 1, 0, __builtin_amdgcn_s_getreg((4 << 0) | (0 << 6) | (31 << 11)));
-    stamp(g.ctrl, 1, 1, __builtin_amdgcn_s_getreg((20 << 0) | (0 << 6) | (3 << 11)));
-    stamp(g.ctrl, 1, 2, now_rt());
+  const stamp_ptr st = g.dep_signal ? stamps_of(g.ctrl) : (stamp_ptr) nullptr;  // measurement only (TTSDEC_STAMPS)
+  if (threadIdx.x == 0) {
+    stamp(st, 1, 0, __builtin_amdgcn_s_getreg((4 << 0) | (0 << 6) | (31 << 11)));
+    stamp(st, 1, 1, __builtin_amdgcn_s_getreg((20 << 0) | (0 << 6) | (3 << 11)));
+    stamp(st, 1, 2, now_rt());
   }
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
   const int L = g.L, D = g.D, D4 = D >> 2;
-  const float* mem = g.memory + (size_t)b * L * D;
+  const auto mem = as_g(g.memory) + (size_t)b * L * D;  // (g.memory comes from the control block: see as_g)
   const float* wprev = g.w_prev + (size_t)b * L;
   float* wnew = g.w_new + (size_t)b * L;
-  float* wout = g.w_out ? g.w_out + ((size_t)b * g.t_stride + g.t_rel) * L : nullptr;
+  const auto wout = as_g(g.w_out ? g.w_out + ((size_t)b * g.t_stride + g.t_rel) * L : nullptr);
 
   float4 qv[NJ];
 #pragma unroll
@@ -257,7 +260,12 @@ __device__ __forceinline__ void attn_body(AttnArgs g, float* part, int b) {
 #pragma unroll
     for (int j = 0; j < NJ; ++j) {
       const int c4 = lane + 64 * j;
-      r[j] = (c4 < D4) ? *reinterpret_cast<const float4*>(mem + (size_t)l * D + c4 * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
+      if (c4 < D4) {
+        const f32x4 v = *reinterpret_cast<__attribute__((address_space(1))) const f32x4*>(mem + (size_t)l * D + c4 * 4);
+        r[j] = make_float4(v[0], v[1], v[2], v[3]);
+      } else {
+        r[j] = make_float4(0.f, 0.f, 0.f, 0.f);
+      }
     }
   };
   auto dot_row = [&](const float4 (&r)[NJ]) {
@@ -329,7 +337,7 @@ __device__ __forceinline__ void attn_body(AttnArgs g, float* part, int b) {
 #pragma unroll
   for (int j = 0; j < NJ; ++j)
     *reinterpret_cast<float4*>(part + ((wv * NJ + j) * 64 + lane) * 4) = acc[j];
-  __syncthreads();
+  lds_barrier();  // (not __syncthreads(): the w stores above stay in flight)
   for (int d = threadIdx.x; d < D; d += kAttnThreads) {
     const int c4 = d >> 2, comp = d & 3;
     const int j = c4 >> 6, ln = c4 & 63;
@@ -352,7 +360,7 @@ __device__ __forceinline__ void attn_body(AttnArgs g, float* part, int b) {
   }
   if (g.dep_signal && g.ctrl != nullptr) {
     role_signal(&g.ctrl->dep_attn);  // the decoder LSTM of this launch waits for ctx
-    if (threadIdx.x == 0) stamp(g.ctrl, 1, 5, now_rt());
+    if (threadIdx.x == 0) stamp(st, 1, 5, now_rt());
   }
 }
 
