@@ -38,7 +38,9 @@ struct FrameLds {
 // NI: projection columns per thread in phase F (r*d_mel + r <= 16 * NI); the two-role launch uses 6 to stay within 128 VGPRs.
 // lds: FrameLds<...>::kFloats floats (16-byte aligned) of the calling kernel's ONE shared array;
 // (bx, by): column block / row block of this workgroup.
-template <int K0H, int PH, int PREC, int NI = kFrameMaxNI>
+// kLean: for launches whose register budget is 128 (two workgroups per CU): the layer-1 weight fragments are requested
+// after layer 0's MFMAs instead of at kernel entry - 32 registers fewer across phase F and layer 0.
+template <int K0H, int PH, int PREC, int NI = kFrameMaxNI, bool kLean = false>
 __device__ __forceinline__ void frame_body(FrameArgs g, float* lds, int bx, int by) {
   using LD = FrameLds<K0H, PH, PREC>;
   constexpr bool F16 = PREC == PREC_F16S;
@@ -84,6 +86,8 @@ __device__ __forceinline__ void frame_body(FrameArgs g, float* lds, int bx, int 
       }
       b0v = g.b0[wave * 32 + l32];
     }
+  }
+  auto load_w1 = [&]() {
     const size_t o1 = (size_t)(n1 < g.P ? n1 : 0) * PH + (wave >> 1) * KQ + half * K1H;
     if constexpr (F16) {
       gf16x8 *sh = (gf16x8*)(g.W1h + o1), *sl = (gf16x8*)(g.W1l + o1);
@@ -94,6 +98,9 @@ __device__ __forceinline__ void frame_body(FrameArgs g, float* lds, int bx, int 
 #pragma unroll
       for (int j = 0; j < NW1; ++j) w1[j] = src[j];
     }
+  };
+  if constexpr (!kLean) {
+    if (!g.only_finalize) load_w1();
   }
 
   // ---- projection partial sums of the previous step (addresses independent of the control
@@ -214,8 +221,12 @@ __device__ __forceinline__ void frame_body(FrameArgs g, float* lds, int bx, int 
   // stamps, and `s_waitcnt vmcnt(8)` in front of that add).  The loads themselves have long arrived by now.
   {
     asm volatile("" ::"v"(b0v), "v"(b1v[0]), "v"(b1v[1]), "v"(b1v[2]), "v"(b1v[3]), "v"(pv[NI - 1]));
-    if constexpr (F16) asm volatile("" ::"v"(w1h[NW1 - 1]), "v"(w1l[NW1 - 1]), "v"(w0h[NW0 - 1]), "v"(w0l[NW0 - 1]));
-    else asm volatile("" ::"v"(w1[NW1 - 1]), "v"(w0[NW0 - 1]));
+    if constexpr (F16) asm volatile("" ::"v"(w0h[NW0 - 1]), "v"(w0l[NW0 - 1]));
+    else asm volatile("" ::"v"(w0[NW0 - 1]));
+    if constexpr (!kLean) {
+      if constexpr (F16) asm volatile("" ::"v"(w1h[NW1 - 1]), "v"(w1l[NW1 - 1]));
+      else asm volatile("" ::"v"(w1[NW1 - 1]));
+    }
     const unsigned keep_bytes = mk1[0] | mk1[1] | mk1[2] | mk1[3] | mk0[15];
     asm volatile("" ::"v"(keep_bytes));
   }
@@ -320,6 +331,7 @@ __device__ __forceinline__ void frame_body(FrameArgs g, float* lds, int bx, int 
         }
       }
     }
+    if constexpr (kLean) load_w1();  // (layer 0's weight registers are free now; the epilogue and a barrier hide the latency)
     const int col = wave * 32 + l32;
     // Straight-line epilogue: the keep decisions of the 16 rows are gathered into one bit mask first (ONE branch on the
     // dropout mode, the Philox words read from LDS in one batch), the range check is a running maximum (ReLU outputs are

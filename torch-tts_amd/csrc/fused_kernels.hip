@@ -66,7 +66,7 @@ __global__ __launch_bounds__(kGemmThreads, WPE) void frame_lstm_kernel(FrameArgs
   const int id = blockIdx.x;
   if (id < n_frame) {
     __builtin_amdgcn_s_setprio(3);  // the producer role is the launch's critical path: it wins issue arbitration
-    frame_body<K0H, PH, PREC, 6>(f, smem, id % frame_cols, id / frame_cols);
+    frame_body<K0H, PH, PREC, 6, WPE == 4>(f, smem, id % frame_cols, id / frame_cols);
   } else {
     const int j = id - n_frame;
     lstm_body<Cfg, WPE == 2>(l, smem, j % lstm_cols, j / lstm_cols);
