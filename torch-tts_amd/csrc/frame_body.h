@@ -366,6 +366,8 @@ __device__ __forceinline__ void frame_body(FrameArgs g, float* lds, int bx, int 
       }
     }
     over |= vmax > kSplitMax;
+  } else {
+    if constexpr (kLean) load_w1();  // (a wave without a layer-0 tile, PreNet hidden width 128, needs its layer-1 fragments too)
   }
   lds_barrier();
 
