@@ -227,8 +227,17 @@ __device__ __forceinline__ void frame_body(FrameArgs g, float* lds, int bx, int 
       if constexpr (F16) asm volatile("" ::"v"(w1h[NW1 - 1]), "v"(w1l[NW1 - 1]));
       else asm volatile("" ::"v"(w1[NW1 - 1]));
     }
-    const unsigned keep_bytes = mk1[0] | mk1[1] | mk1[2] | mk1[3] | mk0[15];
-    asm volatile("" ::"v"(keep_bytes));
+  }
+  // injected keep-masks of layer 0: the 16 bytes become one 16-bit mask here (15 registers fewer across layer 0)
+  unsigned keep_bits = 0xffffu;
+  if (g.dropout_mode == TTSDEC_DROPOUT_MASKS) {
+    keep_bits = 0;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) keep_bits |= (mk0[r] ? 1u : 0u) << r;
+  }
+  {
+    const unsigned keep1 = mk1[0] | mk1[1] | mk1[2] | mk1[3];
+    asm volatile("" ::"v"(keep1), "v"(keep_bits));
   }
   bool over = false;  // a value left the fp16 range (split-fp16 planes saturate): reported once, report_range below
   // store one element of the input frame as the layer-0 A operand
@@ -333,16 +342,11 @@ __device__ __forceinline__ void frame_body(FrameArgs g, float* lds, int bx, int 
     }
     if constexpr (kLean) load_w1();  // (layer 0's weight registers are free now; the epilogue and a barrier hide the latency)
     const int col = wave * 32 + l32;
-    // Straight-line epilogue: the keep decisions of the 16 rows are gathered into one bit mask first (ONE branch on the
-    // dropout mode, the Philox words read from LDS in one batch), the range check is a running maximum (ReLU outputs are
+    // Straight-line epilogue: the keep decisions of the 16 rows are one bit mask (injected masks: packed above; Philox: the
+    // words read from LDS here in one batch), the range check is a running maximum (ReLU outputs are
     // >= 0).  Written naively - mode branches, a conditional atomic and an LDS read per row - this loop was ~70
     // instructions per row and 2-3 us of the role's critical path (time stamps).
-    unsigned keep_bits = 0xffffu;
-    if (g.dropout_mode == TTSDEC_DROPOUT_MASKS) {
-      keep_bits = 0;
-#pragma unroll
-      for (int r = 0; r < 16; ++r) keep_bits |= (mk0[r] ? 1u : 0u) << r;
-    } else if (g.dropout_mode == TTSDEC_DROPOUT_PHILOX) {
+    if (g.dropout_mode == TTSDEC_DROPOUT_PHILOX) {
       uint32_t kb[16];
 #pragma unroll
       for (int r = 0; r < 16; ++r) kb[r] = pm0[((r & 3) + 8 * (r >> 2) + 4 * half) * G0 * 4 + wave];

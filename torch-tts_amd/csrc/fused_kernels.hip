@@ -69,7 +69,7 @@ __global__ __launch_bounds__(kGemmThreads, WPE) void frame_lstm_kernel(FrameArgs
     frame_body<K0H, PH, PREC, 6, WPE == 4>(f, smem, id % frame_cols, id / frame_cols);
   } else {
     const int j = id - n_frame;
-    lstm_body<Cfg, WPE == 2>(l, smem, j % lstm_cols, j / lstm_cols);
+    lstm_body<Cfg, true, true>(l, smem, j % lstm_cols, j / lstm_cols);
   }
 }
 
@@ -83,7 +83,7 @@ __global__ __launch_bounds__(kGemmThreads, WPE) void attn_lstm_kernel(AttnArgs a
     attn_body<NJ>(a, smem, id);
   } else {
     const int j = id - n_attn;
-    lstm_body<Cfg, WPE == 2>(l, smem, j % lstm_cols, j / lstm_cols);
+    lstm_body<Cfg, true, true>(l, smem, j % lstm_cols, j / lstm_cols);
   }
 }
 

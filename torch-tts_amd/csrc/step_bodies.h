@@ -74,8 +74,11 @@ struct RoleGate {
 
 // kEarlyEpi: request the cell-update operands before the K loop (their latency hides under it); the lean tile
 // requests them after it instead - 20 live registers fewer across the loop, to stay within 128 VGPRs.
-template <class Cfg, bool kEarlyEpi = true>
+// kWhole: the caller only ever runs whole cells (mode 0, no sequence mode): the parked partial sums and their registers
+// drop out, which is what lets the lean tile of the two-role launches request the rest of the operands early.
+template <class Cfg, bool kEarlyEpi = true, bool kWhole = false>
 __device__ __forceinline__ void lstm_body(LstmArgs g, float* smem, int bx, int by) {
+  if constexpr (kWhole) { g.mode = 0; g.seq_lens = nullptr; g.seq_out = nullptr; }
   bool live = true;
   if (g.ctrl != nullptr) {
     // live_lag: this launch also holds the frame kernel's workgroups, which may lower stop_t to t-1 while it is
