@@ -89,6 +89,12 @@ __device__ __forceinline__ float isru(float x) { return div_rn(x, sqrt_rn(add_rn
 __device__ __forceinline__ float isru_sigmoid(float x) { return mul_rn(add_rn(1.0f, isru(mul_rn(x, 0.5f))), 0.5f); }
 
 __device__ __forceinline__ float sigmoid_f(float x) { return div_rn(1.0f, add_rn(1.0f, expf(-x))); }
+// The LSTM cell's gate functions on the hardware exponential and reciprocal (v_exp_f32, v_rcp_f32, ~1 ulp each): absolute error <= ~2e-7, two orders below
+// the 1e-4 bar and below what split-fp16 operands already carry (2^-22 relative).  The library forms (range reduction,
+// branches per interval) made the cell update ~350 instructions per element - 1.3 us at the end of each LSTM launch.
+__device__ __forceinline__ float exp_hw(float x) { return __builtin_amdgcn_exp2f(x * 1.4426950408889634f); }  // v_exp_f32
+__device__ __forceinline__ float sigmoid_fast(float x) { return __builtin_amdgcn_rcpf(1.0f + exp_hw(-x)); }
+__device__ __forceinline__ float tanh_fast(float x) { return 1.0f - 2.0f * __builtin_amdgcn_rcpf(1.0f + exp_hw(2.0f * x)); }
 
 // ---------------------------------------------------------------------------
 // Philox4x32-10 (Salmon et al. 2011), used for the on-device PreNet dropout.  One call yields

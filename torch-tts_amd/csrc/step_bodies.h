@@ -182,8 +182,8 @@ __device__ __forceinline__ void lstm_body(LstmArgs g, float* smem, int bx, int b
     const float c_prev = pc[j];
     const float h_prev = ph[j];
     // nn.LSTMCell: c' = sigmoid(f)*c + sigmoid(i)*tanh(g); h' = sigmoid(o)*tanh(c')
-    const float c_new = add_rn(mul_rn(sigmoid_f(gf), c_prev), mul_rn(sigmoid_f(gi), tanhf(gg)));
-    const float h_new = mul_rn(sigmoid_f(go), tanhf(c_new));
+    const float c_new = add_rn(mul_rn(sigmoid_fast(gf), c_prev), mul_rn(sigmoid_fast(gi), tanh_fast(gg)));
+    const float h_new = mul_rn(sigmoid_fast(go), tanh_fast(c_new));
     // rnn.py:36-38 eval-mode zoneout: p*prev + (1-p)*new
     const float q = sub_rn(1.0f, g.pz);
     const float h = add_rn(mul_rn(g.pz, h_prev), mul_rn(q, h_new));
