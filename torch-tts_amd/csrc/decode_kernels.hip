@@ -357,8 +357,10 @@ void launch_lstm_pair(const LstmArgs& a0, const LstmArgs& a1, hipStream_t st) {
 
 void launch_lstm(const LstmArgs& a, hipStream_t st) {
   if (a.M <= 0) return;
+  // (more than two 64-row blocks of 8-unit tiles would be more workgroups than CUs - a second round: 45.8 us for the decoder
+  // LSTM at B = 160 against 25.8 at B = 128 - so anything above 128 rows takes the 16-unit tile)
   if (a.prec == 1) {
-    if (a.M >= 192) {
+    if (a.M > 128) {
       using Cfg = TileCfg<2, 2, 1, 4, PREC_F16S>;  // 64 rows x 16 units, 32 KiB stages (64 k each); S=5 and nt weight loads measured slower
       dim3 grid((a.H + 15) / 16, (a.M + 63) / 64);
       launch_lstm_tagged<Cfg>(a, grid, st);
@@ -375,7 +377,7 @@ void launch_lstm(const LstmArgs& a, hipStream_t st) {
     }
     return;
   }
-  if (a.M >= 192) {
+  if (a.M > 128) {
     using Cfg = TileCfg<2, 2, 1, 6>;  // 64 rows x 16 units, 16 KiB stages
     dim3 grid((a.H + 15) / 16, (a.M + 63) / 64);
     launch_lstm_tagged<Cfg>(a, grid, st);
