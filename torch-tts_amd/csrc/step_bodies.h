@@ -207,22 +207,6 @@ __device__ __forceinline__ void lstm_body(LstmArgs g, float* smem, int bx, int b
 // is still in registers.  Row l needs p0[l-1], so a wave recomputes the energy
 // of the row just before its range.
 // ===========================================================================
-// Sum over the 64 lanes, the same value returned to every lane.  DPP row operations (register-to-register), not
-// __shfl_xor: that is ds_bpermute_b32, an LDS-path instruction with a wait behind each of its six steps.
-__device__ __forceinline__ float wave_sum(float v) {
-  auto dpp = [](float x, auto ctrl, auto row_mask) {
-    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), decltype(ctrl)::value, decltype(row_mask)::value, 0xf, true));
-  };
-  using std::integral_constant;
-  v += dpp(v, integral_constant<int, 0xB1>{}, integral_constant<int, 0xf>{});   // quad_perm [1,0,3,2]
-  v += dpp(v, integral_constant<int, 0x4E>{}, integral_constant<int, 0xf>{});   // quad_perm [2,3,0,1]
-  v += dpp(v, integral_constant<int, 0x141>{}, integral_constant<int, 0xf>{});  // row_half_mirror
-  v += dpp(v, integral_constant<int, 0x140>{}, integral_constant<int, 0xf>{});  // row_mirror: every lane holds its 16-lane row's sum
-  v += dpp(v, integral_constant<int, 0x142>{}, integral_constant<int, 0xa>{});  // row_bcast:15 into rows 1 and 3
-  v += dpp(v, integral_constant<int, 0x143>{}, integral_constant<int, 0xc>{});  // row_bcast:31 into rows 2 and 3: lane 63 holds the total
-  return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 63));
-}
-
 // part: kAttnThreads / 64 * NJ * 256 floats of LDS (the caller's ONE shared array); b: the utterance.
 template <int NJ>
 __device__ __forceinline__ void attn_body(AttnArgs g, float* part, int b) {

@@ -147,8 +147,7 @@ __global__ __launch_bounds__(256) void layernorm_rows_kernel(const float* in, co
     v[j] = c < C ? x[c] : 0.f;
     s += v[j];
   }
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
+  s = wave_sum(s);
   const float mean = s / (float)C;
   float q = 0.f;
 #pragma unroll
@@ -157,8 +156,7 @@ __global__ __launch_bounds__(256) void layernorm_rows_kernel(const float* in, co
     const float dlt = c < C ? v[j] - mean : 0.f;
     q += dlt * dlt;
   }
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) q += __shfl_xor(q, o);
+  q = wave_sum(q);
   const float rstd = 1.0f / sqrt_rn(add_rn(q / (float)C, eps));
   const float mk = mask ? mask[row] : 1.0f;
 #pragma unroll
@@ -248,16 +246,14 @@ __global__ __launch_bounds__(kMhaThreads) void mha_kernel(MhaArgs g) {
       float* row = S + (wave * 4 + rr) * T;
       float mx = -3.4e38f;
       for (int j = lane; j < T; j += 64) mx = fmaxf(mx, row[j]);
-#pragma unroll
-      for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o));
+      mx = wave_max(mx);
       float sum = 0.f;
       for (int j = lane; j < T; j += 64) {
         const float e = expf(row[j] - mx);
         row[j] = e;
         sum += e;
       }
-#pragma unroll
-      for (int o = 32; o > 0; o >>= 1) sum += __shfl_xor(sum, o);
+      sum = wave_sum(sum);
       for (int j = lane; j < T; j += 64) row[j] = div_rn(row[j], sum);
     }
   }
@@ -416,16 +412,14 @@ __global__ __launch_bounds__(kMhaMThreads) void mha_mfma_kernel(MhaArgs g) {
     float* row = S + (wave * 8 + rr) * ST;
     float mx = -3.4e38f;
     for (int j = lane; j < T; j += 64) mx = fmaxf(mx, row[j]);
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o));
+    mx = wave_max(mx);
     float sum = 0.f;
     for (int j = lane; j < T; j += 64) {
       const float e = __expf(row[j] - mx);
       row[j] = e;
       sum += e;
     }
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) sum += __shfl_xor(sum, o);
+    sum = wave_sum(sum);
     if (lane == 0) rinv[wave * 8 + rr] = 1.0f / sum;
   }
   __syncthreads();
