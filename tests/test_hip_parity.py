@@ -263,7 +263,7 @@ def test_two_frames_per_step_r2(H, prec):
     H.assert_close(w2, ow2, RTOL, ATOL, "w teacher r=2")
 
 
-@pytest.mark.parametrize("B,L,T", [(2, 1, 5), (3, 2, 6), (4, 301, 8), (33, 77, 5)])
+@pytest.mark.parametrize("B,L,T", [(2, 1, 5), (3, 2, 6), (4, 301, 8), (2, 520, 4), (33, 77, 5)])  # (L = 520: more rows per wave than lanes)
 def test_memory_length_edges(H, B, L, T):
     """L = 1 (the only column is the absorbing one, e = 1e4), L = 2, and L longer than the
     LJSpeech case; B = 33 leaves a ragged last row tile."""

@@ -285,13 +285,24 @@ __device__ __forceinline__ void attn_body(AttnArgs g, float* part, int b) {
 #pragma unroll
   for (int j = 0; j < NJ; ++j) acc[j] = make_float4(0.f, 0.f, 0.f, 0.f);
 
+  // The previous weights of this wave's rows, l0-1 .. l1-1, in ONE coalesced load (lane i holds w_prev[l0 - 1 + i]); the new
+  // ones are gathered the same way and stored after the loop: a store inside the loop sits in the same in-order queue as the
+  // next group's row loads, whose wait then also waits for the store.
+  const int nrows = l1 > l0 ? l1 - l0 : 0;
+  const bool lanes_hold_w = chunk < 64;  // (rows per wave + 1 <= 64 lanes; longer memories take the per-row accesses)
+  float wp_lane = 0.f, wn_lane = 0.f;
+  if (lanes_hold_w && lane <= nrows && l0 - 1 + lane >= 0 && l0 - 1 + lane < L) wp_lane = wprev[l0 - 1 + lane];
+  auto w_prev_of = [&](int l) {  // l in [l0 - 1, l1): uniform
+    return lanes_hold_w ? __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, wp_lane), l - l0 + 1)) : wprev[l];
+  };
+
   if (l0 < l1) {
     float w1_prev = 0.f;  // w[l-1] * (1 - p0[l-1])   attention.py:120
     if (l0 > 0) {
       float4 r[NJ];
       load_row(l0 - 1, r);
       const float p0 = isru_sigmoid(dot_row(r));  // l0-1 < L-1, never the overridden column
-      w1_prev = mul_rn(wprev[l0 - 1], sub_rn(1.0f, p0));
+      w1_prev = mul_rn(w_prev_of(l0 - 1), sub_rn(1.0f, p0));
     }
     constexpr int G = 4;  // rows in flight per wave (8 measured slower, 17.2 vs 15.2 us; all 15 rows of a wave at once 18.2 vs 15.6 us at
                           // B = 256 and no faster at B = 1: the pass runs at the Infinity-Cache rate, not at a latency chain's)
@@ -310,12 +321,14 @@ __device__ __forceinline__ void attn_body(AttnArgs g, float* part, int b) {
         if (l < l1) {
           const float en = (l == L - 1) ? 1e4f : e[i];  // attention.py:117
           const float p0 = isru_sigmoid(en);            // attention.py:118
-          const float wl = wprev[l];
+          const float wl = w_prev_of(l);
           const float w0 = mul_rn(wl, p0);                      // :119
           float wn = (l > 0) ? add_rn(w0, w1_prev) : w0;        // :122-123
           w1_prev = mul_rn(wl, sub_rn(1.0f, p0));               // :120
           if (g.ctx_only) wn = wl;
-          if (lane == 0 && !g.ctx_only) {
+          if (lanes_hold_w) {
+            if (lane == l - l0) wn_lane = wn;
+          } else if (lane == 0 && !g.ctx_only) {
             wnew[l] = wn;
             if (wout) wout[l] = wn;
           }
@@ -328,6 +341,10 @@ __device__ __forceinline__ void attn_body(AttnArgs g, float* part, int b) {
           }
         }
       }
+    }
+    if (lanes_hold_w && !g.ctx_only && lane < nrows) {
+      wnew[l0 + lane] = wn_lane;
+      if (wout) wout[l0 + lane] = wn_lane;
     }
   }
   // cross-wave sum of the context partials in a fixed order (deterministic)
