@@ -85,6 +85,9 @@ __device__ __forceinline__ float sqrt_rn(float a) { return __fsqrt_rn(a); }
 
 // isru(x) = x / sqrt(1 + 1.0*(x*x))            tacotron/modules/activations.py:9-10
 __device__ __forceinline__ float isru(float x) { return div_rn(x, sqrt_rn(add_rn(1.0f, mul_rn(x, x)))); }
+// The same on the hardware reciprocal square root (v_rsq_f32, ~1 ulp) for the conv epilogues of the Postnet and Encoder2, where
+// a thread finishes 32 outputs per tile: relative error ~2e-7 against a 1e-4 bar.  The attention weights keep the exact form.
+__device__ __forceinline__ float isru_fast(float x) { return x * __builtin_amdgcn_rsqf(fmaf(x, x, 1.0f)); }
 // isru_sigmoid(x) = (1 + isru(x/2)) / 2         tacotron/modules/activations.py:5-6
 __device__ __forceinline__ float isru_sigmoid(float x) { return mul_rn(add_rn(1.0f, isru(mul_rn(x, 0.5f))), 0.5f); }
 
