@@ -22,11 +22,11 @@ sys.path.insert(0, ROOT)
 # kernel symbol -> the step-kernel names bench.py uses
 STEP_KERNELS = [
     ("frame_lstm_kernel", "prenet+lstm_att"), ("attn_lstm_kernel", "attention+lstm_dec"), ("lstm_lean_kernel", "lstm_lean(alone)"),
-    ("frame_kernel", "prenet"), ("attn_kernel", "attention"),
+    ("frame_kernel", "prenet"), ("attn_kernel", "attention"), ("proj_kernel", "proj"),
 ]
 
 
-STEP_LABELS = {label for _, label in STEP_KERNELS} | {"lstm_att", "lstm_dec", "gemm_rows:TileCfg<1, 1, 2, 4, 1, 0, 1, 1, 0>, 0, 0"}
+STEP_LABELS = {label for _, label in STEP_KERNELS} | {"lstm_att", "lstm_dec", "query"}
 
 
 def short(name):
@@ -36,6 +36,8 @@ def short(name):
             return label
     if "lstm_kernel" in name:
         return "lstm_dec" if name.rstrip().endswith("1>(ttsdec::LstmArgs)") else "lstm_att"
+    if "gemm_rows_kernel<ttsdec::TileCfg<1, 1, 2, 4, 1, 0, 1, 1, 0>, 0, 0>" in name:
+        return "query"  # (the split-K query projection is the only user of this instantiation in a decode step)
     if "gemm_rows_kernel" in name:
         return "gemm_rows:" + name.split("gemm_rows_kernel<")[1].split(">(")[0].replace("ttsdec::", "")
     return name.split("(")[0][:80]

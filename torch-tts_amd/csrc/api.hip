@@ -78,11 +78,11 @@ struct ttsdec_handle {
   std::string hip_err;
   bool use_graph;   // replay a captured hipGraph instead of launching every kernel
   // Two-role launches (fused_kernels.hip) where they apply: 1 = frame || lstm_att; 2 = also attention || lstm_dec;
-  // 0 = off; -1 (default) = by batch size: level 2 below 192 utterances, level 1 from there.  Measured us per step for
-  // levels 1 / 2 (end of round 2, profiles/r02_h_levels.txt): B = 128 69.0 / 53.7, B = 160 90.7 / 66.1, B = 176 92.3 / 68.9,
-  // B = 192 69.1 / 70.4, B = 256 80.8 / 86.1: with 192+ attention workgroups most of them share a CU with an LSTM
-  // workgroup, starve beside its tile stream, and the LSTM then waits for the slowest of them.  (Split-fp16; exact fp32:
-  // see overlap_level.)
+  // 0 = off; -1 (default) = by batch size: level 2 up to 320 utterances, level 1 above.  Measured us per step for levels
+  // 1 / 2 (end of round 2): B = 128 69.0 / 53.7, B = 192 66.2 / 59.5, B = 256 77.2 / 70.2.  Until the attention role's row sums
+  // moved from ds_bpermute to DPP (common.h wave_sum) level 2 LOST from 192 utterances on (B = 256: 80.8 / 86.1): the role's
+  // LDS-path shuffles queued behind the co-resident LSTM workgroup's LDS traffic, the attention workgroups finished late and
+  // every LSTM workgroup waited for the slowest of them.  (Split-fp16; exact fp32: see overlap_level.)
   // TTSDEC_OVERLAP=0/1/2 or TTSDEC_NO_OVERLAP=1 (measurement switches).
   int overlap;
   bool chunk_a, chunk_b;  // chunked layout of the activation planes / LSTM weight planes; TTSDEC_CHUNK_A/B=0 (measurement)
@@ -634,7 +634,7 @@ int overlap_level(const ttsdec_handle* h, int B) {
   const ttsdec_dims& d = h->d;
   if (is_taco2(d) || !fused_supported(d.d_mel, d.r, pre_hidden(d), d.d_pre, d.d_ctx)) return 0;
   if (h->overlap >= 0) return h->overlap;
-  if (lstm_prec(h)) return B < 192 ? 2 : 1;
+  if (lstm_prec(h)) return B <= 320 ? 2 : 1;  // (above that the two differ by +-1.5 %: B = 384 110.6 / 112.5, B = 512 133.4 / 130.0, B = 2048 494.5 / 502.3)
   // exact fp32: the matrix pipe is the LSTMs' bound there, and the 64x8 lean tile of the middle batch sizes keeps only
   // two of a CU's four matrix pipes busy - so small batches (stand-alone tile) and chip-filling ones only.  us per step for
   // levels 0 / 1 / 2: B = 32 75.3 / 67.4 / 56.4, B = 64 76.2 / 87.1 / 109.8, B = 96 100.8 / 103.9 / 114.3, B = 128 102.2 /

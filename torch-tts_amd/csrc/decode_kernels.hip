@@ -182,6 +182,21 @@ __global__ __launch_bounds__(kGemmThreads) void gemm_rows_kernel(GemmArgs g) {
   }
   if (!live) return;
 
+  // 128x128 tiles: the per-ELEMENT operands (residual, row mask) of all 32 outputs are requested in one batch - inside the
+  // loop below each was a load with its own wait
+  constexpr int NBATCH = kColConst && (EK == EPI_RESIDUAL || EK == EPI_GENERIC) ? EPT : 1;
+  float bat_res[NBATCH], bat_rm[NBATCH];
+  if constexpr (NBATCH > 1) {
+    const bool has_res = EK == EPI_RESIDUAL || g.resid != nullptr, has_rm = EK == EPI_GENERIC && g.row_mask != nullptr;
+#pragma unroll
+    for (int j = 0; j < EPT; ++j) {
+      const int e = threadIdx.x + j * kGemmThreads;
+      const int m = m0 + e / BN, n = n0 + e % BN;
+      const bool ok = m < g.M && n < g.N;
+      bat_res[j] = (ok && has_res) ? g.resid[(size_t)m * g.ldo + n] : 0.f;
+      bat_rm[j] = (ok && has_rm) ? g.row_mask[m] : 1.0f;
+    }
+  }
 #pragma unroll
   for (int j = 0; j < EPT; ++j) {
     const int e = threadIdx.x + j * kGemmThreads;
@@ -194,11 +209,7 @@ __global__ __launch_bounds__(kGemmThreads) void gemm_rows_kernel(GemmArgs g) {
     if constexpr (kPre) { pb = pre_bias[j]; pr = pre_res[j]; prm = pre_rm[j]; pm = pre_mask[j]; }
     else if constexpr (kColConst) {
       pb = col_b; pr = col_r; prm = 1.0f; pm = 1;
-      if (EK == EPI_RESIDUAL) pr = g.resid[(size_t)m * g.ldo + n];
-      if (EK == EPI_GENERIC) {
-        if (g.resid != nullptr) pr = g.resid[(size_t)m * g.ldo + n];
-        if (g.row_mask != nullptr) prm = g.row_mask[m];
-      }
+      if constexpr (NBATCH > 1) { pr = bat_res[j]; prm = bat_rm[j]; }
       if (EK == EPI_RELU_DROPOUT && g.dropout_mode == TTSDEC_DROPOUT_MASKS) pm = as_g(g.masks)[(size_t)m * g.N + n];
     } else load_epi(m, n, true, pb, pr, prm, pm);
     if (EK != EPI_BN_ISRU && EK != EPI_BN_LRELU && EK != EPI_BN_ISRLU && g.bias != nullptr) v = add_rn(v, pb);
