@@ -197,12 +197,19 @@ __global__ __launch_bounds__(kGemmThreads) void gemm_rows_kernel(GemmArgs g) {
       bat_rm[j] = (ok && has_rm) ? g.row_mask[m] : 1.0f;
     }
   }
+  // (the 128x128 tiles step the element offset from row to row instead of recomputing m * ldo + n in 64-bit arithmetic
+  // for each of a thread's 32 outputs; the 16-bit output kind and the range check are resolved once)
+  const size_t o_first = (size_t)(m0 + (int)(threadIdx.x / BN)) * g.ldo + n0 + (int)(threadIdx.x % BN);
+  const size_t o_step = (size_t)(kGemmThreads / BN) * g.ldo;
+  const int okind = g.out_kind;
+  bool over = false;
 #pragma unroll
   for (int j = 0; j < EPT; ++j) {
     const int e = threadIdx.x + j * kGemmThreads;
     const int row = e / BN, col = e % BN;
     const int m = m0 + row, n = n0 + col;
     if (m >= g.M || n >= g.N) continue;
+    const size_t o = kColConst ? o_first + (size_t)j * o_step : (size_t)m * g.ldo + n;
     float v = smem[row * LDO + col];
     float pb, pr, prm;
     uint8_t pm;
@@ -214,12 +221,14 @@ __global__ __launch_bounds__(kGemmThreads) void gemm_rows_kernel(GemmArgs g) {
     } else load_epi(m, n, true, pb, pr, prm, pm);
     if (EK != EPI_BN_ISRU && EK != EPI_BN_LRELU && EK != EPI_BN_ISRLU && g.bias != nullptr) v = add_rn(v, pb);
     auto store16 = [&](float val) {  // 16-bit copies for a following 16-bit GEMM
-      const size_t o = (size_t)m * g.ldo + n;
-      if (g.out_kind == 1) split_f16_checked(val, g.out_h[o], g.out_l[o], g.ctrl);
-      else if (g.out_kind == 2) reinterpret_cast<bf16*>(g.out_h)[o] = (bf16)val;
+      if (okind == 1) {
+        split_f16_flag(val, g.out_h[o], g.out_l[o], over);  // (saturating; reported once, below)
+      } else if (okind == 2) {
+        reinterpret_cast<bf16*>(g.out_h)[o] = (bf16)val;
+      }
     };
     if (EK == EPI_PLAIN) {
-      g.out[(size_t)m * g.ldo + n] = v;
+      g.out[o] = v;
       store16(v);
     } else if (EK == EPI_RELU_DROPOUT) {
       // modules.py:39-40: relu then dropout(p, always): kept units scaled by 1/(1-p)
@@ -229,7 +238,7 @@ __global__ __launch_bounds__(kGemmThreads) void gemm_rows_kernel(GemmArgs g) {
       } else if (g.dropout_mode == TTSDEC_DROPOUT_PHILOX) {
         v = philox_keep(g.seed, (uint32_t)g.t, (uint32_t)g.layer, (uint32_t)m, (uint32_t)n) ? mul_rn(v, g.keep_scale) : 0.f;
       }
-      g.out[(size_t)m * g.ldo + n] = v;
+      g.out[o] = v;
       store16(v);
     } else if (EK == EPI_PROJ) {
       const int nm = g.r * g.d_mel;
@@ -248,33 +257,34 @@ __global__ __launch_bounds__(kGemmThreads) void gemm_rows_kernel(GemmArgs g) {
     } else if (EK == EPI_BN_ISRU) {
       // modules.py:181 isru(BatchNorm1d(conv(x))) with eval-mode BN as x*alpha + beta
       v = isru_fast(add_rn(mul_rn(v, pb), pr));
-      if (g.out != nullptr) g.out[(size_t)m * g.ldo + n] = v;
+      if (g.out != nullptr) g.out[o] = v;
       store16(v);
     } else if (EK == EPI_BN_ISRLU) {
       // encoder.py:49-57 ISRLU(BatchNorm1d(conv(x))): x >= 0 ? x : x / sqrt(1 + x*x)  (activations.py:13-14)
       v = add_rn(mul_rn(v, pb), pr);
       v = v >= 0.f ? v : isru_fast(v);
-      if (g.out != nullptr) g.out[(size_t)m * g.ldo + n] = v;
+      if (g.out != nullptr) g.out[o] = v;
       store16(v);
     } else if (EK == EPI_BN_LRELU) {
       // modules.py:196-198 LeakyReLU(BatchNorm1d(conv(x))), default negative_slope 0.01
       v = add_rn(mul_rn(v, pb), pr);
       v = v > 0.f ? v : mul_rn(v, 0.01f);
-      if (g.out != nullptr) g.out[(size_t)m * g.ldo + n] = v;
+      if (g.out != nullptr) g.out[o] = v;
       store16(v);
     } else if (EK == EPI_GENERIC) {
       if (g.act == 1) v = v > 0.f ? v : 0.f;
       if (g.row_mask != nullptr) v = mul_rn(v, prm);
       if (g.resid != nullptr) v = add_rn(pr, v);
-      g.out[(size_t)m * g.ldo + n] = v;
+      g.out[o] = v;
       store16(v);
     } else if (EK == EPI_RESIDUAL) {
       // modules.py:184 x + fc_out(...)  /  modules.py:215 x + layer(x)
       v = add_rn(pr, v);
-      g.out[(size_t)m * g.ldo + n] = v;
+      g.out[o] = v;
       store16(v);
     }
   }
+  report_range(over, g.ctrl);
 }
 
 template <int AK, int EK, int PREC>
