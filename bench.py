@@ -351,17 +351,17 @@ class Workload:
         # Two-role step (csrc/fused_kernels.hip): each LSTM shares a launch with the small kernel in front of it;
         # the launch's algorithmic bytes are the sum of its two roles'.
         alg = dict(bytes_k)
-        alg.update({
-            "prenet+lstm_att": bytes_k["prenet"] + bytes_k["lstm_att"], "attention+lstm_dec": bytes_k["attention"] + bytes_k["lstm_dec"],
-            "prenet0": 0, "prenet1": 0,
-        })
+        alg.update({"prenet0": 0, "prenet1": 0})
+
+        def alg_bytes(name):  # "a+b+c" = one launch running those roles: the sum of their bytes
+            return sum(alg.get(part, 0) for part in name.split("+"))
         per_kernel, alone = {}, {}
         for name, ms in kms.items():
             if name.endswith("(alone)"):
                 alone[name] = round(ms, 5)
                 continue
             key = "prenet" if name in ("prenet0", "prenet1") else name
-            ent = per_kernel.setdefault(key, {"ms": 0.0, "alg_bytes": alg.get(key, 0)})
+            ent = per_kernel.setdefault(key, {"ms": 0.0, "alg_bytes": alg_bytes(key)})
             ent["ms"] += ms
         for ent in per_kernel.values():
             ent["GBps"] = round(ent["alg_bytes"] / (ent["ms"] * 1e-3) / 1e9, 1)

@@ -1077,6 +1077,8 @@ _STEP_SWITCHES = [
     {}, {"TTSDEC_OVERLAP": "0"}, {"TTSDEC_OVERLAP": "1"}, {"TTSDEC_OVERLAP": "2"}, {"TTSDEC_NO_GRAPH": "1"},
     {"TTSDEC_OVERLAP": "2", "TTSDEC_NO_GRAPH": "1"}, {"TTSDEC_CHUNK_A": "0"}, {"TTSDEC_CHUNK_B": "0"},
     {"TTSDEC_CHUNK_A": "0", "TTSDEC_CHUNK_B": "0", "TTSDEC_OVERLAP": "2"}, {"TTSDEC_PROJ_REGW": "0"},
+    {"TTSDEC_HEAD_PROJ": "1"}, {"TTSDEC_HEAD_PROJ": "1", "TTSDEC_OVERLAP": "1"}, {"TTSDEC_HEAD_PROJ": "1", "TTSDEC_NO_GRAPH": "1"},
+    {"TTSDEC_HEAD_PROJ": "0"},
 ]
 
 
@@ -1100,7 +1102,10 @@ def test_all_step_orders_and_layouts_vs_oracle(H, prec, monkeypatch):
                     from torch_tts_amd import _lib
                     names = set(dec.engine(torch.device("cuda:0")).profile_step(mem.cuda(), 1, _lib.DROPOUT_OFF, None, 0))
                     lv = int(env["TTSDEC_OVERLAP"])
-                    assert ("prenet+lstm_att" in names) == (lv >= 1) and ("attention+lstm_dec" in names) == (lv >= 2), (env, names)
+                    fa = "prenet+lstm_att" in names or "proj+prenet+lstm_att" in names
+                    assert fa == (lv >= 1) and ("attention+lstm_dec" in names) == (lv >= 2), (env, names)
+                    if env.get("TTSDEC_HEAD_PROJ") == "1" and prec == "split_f16":
+                        assert "proj+prenet+lstm_att" in names and "proj" not in names, (env, names)
             what = f"B={B} {prec} {env}"
             assert not fired and y.shape == oy.shape, what
             H.assert_close(y, oy, RTOL, ATOL, "y " + what)

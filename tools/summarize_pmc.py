@@ -26,11 +26,13 @@ STEP_KERNELS = [
 ]
 
 
-STEP_LABELS = {label for _, label in STEP_KERNELS} | {"lstm_att", "lstm_dec", "query"}
+STEP_LABELS = {label for _, label in STEP_KERNELS} | {"lstm_att", "lstm_dec", "query", "proj+prenet+lstm_att"}
 
 
 def short(name):
     name = name.replace("(anonymous namespace)::", "").replace("void ", "")
+    if "frame_lstm_kernel" in name and name.rstrip().endswith(", true>(ttsdec::FrameArgs, ttsdec::LstmArgs, ttsdec::ProjArgs, int, int, int, int)"):
+        return "proj+prenet+lstm_att"  # (the three-role form of the frame launch)
     for key, label in STEP_KERNELS:
         if key in name:
             return label

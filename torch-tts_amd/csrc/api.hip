@@ -87,6 +87,7 @@ struct ttsdec_handle {
   int overlap;
   bool chunk_a, chunk_b;  // chunked layout of the activation planes / LSTM weight planes; TTSDEC_CHUNK_A/B=0 (measurement)
   bool proj_regw;         // mel/stop projection on the register-weight kernel where it applies; TTSDEC_PROJ_REGW=0 (measurement)
+  int head_proj;          // that projection as a role at the head of the NEXT step's frame launch: 1 / 0, -1 = by batch size; TTSDEC_HEAD_PROJ
   hipStream_t cap_stream;
   bool streams_ready;
   // one cached graph: valid for exactly this (workspace, blob, B, L, precision)
@@ -340,8 +341,9 @@ struct StepIo {
 // projection + both PreNet layers), N_FIN its end-of-call form; N_P0 / N_P1 are the separate
 // PreNet layers used when the dims are outside what the frame kernel covers.
 // Two-role step (fused_kernels.hip): N_FA = frame || attention LSTM, N_TD = attention || decoder LSTM;
-// N_AG / N_DG are those LSTMs alone on the lean tile (profiling).
-enum Node { N_F, N_FIN, N_P0, N_P1, N_A, N_Q, N_T, N_D, N_J, N_FA, N_TD, N_AG, N_DG };
+// N_AG / N_DG are those LSTMs alone on the lean tile (profiling).  N_JFA = N_FA with the PREVIOUS step's mel/stop projection as a
+// role at its head (then no N_J in the step), N_JFIN = the projection of a call's last step.
+enum Node { N_F, N_FIN, N_P0, N_P1, N_A, N_Q, N_T, N_D, N_J, N_FA, N_TD, N_AG, N_DG, N_JFA, N_JFIN };
 // PART_GATED: the whole cell with the segment that waits for the other role of the launch LAST
 enum LstmPart { PART_WHOLE = 0, PART_EARLY = 1, PART_LATE = 2, PART_GATED = 3 };
 
@@ -356,6 +358,7 @@ struct StepOrder {
 bool split_ok(const ttsdec_dims& d) { return !((d.d_pre | d.d_ctx | d.h_att | d.h_dec) & 7); }
 // launch order of one step: the Prod cell attends between its two LSTMs, the Taco2 cell after both
 const StepOrder& step_order(const ttsdec_handle* h, int B);
+bool head_proj(const ttsdec_handle* h, int B);
 int lstm_prec(const ttsdec_handle* h) {
   return (h->precision == TTSDEC_PREC_SPLIT_F16 && split_ok(h->d) && h->wmax_dec < kSplitMax) ? 1 : 0;
 }
@@ -577,7 +580,12 @@ void launch_node(const ttsdec_handle* h, const StepBufs& sb, const StepIo& io, N
       launch_gemm(g, A_PLAIN, EPI_PLAIN, st);
       break;
     }
+    case N_JFA:
+    case N_JFIN:
     case N_J: {
+      // N_J: at the end of step t (buffer parity p).  N_JFA: the same GEMM for step t-1, at the head of step t's launch -
+      // step t-1's outputs are this step's "previous" buffers.  N_JFIN: io.slot carries the last step's parity.
+      const int p = node == N_JFA ? 1 - ((io.use_ctrl ? io.slot : io.t) & 1) : ((io.use_ctrl ? io.slot : io.t) & 1);
       GemmArgs g;
       memset(&g, 0, sizeof(g));
       // projection input: cat[h_dec, ctx] (Prod, decoder_cell.py:192) or cat[h0, h1, zeros] (Taco2, :136)
@@ -602,7 +610,15 @@ void launch_node(const ttsdec_handle* h, const StepBufs& sb, const StepIo& io, N
         pa.a = g.a; pa.a_lo = g.a_lo; pa.W = g.W; pa.W_lo = g.W_lo; pa.ldw = g.ldw; pa.prec = g.prec;
         pa.M = B; pa.N = g.N; pa.K = g.K; pa.ksplit = proj_parts(h, prec); pa.split_stride = (size_t)B * proj_ldp(d);
         pa.out = sb.jparts; pa.ldo = proj_ldp(d); pa.ctrl = ctrl; pa.slot = io.slot;
-        launch_proj(pa, st);
+        pa.mode = node == N_JFA ? PROJ_HEAD : (node == N_JFIN ? PROJ_FINAL : PROJ_STEP);
+        if (node == N_JFA) {
+          FrameArgs f = frame_args(false);
+          f.dep_signal = 1;
+          f.wait_n = proj_grid_size(pa.M, pa.N, pa.ksplit);
+          launch_proj_frame_lstm(pa, f, lstm_args(0, PART_GATED), st);
+        } else {
+          launch_proj(pa, st);
+        }
         break;
       }
       if (use_frame(d)) {
@@ -629,6 +645,9 @@ const StepOrder kOrderProdF = {6, {N_F, N_A, N_Q, N_T, N_D, N_J}, {"prenet", "ls
 const StepOrder kOrderTaco2F = {6, {N_F, N_A, N_D, N_Q, N_T, N_J}, {"prenet", "lstm_att", "lstm_dec", "query", "attention", "proj"}};
 const StepOrder kOrderProdO = {5, {N_FA, N_Q, N_T, N_D, N_J}, {"prenet+lstm_att", "query", "attention", "lstm_dec", "proj"}};
 const StepOrder kOrderProdO2 = {4, {N_FA, N_Q, N_TD, N_J}, {"prenet+lstm_att", "query", "attention+lstm_dec", "proj"}};
+// ... with step t-1's projection at the head of step t's first launch
+const StepOrder kOrderProdH = {4, {N_JFA, N_Q, N_T, N_D}, {"proj+prenet+lstm_att", "query", "attention", "lstm_dec"}};
+const StepOrder kOrderProdH2 = {3, {N_JFA, N_Q, N_TD}, {"proj+prenet+lstm_att", "query", "attention+lstm_dec"}};
 // the two-role step: LJSpeech-type cell, either arithmetic mode
 int overlap_level(const ttsdec_handle* h, int B) {
   const ttsdec_dims& d = h->d;
@@ -641,9 +660,19 @@ int overlap_level(const ttsdec_handle* h, int B) {
   // 105.2 / 115.1, B = 192 141.9 / 129.7 / 119.2, B = 256 143.2 / 138.1 / 127.3 (profiles/r02_h_levels.txt)
   return B <= 32 ? 2 : (B >= 192 ? 2 : 0);
 }
+// The projection as the head role of the next step's frame launch, wherever the register-weight kernel applies (split-fp16).
+// us per step without / with it, same box: B = 1 43.0 / 39.8, B = 64 51.8 / 50.1, B = 128 54.2 / 53.5, B = 256 73.4 / 73.3 (there
+// the frame role's chain is what the launch waits for, and it grows by what the projection's own launch cost).
+bool head_proj(const ttsdec_handle* h, int B) {
+  if (!overlap_level(h, B) || !proj_regw(h, lstm_prec(h))) return false;
+  return h->head_proj != 0;  // (-1 = default = on)
+}
 const StepOrder& step_order(const ttsdec_handle* h, int B) {
   const ttsdec_dims& d = h->d;
-  if (const int lv = overlap_level(h, B)) return lv >= 2 ? kOrderProdO2 : kOrderProdO;
+  if (const int lv = overlap_level(h, B)) {
+    if (head_proj(h, B)) return lv >= 2 ? kOrderProdH2 : kOrderProdH;
+    return lv >= 2 ? kOrderProdO2 : kOrderProdO;
+  }
   if (use_frame(d)) return is_taco2(d) ? kOrderTaco2F : kOrderProdF;
   return is_taco2(d) ? kOrderTaco2 : kOrderProd;
 }
@@ -754,6 +783,8 @@ int ttsdec_create(const ttsdec_dims* dims, ttsdec_handle** out) {
   h->chunk_b = !(e5 && !atoi(e5));
   const char* e6 = getenv("TTSDEC_PROJ_REGW");
   h->proj_regw = !(e6 && !atoi(e6));
+  const char* e7 = getenv("TTSDEC_HEAD_PROJ");
+  h->head_proj = e7 ? atoi(e7) : -1;
   h->device = current_device_or_minus1();
   *out = h;
   return TTSDEC_OK;
@@ -992,6 +1023,10 @@ int ttsdec_decode(ttsdec_handle* h, const float* memory, int B, int L, int t_beg
       io.slot = i;
       launch_step_serial(h, sb, io, st);
     }
+  }
+  if (head_proj(h, B) && n_steps > 0) {  // (that step order leaves each step's projection to the NEXT step's launch)
+    io.slot = (n_steps - 1) & 1;        // buffer parity of the call's last step (t_begin is even)
+    launch_node(h, sb, io, N_JFIN, st);
   }
   if (use_frame(d)) launch_node(h, sb, io, N_FIN, st);  // the last step's frame: y, s, stop rule, next input
   launch_finish(sb.ctrl, T_out, st);
@@ -1286,7 +1321,7 @@ int ttsdec_profile_step(ttsdec_handle* h, const float* memory, int B, int L, int
   const char* names[kMaxKernelsPerStep + 4];
   int nn = 0;
   for (int k = 0; k < order.n; ++k) { nodes[nn] = order.nodes[k]; names[nn++] = order.names[k]; }
-  if ((&order == &kOrderProdO || &order == &kOrderProdO2) && n_out >= order.n + 4) {
+  if ((&order == &kOrderProdO || &order == &kOrderProdO2 || &order == &kOrderProdH || &order == &kOrderProdH2) && n_out >= order.n + 4) {
     const Node extra[4] = {N_F, N_AG, N_T, N_DG};
     const char* extra_names[4] = {"prenet(alone)", "lstm_att_lean(alone)", "attention(alone)", "lstm_dec_lean(alone)"};
     for (int k = 0; k < 4; ++k) { nodes[nn] = extra[k]; names[nn++] = extra_names[k]; }

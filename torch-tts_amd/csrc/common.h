@@ -44,9 +44,11 @@ struct Ctrl {
   // Two-role launches (fused_kernels.hip): arrival counters of the producer roles, zeroed at the start of every
   // ttsdec_decode call; after step t of the call they read (t - t_call + 1) * (producer workgroups per step).
   unsigned int dep_frame, dep_attn;
+  // ... and of the projection role at the head of the frame launch: after step t of the call (t - t_call) * (its workgroups)
+  unsigned int dep_proj;
   // measurement only (TTSDEC_STAMPS=1): per-workgroup wall-clock stamps of the two-role launches, else nullptr
   unsigned long long* stamps;
-  int pad[27];
+  int pad[26];
 };
 // stamps[(kind * 1024 + block) * 8 + k]; kind 0 = frame || lstm_att, 1 = attention || lstm_dec;
 // k: 0 = role << 32 | HW_ID, 1 = XCC_ID, 2 = start, 3 = gate reached, 4 = gate passed, 5 = end (s_memrealtime, 10 ns units)

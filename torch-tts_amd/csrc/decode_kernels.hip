@@ -537,6 +537,7 @@ __global__ void set_call_kernel(Ctrl* c, CallArgs a) {
   c->w = a.w;
   c->dep_frame = 0;
   c->dep_attn = 0;
+  c->dep_proj = 0;
   c->stamps = a.stamps;
 }
 void launch_set_call(Ctrl* ctrl, const CallArgs& a, hipStream_t st) {

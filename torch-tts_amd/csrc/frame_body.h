@@ -40,7 +40,9 @@ struct FrameLds {
 // (bx, by): column block / row block of this workgroup.
 // kLean: for launches whose register budget is 128 (two workgroups per CU): the layer-1 weight fragments are requested
 // after layer 0's MFMAs instead of at kernel entry - 32 registers fewer across phase F and layer 0.
-template <int K0H, int PH, int PREC, int NI = kFrameMaxNI, bool kLean = false>
+// kHead: the partial sums come from a projection ROLE at the head of this very launch (FrameArgs::wait_n workgroups): they are
+// requested once that role's arrival counter is complete, after the control block has been read, instead of first thing.
+template <int K0H, int PH, int PREC, int NI = kFrameMaxNI, bool kLean = false, bool kHead = false>
 __device__ __forceinline__ void frame_body(FrameArgs g, float* lds, int bx, int by) {
   using LD = FrameLds<K0H, PH, PREC>;
   constexpr bool F16 = PREC == PREC_F16S;
@@ -113,28 +115,31 @@ __device__ __forceinline__ void frame_body(FrameArgs g, float* lds, int bx, int 
   // load per branch)
   constexpr int kMaxParts = 4;
   float pv[NI];
-  if (g.parts != nullptr) {
-    float pz[NI][kMaxParts], pbias[NI];
+  auto load_parts = [&]() {
+    if (g.parts != nullptr) {
+      float pz[NI][kMaxParts], pbias[NI];
 #pragma unroll
-    for (int i = 0; i < NI; ++i) {
-      const int n = (tid & 15) + 16 * i;
-      const bool ok = fm < g.M && n < NJ;
-      const size_t idx = ok ? (size_t)fm * g.ldp + n : 0;
+      for (int i = 0; i < NI; ++i) {
+        const int n = (tid & 15) + 16 * i;
+        const bool ok = fm < g.M && n < NJ;
+        const size_t idx = ok ? (size_t)fm * g.ldp + n : 0;
 #pragma unroll
-      for (int z = 0; z < kMaxParts; ++z) pz[i][z] = g.parts[z * g.part_stride + idx];
-      pbias[i] = g.proj_bias[ok ? n : 0];
+        for (int z = 0; z < kMaxParts; ++z) pz[i][z] = g.parts[z * g.part_stride + idx];
+        pbias[i] = g.proj_bias[ok ? n : 0];
+      }
+#pragma unroll
+      for (int i = 0; i < NI; ++i) {
+        float v = pz[i][0];
+#pragma unroll
+        for (int z = 1; z < kMaxParts; ++z) v = add_rn(v, z < g.n_parts ? pz[i][z] : 0.f);
+        pv[i] = add_rn(v, pbias[i]);
+      }
+    } else {
+#pragma unroll
+      for (int i = 0; i < NI; ++i) pv[i] = 0.f;
     }
-#pragma unroll
-    for (int i = 0; i < NI; ++i) {
-      float v = pz[i][0];
-#pragma unroll
-      for (int z = 1; z < kMaxParts; ++z) v = add_rn(v, z < g.n_parts ? pz[i][z] : 0.f);
-      pv[i] = add_rn(v, pbias[i]);
-    }
-  } else {
-#pragma unroll
-    for (int i = 0; i < NI; ++i) pv[i] = 0.f;
-  }
+  };
+  if constexpr (!kHead) load_parts();
 
   // ---- "now" ----
   int t = g.t, t_rel = g.t_rel, finalize = g.finalize;
@@ -168,6 +173,14 @@ __device__ __forceinline__ void frame_body(FrameArgs g, float* lds, int bx, int 
     g.check_stop = c->check_stop;
   }
 
+  if constexpr (kHead) {
+    if (finalize && g.wait_n > 0 && g.ctrl != nullptr) {
+      // step t-1's projection is complete when (t - t_call) steps x wait_n workgroups have signalled
+      if (wave == 0) role_wait(&g.ctrl->dep_proj, (unsigned int)t_rel * (unsigned int)g.wait_n, g.ctrl);
+      lds_barrier();
+    }
+    load_parts();
+  }
   const stamp_ptr st = g.dep_signal ? stamps_of(g.ctrl) : (stamp_ptr) nullptr;  // measurement only (TTSDEC_STAMPS)
   if (tid == 0) {  // role 0 of launch kind 0
     stamp(st, 0, 0, __builtin_amdgcn_s_getreg((4 << 0) | (0 << 6) | (31 << 11)));
@@ -477,6 +490,127 @@ __device__ __forceinline__ void frame_body(FrameArgs g, float* lds, int bx, int 
     role_signal(&g.ctrl->dep_frame);  // the attention LSTM of this launch waits for x_pre
     if (tid == 0) stamp(st, 0, 5, now_rt());
   }
+}
+
+
+// ===========================================================================
+// mel/stop projection [fc_mel; fc_stop] (decoder.py:52-53) as split-K partial sums for the frame kernel (kernels.h ProjArgs)
+// ===========================================================================
+constexpr int kProjTile = 32;  // rows and columns of a workgroup's output tile
+constexpr int kProjNS = 4;     // k16 steps per wave at most
+
+// address of element (row, k) of a segmented activation operand with EB-byte elements
+template <int EB>
+__device__ __forceinline__ gbyte* seg_elem_ptr(const Seg3& s, int row, int k) {
+  const int i = k < s.e0 ? 0 : (k < s.e1 ? 1 : 2);
+  const int kk = k - (i == 0 ? 0 : (i == 1 ? s.e0 : s.e1));
+  gbyte* p = seg_row_ptr<EB>(s, row, i);
+  return p + (s.mpad > 0 ? (long)(kk >> 5) * s.mpad * kChunkBytes + (long)(kk & 31) * EB : (long)kk * EB);
+}
+
+constexpr int kProjLdsFloats = 8 * 32 * 33;
+// red: kProjLdsFloats floats of LDS (the caller's ONE shared array); id: index of the workgroup within the kernel or role
+template <int PREC>
+__device__ __forceinline__ void proj_body(ProjArgs g, float* red, int id) {
+  constexpr bool F16 = PREC == PREC_F16S;
+  constexpr int EB = F16 ? 2 : 4, RS = 33;
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, l32 = lane & 31, half = lane >> 5;
+  const int nx = (g.N + kProjTile - 1) / kProjTile, ny = (g.M + kProjTile - 1) / kProjTile;
+  const int n0 = (id % nx) * kProjTile, m0 = ((id / nx) % ny) * kProjTile, z = id / (nx * ny);
+  const int spw = g.K / (128 * g.ksplit);  // k16 steps per wave, <= kProjNS
+  // this lane's K run: slice z, the wave's share of it, the lane half's half of that - 8 * spw consecutive k
+  const int kbeg = ((z * 8 + wave) * 2 + half) * spw * 8;
+
+  // ---- weights: independent of everything, requested first ----
+  f16x8 wh[F16 ? kProjNS : 1], wl[F16 ? kProjNS : 1];
+  f32x4 wf[F16 ? 1 : 2 * kProjNS];
+  {
+    const int n = n0 + l32 < g.N ? n0 + l32 : 0;
+    const size_t o = ((size_t)n * g.ldw + kbeg) * EB;
+    if constexpr (F16) {
+      gf16x8 *sh = (gf16x8*)(as_global(g.W) + o), *sl = (gf16x8*)(as_global(g.W_lo) + o);
+#pragma unroll
+      for (int j = 0; j < kProjNS; ++j)
+        if (j < spw) { wh[j] = sh[j]; wl[j] = sl[j]; }
+    } else {
+      gf32x4* sf = (gf32x4*)(as_global(g.W) + o);
+#pragma unroll
+      for (int j = 0; j < 2 * kProjNS; ++j)
+        if (j < 2 * spw) wf[j] = sf[j];
+    }
+  }
+  bool signal = false;
+  if (g.ctrl != nullptr) {
+    const Ctrl* c = g.ctrl;
+    const int t = c->t_cur + g.slot;
+    bool live;
+    // (PROJ_HEAD: the frame role of the same launch may lower stop_t to t-1 while this is read; t-1 <= stop_t cannot be
+    // changed by that - see lstm_body's live_lag)
+    if (g.mode == PROJ_HEAD) live = t < c->t_end && t - 1 <= c->stop_t && t > c->t_call;
+    else if (g.mode == PROJ_FINAL) live = c->t_end > c->t_call && c->t_end - 1 <= c->stop_t;
+    else live = t < c->t_end && t <= c->stop_t;
+    if (!live) return;
+    signal = g.mode == PROJ_HEAD;
+  }
+
+  // ---- activations: row m0 + l32, the same K run (A and W only have to agree on which k a lane element means) ----
+  f32x16 acc = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+  {
+    const int m = m0 + l32 < g.M ? m0 + l32 : g.M - 1;
+    if constexpr (F16) {
+      f16x8 ah[kProjNS], al[kProjNS];
+#pragma unroll
+      for (int j = 0; j < kProjNS; ++j)
+        if (j < spw) {
+          ah[j] = *(gf16x8*)seg_elem_ptr<2>(g.a, m, kbeg + 8 * j);
+          al[j] = *(gf16x8*)seg_elem_ptr<2>(g.a_lo, m, kbeg + 8 * j);
+        }
+      f32x16 acc2 = acc;
+#pragma unroll
+      for (int j = 0; j < kProjNS; ++j)
+        if (j < spw) {
+          acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[j], wh[j], acc, 0, 0, 0);
+          acc2 = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[j], wl[j], acc2, 0, 0, 0);
+          acc2 = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[j], wh[j], acc2, 0, 0, 0);
+        }
+#pragma unroll
+      for (int i = 0; i < 16; ++i) acc[i] = fmaf(acc2[i], 1.0f / kSplitScale, acc[i]);
+    } else {
+      f32x4 af[2 * kProjNS];
+#pragma unroll
+      for (int j = 0; j < 2 * kProjNS; ++j)
+        if (j < 2 * spw) af[j] = *(gf32x4*)seg_elem_ptr<4>(g.a, m, kbeg + 4 * j);
+#pragma unroll
+      for (int j = 0; j < 2 * kProjNS; ++j)
+        if (j < 2 * spw) {
+#pragma unroll
+          for (int e = 0; e < 4; ++e) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(af[j][e], wf[j][e], acc, 0, 0, 0);
+        }
+    }
+  }
+
+  // ---- the 8 waves' partial tiles, added in wave order (deterministic) ----
+  {
+    float* out = red + wave * 32 * RS;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) out[((r & 3) + 8 * (r >> 2) + 4 * half) * RS + l32] = acc[r];
+  }
+  __syncthreads();
+  float* slab = g.out + (size_t)z * g.split_stride;
+#pragma unroll
+  for (int j = 0; j < 2; ++j) {
+    const int e = tid + j * kFrameThreads;
+    const int row = e >> 5, col = e & 31;
+    const int m = m0 + row, n = n0 + col;
+    if (m >= g.M || n >= g.N) continue;
+    const float* pr = red + row * RS + col;
+    float v = pr[0];
+#pragma unroll
+    for (int w = 1; w < 8; ++w) v = add_rn(v, pr[w * 32 * RS]);
+    if (signal) store_wt(slab + (size_t)m * g.ldo + n, v);  // read by the frame role of this very launch
+    else slab[(size_t)m * g.ldo + n] = v;
+  }
+  if (signal) role_signal(&g.ctrl->dep_proj);
 }
 
 

@@ -20,6 +20,8 @@
 // Measured alternatives: the same overlap as two STREAMS (round 1: slower - cross-stream graph
 // edges, one 128-KiB workgroup per CU); the early segments as a separate partial-sum launch beside role A plus
 // a "late" launch (round 2: 86.4 vs 88.3 us per step - the extra launch costs what the overlap wins).
+#include <string.h>
+
 #include "frame_body.h"
 #include "step_bodies.h"
 
@@ -59,14 +61,27 @@ constexpr int cmax() { return A > B ? A : B; }
 
 // ---- role A = frame kernel (finish proj(t-1), PreNet), role B = early part of the attention LSTM ----
 // WPE: waves per SIMD the register budget must allow (4 = two 512-thread workgroups per CU, 2 = one)
-template <int K0H, int PH, class Cfg, int WPE>
-__global__ __launch_bounds__(kGemmThreads, WPE) void frame_lstm_kernel(FrameArgs f, LstmArgs l, int n_frame, int frame_cols, int lstm_cols) {
+// kHead: the launch starts with the previous step's mel/stop projection as a third role, [proj(t-1) | frame | lstm_att] by
+// block id.  Every role waits only for roles with LOWER ids and the grid dispatches in id order, so whatever a workgroup
+// waits for is resident or done.  The frame role has slack for it at large batches (it ends at 10.8 us where the LSTM
+// reaches its gate at 14.2, B = 256): the projection's 5.8-us launch disappears from the step.
+template <int K0H, int PH, class Cfg, int WPE, bool kHead>
+__global__ __launch_bounds__(kGemmThreads, WPE) void frame_lstm_kernel(FrameArgs f, LstmArgs l, ProjArgs pj, int n_proj, int n_frame, int frame_cols,
+                                                                       int lstm_cols) {
   constexpr int PREC = Cfg::kPrec;
-  __shared__ __attribute__((aligned(16))) float smem[cmax<Cfg::kLdsFloats, FrameLds<K0H, PH, PREC>::kFloats>()];
-  const int id = blockIdx.x;
+  __shared__ __attribute__((aligned(16))) float smem[cmax<cmax<Cfg::kLdsFloats, FrameLds<K0H, PH, PREC>::kFloats>(), kHead ? kProjLdsFloats : 1>()];
+  int id = blockIdx.x;
+  if constexpr (kHead) {
+    if (id < n_proj) {
+      __builtin_amdgcn_s_setprio(3);
+      proj_body<PREC>(pj, smem, id);
+      return;
+    }
+    id -= n_proj;
+  }
   if (id < n_frame) {
     __builtin_amdgcn_s_setprio(3);  // the producer role is the launch's critical path: it wins issue arbitration
-    frame_body<K0H, PH, PREC, 6, WPE == 4>(f, smem, id % frame_cols, id / frame_cols);
+    frame_body<K0H, PH, PREC, 6, WPE == 4, kHead>(f, smem, id % frame_cols, id / frame_cols);
   } else {
     const int j = id - n_frame;
     lstm_body<Cfg, true, true>(l, smem, j % lstm_cols, j / lstm_cols);
@@ -110,25 +125,35 @@ static LeanKind lean_kind(int M, int n_producer, int H) {
   return M <= kLean8MaxRows ? LEAN_64x8 : LEAN_64x16;
 }
 
-template <int K0H, int PH, int PREC>
-static void launch_frame_lstm_ph(const FrameArgs& f, const LstmArgs& l, hipStream_t st) {
+template <int K0H, int PH, int PREC, bool kHead>
+static void launch_frame_lstm_ph(const FrameArgs& f, const LstmArgs& l, const ProjArgs& pj, hipStream_t st) {
   using TL = LeanTiles<PREC>;
   const int fcols = (f.P + kFrameCols - 1) / kFrameCols, frows = (f.M + kFrameRows - 1) / kFrameRows;
-  const int n_frame = fcols * frows;
-  const LeanKind kind = lean_kind(l.M, n_frame, l.H);
+  const int n_frame = fcols * frows, n_proj = kHead ? proj_grid_size(pj.M, pj.N, pj.ksplit) : 0;
+  const LeanKind kind = lean_kind(l.M, n_proj + n_frame, l.H);
   const int lcols = kind == LEAN_64x16 ? (l.H + 15) / 16 : (l.H + 7) / 8;
   const int lrows = kind == SMALL_FAT ? (l.M + 31) / 32 : (l.M + 63) / 64;
-  dim3 grid(n_frame + lcols * lrows), block(kGemmThreads);
-  if (kind == SMALL_FAT) hipLaunchKernelGGL((frame_lstm_kernel<K0H, PH, typename TL::SmallFat, 2>), grid, block, 0, st, f, l, n_frame, fcols, lcols);
-  else if (kind == LEAN_64x8) hipLaunchKernelGGL((frame_lstm_kernel<K0H, PH, typename TL::Lean64x8, 4>), grid, block, 0, st, f, l, n_frame, fcols, lcols);
-  else hipLaunchKernelGGL((frame_lstm_kernel<K0H, PH, typename TL::Lean64x16, 4>), grid, block, 0, st, f, l, n_frame, fcols, lcols);
+  dim3 grid(n_proj + n_frame + lcols * lrows), block(kGemmThreads);
+  if (kind == SMALL_FAT)
+    hipLaunchKernelGGL((frame_lstm_kernel<K0H, PH, typename TL::SmallFat, 2, kHead>), grid, block, 0, st, f, l, pj, n_proj, n_frame, fcols, lcols);
+  else if (kind == LEAN_64x8)
+    hipLaunchKernelGGL((frame_lstm_kernel<K0H, PH, typename TL::Lean64x8, 4, kHead>), grid, block, 0, st, f, l, pj, n_proj, n_frame, fcols, lcols);
+  else
+    hipLaunchKernelGGL((frame_lstm_kernel<K0H, PH, typename TL::Lean64x16, 4, kHead>), grid, block, 0, st, f, l, pj, n_proj, n_frame, fcols, lcols);
 }
-void launch_frame_lstm(const FrameArgs& f, const LstmArgs& l, hipStream_t st) {
+template <bool kHead>
+static void launch_frame_lstm_any(const FrameArgs& f, const LstmArgs& l, const ProjArgs& pj, hipStream_t st) {
   if (f.M <= 0) return;
   const bool f16 = l.prec == 1;
-  if (f.Ph == 256) { if (f16) launch_frame_lstm_ph<40, 256, PREC_F16S>(f, l, st); else launch_frame_lstm_ph<40, 256, PREC_F32>(f, l, st); }
-  else { if (f16) launch_frame_lstm_ph<40, 128, PREC_F16S>(f, l, st); else launch_frame_lstm_ph<40, 128, PREC_F32>(f, l, st); }
+  if (f.Ph == 256) { if (f16) launch_frame_lstm_ph<40, 256, PREC_F16S, kHead>(f, l, pj, st); else launch_frame_lstm_ph<40, 256, PREC_F32, kHead>(f, l, pj, st); }
+  else { if (f16) launch_frame_lstm_ph<40, 128, PREC_F16S, kHead>(f, l, pj, st); else launch_frame_lstm_ph<40, 128, PREC_F32, kHead>(f, l, pj, st); }
 }
+void launch_frame_lstm(const FrameArgs& f, const LstmArgs& l, hipStream_t st) {
+  ProjArgs none;
+  memset(&none, 0, sizeof(none));
+  launch_frame_lstm_any<false>(f, l, none, st);
+}
+void launch_proj_frame_lstm(const ProjArgs& pj, const FrameArgs& f, const LstmArgs& l, hipStream_t st) { launch_frame_lstm_any<true>(f, l, pj, st); }
 
 template <int NJ, int PREC>
 static void launch_attn_lstm_nj(const AttnArgs& a, const LstmArgs& l, hipStream_t st) {

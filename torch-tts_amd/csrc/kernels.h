@@ -174,6 +174,7 @@ struct FrameArgs {
   int t;    // ctrl == nullptr
   int dbg;  // measurement ablations (ttsdec_profile_step only): bit 1 = no layer-0 MFMAs, bit 2 = no layer-1 MFMAs
   int dep_signal;  // 1: two-role launch - every workgroup signals Ctrl::dep_frame after its last store
+  int wait_n;      // > 0: the partial sums come from wait_n projection-role workgroups at the head of this very launch (Ctrl::dep_proj)
 };
 bool frame_supported(int d_mel, int r, int Ph, int P);
 void launch_frame(const FrameArgs& a, hipStream_t st);
@@ -192,9 +193,15 @@ struct ProjArgs {
   size_t split_stride;
   float* out;
   int ldo;
-  Ctrl* ctrl;            // != nullptr: the launch does nothing unless step ctrl->t_cur + slot is live
+  Ctrl* ctrl;            // != nullptr: the launch does nothing unless its step is live (see mode)
   int slot;
+  // mode 0: a launch of its own at the end of step t = ctrl->t_cur + slot.  mode 1 (PROJ_HEAD): a ROLE at the head of step t's
+  // frame launch, computing step t-1's projection - live like that launch's finalize phase (t-1 <= stop_t, t > t_call) - whose
+  // slabs are stored write-through and signalled through Ctrl::dep_proj.  mode 2 (PROJ_FINAL): the projection of the call's
+  // last step, a launch of its own in front of the end-of-call frame launch.
+  int mode;
 };
+enum ProjMode { PROJ_STEP = 0, PROJ_HEAD = 1, PROJ_FINAL = 2 };
 int proj_split(int K);  // the ksplit of this kernel for K, or 0 when it does not cover K
 void launch_proj(const ProjArgs& a, hipStream_t st);
 
@@ -204,6 +211,9 @@ void launch_proj(const ProjArgs& a, hipStream_t st);
 bool fused_supported(int d_mel, int r, int Ph, int P, int D);
 int frame_grid_size(int M, int P);                                              // workgroups of the frame role
 void launch_frame_lstm(const FrameArgs& f, const LstmArgs& l, hipStream_t st);  // frame kernel || attention LSTM
+// ... with the previous step's mel/stop projection as a role at its head: proj(t-1) -> frame(t) || lstm_att(t)
+void launch_proj_frame_lstm(const ProjArgs& pj, const FrameArgs& f, const LstmArgs& l, hipStream_t st);
+int proj_grid_size(int M, int N, int ksplit);  // workgroups of the projection kernel / role
 void launch_attn_lstm(const AttnArgs& a, const LstmArgs& l, hipStream_t st);    // attention || decoder LSTM
 void launch_lstm_lean(const LstmArgs& l, hipStream_t st);                       // an LSTM on the lean tile alone (profiling)
 
