@@ -13,6 +13,7 @@
 
 #include <new>
 #include <string>
+#include <type_traits>
 
 #include "kernels.h"
 
@@ -311,189 +312,280 @@ __global__ __launch_bounds__(kMhaThreads) void mha_kernel(MhaArgs g) {
 //           (a lane holds a contiguous half of its row's dk values: the K index of an fp32 MFMA may
 //           be permuted freely as long as A and B agree); relative-key logits R = Q E_k^T the same way
 //   softmax over the rows of S in LDS
-//   pass 2: out[32, dk] = P V: P from LDS, V rows from global (lanes along d: coalesced), keys split
-//           over the waves, partial tiles reduced through LDS in wave order
+//   pass 2: out[32, dk] = P V: P from LDS, V from global (a lane owns NDT ADJACENT output columns, so its
+//           values of one key are one load), keys split over the waves, partial tiles reduced through LDS
+//           in wave order
+// How the loads and the instruction stream are arranged (tools/ubench_mha.hip has the shipped-before
+// kernel next to this one, pass by pass; profiles/r02_j_ubench_mha.txt the numbers):
+//  * every global load a wave needs before its first use is requested up front (Q, the row masks, the first K tiles with
+//    their key masks, E_k, E_v); barriers that only order LDS do not drain the vector-memory queue
+//  * pass 1: DK1 key tiles in flight per wave, the key's mask value travels with its tile (a global load inside the tile's
+//    epilogue would wait for every prefetched tile behind it: one in-order queue)
+//  * softmax: the 8 rows of a wave side by side
+//  * pass 2: DV groups of V values in flight per wave
+//  * E_v staged in LDS for the output loop
 constexpr int kMhaMRows = 32, kMhaMThreads = 256;
 template <int DKH>  // dk / 2 (a multiple of 4)
-__global__ __launch_bounds__(kMhaMThreads) void mha_mfma_kernel(MhaArgs g) {
-  constexpr int DK = 2 * DKH, NDT = (DK + 31) / 32;
+__global__ __launch_bounds__(kMhaMThreads, 2) void mha_mfma_kernel(MhaArgs g) {
+  constexpr int DK = 2 * DKH, NDT = (DK + 31) / 32, NQ = DKH / 4;
+  constexpr int DK1 = DKH > 24 ? 2 : 4, DV = DKH > 24 ? 2 : 4, G = 8;  // tiles / groups in flight per wave
+  constexpr int NEV = (31 * DK + kMhaMThreads - 1) / kMhaMThreads;  // E_v values per thread (window <= 15)
   extern __shared__ __attribute__((aligned(16))) float sm[];
   const int T = g.T, C = g.C, w = g.window;
-  const int ST = T | 1;                    // odd row stride: the 32 rows of a column hit 32 banks
-  float* S = sm;                           // [32][ST]   (aliased by the pass-2 reduction buffer)
-  float* R = S + kMhaMRows * ST;           // [32][33] relative-key logits (windowed attention only)
+  const int ST = T | 1;
+  float* S = sm;
+  float* R = S + kMhaMRows * ST;
   const int nrel = w >= 0 ? 2 * w + 1 : 0;
-  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, l32 = lane & 31, half = lane >> 5;
+  const int tid = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63, l32 = lane & 31, half = lane >> 5;
   const int b = blockIdx.z, hd = blockIdx.y, i0 = blockIdx.x * kMhaMRows;
   const size_t rowb = (size_t)b * T;
   const float* base = g.qkv + rowb * 3 * C + hd * DK;
   typedef __attribute__((address_space(1))) const f32x4 gf32x4;
+  typedef __attribute__((address_space(1))) const float gf32;
+  gf32* maskg = (gf32*)(g.mask + rowb);
+  const int ntile = (T + 31) / 32;
 
-  // A fragments of Q (scaled): row i0 + l32, k in [half*DKH, +DKH)
-  f32x4 qa[DKH / 4];
+  f32x4 qa[NQ];
   {
     const int i = i0 + l32 < T ? i0 + l32 : T - 1;
     gf32x4* src = (gf32x4*)(base + (size_t)i * 3 * C + half * DKH);
 #pragma unroll
-    for (int j = 0; j < DKH / 4; ++j) {
-      f32x4 v = src[j];
-#pragma unroll
-      for (int e = 0; e < 4; ++e) v[e] = div_rn(v[e], g.qscale);
-      qa[j] = v;
-    }
+    for (int j = 0; j < NQ; ++j) qa[j] = src[j];
   }
-  // relative-key logits: R[i][r] = q_i . E_k[r]   (wave 0; rows r >= nrel of the B operand are zero)
+  f32x4 e4[NQ];
   if (w >= 0 && wave == 0) {
-    f32x16 acc = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-    for (int j = 0; j < DKH / 4; ++j) {
-      f32x4 e4 = {0.f, 0.f, 0.f, 0.f};
-      if (l32 < nrel) e4 = *reinterpret_cast<const f32x4*>(g.ek + (size_t)l32 * DK + half * DKH + 4 * j);
-#pragma unroll
-      for (int e = 0; e < 4; ++e) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(qa[j][e], e4[e], acc, 0, 0, 0);
+    for (int j = 0; j < NQ; ++j) {
+      e4[j] = f32x4{0.f, 0.f, 0.f, 0.f};
+      if (l32 < nrel) e4[j] = *(gf32x4*)(g.ek + (size_t)l32 * DK + half * DKH + 4 * j);
     }
-#pragma unroll
-    for (int r = 0; r < 16; ++r) R[((r & 3) + 8 * (r >> 2) + 4 * half) * 33 + l32] = acc[r];
   }
-  __syncthreads();
-  // ---- pass 1: scores, 32 keys per tile, tiles round-robin over the waves; the next tile's K
-  // fragments are requested before the current tile's MFMAs ----
-  const int ntile = (T + 31) / 32;
-  auto load_k = [&](int kt, f32x4 (&kb)[DKH / 4]) {
-    const int j = kt * 32 + l32;
-    gf32x4* src = (gf32x4*)(base + (size_t)(j < T ? j : T - 1) * 3 * C + C + half * DKH);
-#pragma unroll
-    for (int q = 0; q < DKH / 4; ++q) kb[q] = src[q];
-  };
-  float mrow[16];  // frame mask of the 16 query rows this lane's accumulator registers belong to
+  float mrow[16];
 #pragma unroll
   for (int r = 0; r < 16; ++r) {
     const int i = i0 + (r & 3) + 8 * (r >> 2) + 4 * half;
-    mrow[r] = i < T ? g.mask[rowb + i] : 0.f;
+    mrow[r] = i < T ? maskg[i] : 0.f;
   }
-  auto score_tile = [&](int kt, const f32x4 (&kb)[DKH / 4]) {
+  f32x4 kb[DK1][NQ];
+  float mj[DK1];
+  auto load_k = [&](int kt, int u) {
+    const int j = kt * 32 + l32, jc = j < T ? j : T - 1;
+    gf32x4* src = (gf32x4*)(base + (size_t)jc * 3 * C + C + half * DKH);
+#pragma unroll
+    for (int q = 0; q < NQ; ++q) kb[u][q] = src[q];
+    mj[u] = maskg[jc];
+  };
+#pragma unroll
+  for (int u = 0; u < DK1; ++u) load_k(wave + 4 * u, u);  // past the last tile: the clamped row again (no branch, so the
+                                                           // compiler can count the loads in flight exactly)
+  float evr[NEV];
+#pragma unroll
+  for (int q = 0; q < NEV; ++q) {
+    const int e = tid + q * kMhaMThreads;
+    evr[q] = (w >= 0 && e < nrel * DK) ? ((gf32*)g.ev)[e] : 0.f;
+  }
+#pragma unroll
+  for (int j = 0; j < NQ; ++j)
+#pragma unroll
+    for (int e = 0; e < 4; ++e) qa[j][e] = div_rn(qa[j][e], g.qscale);
+  if (w >= 0 && wave == 0) {
+    f32x16 acc = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int j = 0; j < NQ; ++j)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(qa[j][e], e4[j][e], acc, 0, 0, 0);
+#pragma unroll
+    for (int r = 0; r < 16; ++r) R[((r & 3) + 8 * (r >> 2) + 4 * half) * 33 + l32] = acc[r];
+  }
+  lds_barrier();
+  // ---- pass 1 ----
+  auto score_tile = [&](int kt, int u) {
     const int j = kt * 32 + l32;
     f32x16 acc = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-    for (int q = 0; q < DKH / 4; ++q)
+    for (int q = 0; q < NQ; ++q)
 #pragma unroll
-      for (int e = 0; e < 4; ++e) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(qa[q][e], kb[q][e], acc, 0, 0, 0);
+      for (int e = 0; e < 4; ++e) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(qa[q][e], kb[u][q][e], acc, 0, 0, 0);
     if (j < T) {
-      const float mj = g.mask[rowb + j];
+      const float mjv = mj[u];
+      float* sj = S + j;
+      // does any (query, key) pair of this tile lie inside the relative window?  (the same answer in every lane)
+      const bool near = w >= 0 && kt * 32 + 31 + w >= i0 && kt * 32 <= i0 + 31 + w;
+      if (near) {
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int row = (r & 3) + 8 * (r >> 2) + 4 * half;
-        const int i = i0 + row;
-        float s = acc[r];
-        const int rr = j - i + w;
-        if (w >= 0 && rr >= 0 && rr <= 2 * w) s = add_rn(s, R[row * 33 + rr]);
-        if (mrow[r] * mj == 0.f) s = -1e4f;
-        S[row * ST + j] = s;
+        for (int r = 0; r < 16; ++r) {
+          const int row = (r & 3) + 8 * (r >> 2) + 4 * half;
+          float s = acc[r];
+          const int rr = j - (i0 + row) + w;
+          if (rr >= 0 && rr <= 2 * w) s = add_rn(s, R[row * 33 + rr]);
+          if (mrow[r] * mjv == 0.f) s = -1e4f;
+          sj[row * ST] = s;
+        }
+      } else {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int row = (r & 3) + 8 * (r >> 2) + 4 * half;
+          sj[row * ST] = mrow[r] * mjv == 0.f ? -1e4f : acc[r];
+        }
       }
     }
   };
+  for (int kt0 = wave; kt0 < ntile; kt0 += 4 * DK1) {
+#pragma unroll
+    for (int u = 0; u < DK1; ++u) {
+      const int kt = kt0 + 4 * u;
+      if (kt < ntile) score_tile(kt, u);
+      load_k(kt + 4 * DK1, u);
+    }
+  }
+  lds_barrier();
+  // ---- softmax numerators, the wave's 8 rows side by side ----
+  float* rinv = S + kMhaMRows * ST + (w >= 0 ? 32 * 33 : 0);
   {
-    f32x4 kb0[DKH / 4], kb1[DKH / 4];
-    if (wave < ntile) load_k(wave, kb0);
-    for (int kt = wave; kt < ntile; kt += 8) {
-      if (kt + 4 < ntile) load_k(kt + 4, kb1);
-      score_tile(kt, kb0);
-      if (kt + 4 < ntile) {
-        if (kt + 8 < ntile) load_k(kt + 8, kb0);
-        score_tile(kt + 4, kb1);
+    float* row0 = S + (wave * 8) * ST;
+    float mx[8], sum[8];
+#pragma unroll
+    for (int q = 0; q < 8; ++q) mx[q] = -3.4e38f, sum[q] = 0.f;
+    for (int j = lane; j < T; j += 64)
+#pragma unroll
+      for (int q = 0; q < 8; ++q) mx[q] = fmaxf(mx[q], row0[q * ST + j]);
+#pragma unroll
+    for (int q = 0; q < 8; ++q) mx[q] = wave_max(mx[q]);
+    for (int j = lane; j < T; j += 64)
+#pragma unroll
+      for (int q = 0; q < 8; ++q) {
+        const float e = __expf(row0[q * ST + j] - mx[q]);
+        row0[q * ST + j] = e;
+        sum[q] += e;
       }
-    }
+#pragma unroll
+    for (int q = 0; q < 8; ++q) sum[q] = wave_sum(sum[q]);
+    if (lane == 0)
+#pragma unroll
+      for (int q = 0; q < 8; ++q) rinv[wave * 8 + q] = 1.0f / sum[q];
   }
-  __syncthreads();
-  // ---- softmax numerators: wave v owns rows 8v .. 8v+7.  S keeps e = exp(s - max); the division by the
-  // row sum is applied once to the 32 x dk output instead of to the 32 x T scores ----
-  float* rinv = S + kMhaMRows * ST + (w >= 0 ? 32 * 33 : 0);  // [32] 1 / row sum
-  for (int rr = 0; rr < 8; ++rr) {
-    float* row = S + (wave * 8 + rr) * ST;
-    float mx = -3.4e38f;
-    for (int j = lane; j < T; j += 64) mx = fmaxf(mx, row[j]);
-    mx = wave_max(mx);
-    float sum = 0.f;
-    for (int j = lane; j < T; j += 64) {
-      const float e = __expf(row[j] - mx);
-      row[j] = e;
-      sum += e;
-    }
-    sum = wave_sum(sum);
-    if (lane == 0) rinv[wave * 8 + rr] = 1.0f / sum;
-  }
-  __syncthreads();
-  // ---- pass 2: out = P V; wave v takes the key pairs {v, v+4, v+8, ...} ----
+  lds_barrier();
+  // ---- pass 2 ----
   f32x16 acc[NDT];
 #pragma unroll
   for (int dt = 0; dt < NDT; ++dt) acc[dt] = f32x16{0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
   {
-    const float* vb = base + 2 * C;
+    gf32* vb = (gf32*)(base + 2 * C);
     const float* prow = S + l32 * ST;
     const int npair = (T + 1) / 2;
-    constexpr int G = 8;  // key pairs whose V values are requested together (latency paid once per group)
-    for (int p0 = wave * G; p0 < npair; p0 += 4 * G) {
-      float pv[G], vv[G][NDT];
+    struct VN { float v[NDT]; };  // DK % NDT == 0 for the built sizes: a lane's columns are all inside or all outside
+    static_assert(DK % NDT == 0, "");
+    float pv[DV][G], vv[DV][G][NDT];
+    // one key pair of a group: its P value (LDS) and the lane's NDT adjacent V values (one global load)
+    // lanes whose columns lie past DK read column 0 instead: their accumulators are never stored
+    gf32* vlane = vb + (NDT * l32 < DK ? NDT * l32 : 0) + (size_t)half * 3 * C;
+    const float* plane = prow + half;
+    auto load_1 = [&](int p0, int s, int u) {
+      if (2 * (p0 + G) <= T) {  // every key of the group exists (the same answer in all lanes): no predicates
+        pv[s][u] = plane[2 * (p0 + u)];
+        gf32* vk = vlane + (size_t)(2 * (p0 + u)) * 3 * C;
 #pragma unroll
-      for (int u = 0; u < G; ++u) {
+        for (int dt = 0; dt < NDT; ++dt) vv[s][u][dt] = vk[dt];
+      } else {
         const int key = 2 * (p0 + u) + half;
         const bool ok = key < T;
-        pv[u] = ok ? prow[key] : 0.f;
+        const int kc = ok ? key : T - 1;
+        const float pl = prow[kc];
+        gf32* vk = vlane + (size_t)(kc - half) * 3 * C;
+        pv[s][u] = ok ? pl : 0.f;
 #pragma unroll
         for (int dt = 0; dt < NDT; ++dt) {
-          const int d = dt * 32 + l32;
-          vv[u][dt] = (ok && d < DK) ? vb[(size_t)key * 3 * C + d] : 0.f;
+          const float vl = vk[dt];
+          vv[s][u][dt] = ok ? vl : 0.f;
         }
       }
+    };
 #pragma unroll
-      for (int u = 0; u < G; ++u)
+    for (int s = 0; s < DV; ++s)
+      if (wave * G + s * 4 * G < npair) {
 #pragma unroll
-        for (int dt = 0; dt < NDT; ++dt) acc[dt] = __builtin_amdgcn_mfma_f32_32x32x2f32(pv[u], vv[u][dt], acc[dt], 0, 0, 0);
-    }
-  }
-  // relative values need p[i, i + r - w]: read them (and the row's 1/sum) before S is reused as the reduction buffer
-  const int oi = tid >> 3;  // output row of this thread in the final loop (32 rows x 8 threads)
-  const float ri = rinv[oi];
-  float prel[32];
-#pragma unroll
-  for (int r = 0; r < 32; ++r) {
-    const int j = i0 + oi + r - w;
-    prel[r] = (w >= 0 && r < nrel && j >= 0 && j < T) ? S[oi * ST + j] : 0.f;
-  }
-  __syncthreads();
-  float* red = S;  // [4 waves][32][DK + 1]
-  constexpr int RS = DK + 1;
-#pragma unroll
-  for (int dt = 0; dt < NDT; ++dt) {
-    const int d = dt * 32 + l32;
-    if (d < DK) {
-#pragma unroll
-      for (int r = 0; r < 16; ++r) red[(wave * 32 + (r & 3) + 8 * (r >> 2) + 4 * half) * RS + d] = acc[dt][r];
-    }
-  }
-  __syncthreads();
-  if (i0 + oi < T) {
-    for (int d = tid & 7; d < DK; d += 8) {
-      float v = red[oi * RS + d];
-#pragma unroll
-      for (int q = 1; q < 4; ++q) v = add_rn(v, red[(q * 32 + oi) * RS + d]);
-      if (w >= 0) {
-        float a = 0.f;
-#pragma unroll
-        for (int r = 0; r < 32; ++r)
-          if (r < nrel) a = fmaf(prel[r], g.ev[(size_t)r * DK + d], a);
-        v = add_rn(v, a);
+        for (int u = 0; u < G; ++u) load_1(wave * G + s * 4 * G, s, u);
       }
-      const size_t o = (rowb + i0 + oi) * C + hd * DK + d;
-      g.out[o] = v * ri;
-      if (g.out_p) split_f16(v * ri, g.out_p[o], g.out_p[g.n_out + o]);
+    for (int pb = wave * G; pb < npair; pb += DV * 4 * G) {
+#pragma unroll
+      for (int s = 0; s < DV; ++s) {
+        const int p0 = pb + s * 4 * G;
+        if (p0 < npair) {
+          const bool more = p0 + DV * 4 * G < npair;
+          // the slot's next key pair is requested right behind the MFMAs that consumed the old one, so the address
+          // arithmetic runs while the matrix pipe is busy instead of after the whole group
+#pragma unroll
+          for (int u = 0; u < G; ++u) {
+#pragma unroll
+            for (int dt = 0; dt < NDT; ++dt) acc[dt] = __builtin_amdgcn_mfma_f32_32x32x2f32(pv[s][u], vv[s][u][dt], acc[dt], 0, 0, 0);
+            if (more) load_1(p0 + DV * 4 * G, s, u);
+          }
+        }
+      }
     }
   }
+  // relative values need p[i, i + r - w]: read them (and the row's 1/sum) before S is reused as the reduction buffer.
+  // NR: compile-time bound on the window rows (9 covers the reference's window_size = 4)
+  auto finish = [&](auto nr_c) {
+    constexpr int NR = decltype(nr_c)::value;
+    const int oi = tid >> 3;  // output row of this thread (32 rows x 8 threads)
+    const float ri = rinv[oi];
+    float prel[NR];
+#pragma unroll
+    for (int r = 0; r < NR; ++r) {
+      const int j = i0 + oi + r - w;
+      prel[r] = (r < nrel && j >= 0 && j < T) ? S[oi * ST + j] : 0.f;
+    }
+    lds_barrier();
+    float* red = S;  // [4 waves][32][DK + 1], then E_v [nrel][DK]
+    constexpr int RS = DK + 1;
+    float* evs = red + 4 * 32 * RS;
+#pragma unroll
+    for (int dt = 0; dt < NDT; ++dt) {
+      const int d = NDT * l32 + dt;
+      if (d < DK) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) red[(wave * 32 + (r & 3) + 8 * (r >> 2) + 4 * half) * RS + d] = acc[dt][r];
+      }
+    }
+#pragma unroll
+    for (int q = 0; q < NEV; ++q) {
+      const int e = tid + q * kMhaMThreads;
+      if (e < nrel * DK) evs[e] = evr[q];
+    }
+    lds_barrier();
+    if (i0 + oi < T) {
+      const float* rp = red + oi * RS + (tid & 7);
+      const float* ep = evs + (tid & 7);
+      float* op = g.out + (rowb + i0 + oi) * C + hd * DK + (tid & 7);
+#pragma unroll
+      for (int d0 = 0; d0 < DK; d0 += 8) {
+        float v = rp[d0];
+#pragma unroll
+        for (int q = 1; q < 4; ++q) v = add_rn(v, rp[q * 32 * RS + d0]);
+        if (NR > 0 && w >= 0) {
+          float a = 0.f;
+#pragma unroll
+          for (int r = 0; r < NR; ++r)
+            if (r < nrel) a = fmaf(prel[r], ep[r * DK + d0], a);
+          v = add_rn(v, a);
+        }
+        op[d0] = v * ri;
+        if (g.out_p) {
+          const size_t o = (size_t)(op - g.out) + d0;
+          split_f16(v * ri, g.out_p[o], g.out_p[g.n_out + o]);
+        }
+      }
+    }
+  };
+  if (nrel <= 9) finish(std::integral_constant<int, 9>{});
+  else finish(std::integral_constant<int, 31>{});
 }
+
 size_t mha_mfma_lds_bytes(int T, int dk, int window) {
   const size_t rel = (window >= 0 ? 32 * 33 : 0) + 32;  // relative-key logits, 1 / row sums
   const size_t s = (size_t)kMhaMRows * (T | 1) + rel;
-  const size_t red = (size_t)4 * 32 * (dk + 1);
+  const size_t red = (size_t)4 * 32 * (dk + 1) + (size_t)(window >= 0 ? 2 * window + 1 : 0) * dk;  // partial tiles, E_v
   return (s > red ? s : red) * sizeof(float);
 }
 
