@@ -203,12 +203,20 @@ __global__ __launch_bounds__(kGemmThreads) void gemm_rows_kernel(GemmArgs g) {
   const size_t o_step = (size_t)(kGemmThreads / BN) * g.ldo;
   const int okind = g.out_kind;
   bool over = false;
+  // A tile that lies wholly inside the matrix (all but the last row / column of tiles) takes a copy of the loop without the
+  // per-element bounds test: with the test every output is its own basic block - LDS read, wait, arithmetic, stores, one
+  // after the other, 32 times; without it the compiler batches the reads and overlaps the stores.
+  auto emit = [&](auto whole_c) {
+  constexpr bool kWholeTile = decltype(whole_c)::value;
+  float vals[EPT];
 #pragma unroll
   for (int j = 0; j < EPT; ++j) {
     const int e = threadIdx.x + j * kGemmThreads;
     const int row = e / BN, col = e % BN;
     const int m = m0 + row, n = n0 + col;
-    if (m >= g.M || n >= g.N) continue;
+    if constexpr (!kWholeTile) {
+      if (m >= g.M || n >= g.N) continue;
+    }
     const size_t o = kColConst ? o_first + (size_t)j * o_step : (size_t)m * g.ldo + n;
     float v = smem[row * LDO + col];
     float pb, pr, prm;
@@ -220,13 +228,7 @@ __global__ __launch_bounds__(kGemmThreads) void gemm_rows_kernel(GemmArgs g) {
       if (EK == EPI_RELU_DROPOUT && g.dropout_mode == TTSDEC_DROPOUT_MASKS) pm = as_g(g.masks)[(size_t)m * g.N + n];
     } else load_epi(m, n, true, pb, pr, prm, pm);
     if (EK != EPI_BN_ISRU && EK != EPI_BN_LRELU && EK != EPI_BN_ISRLU && g.bias != nullptr) v = add_rn(v, pb);
-    auto store16 = [&](float val) {  // 16-bit copies for a following 16-bit GEMM
-      if (okind == 1) {
-        split_f16_flag(val, g.out_h[o], g.out_l[o], over);  // (saturating; reported once, below)
-      } else if (okind == 2) {
-        reinterpret_cast<bf16*>(g.out_h)[o] = (bf16)val;
-      }
-    };
+    auto store16 = [&](float val) { vals[j] = val; };  // 16-bit copies for a following 16-bit GEMM: second loop, below
     if (EK == EPI_PLAIN) {
       g.out[o] = v;
       store16(v);
@@ -284,6 +286,26 @@ __global__ __launch_bounds__(kGemmThreads) void gemm_rows_kernel(GemmArgs g) {
       store16(v);
     }
   }
+  // the 16-bit copies in a loop of their own per kind: the kind is the same for every output, and tested per output it cut
+  // the loop above into one basic block per element
+  if constexpr (EK != EPI_PROJ) {
+    auto each = [&](auto&& f) {
+#pragma unroll
+      for (int j = 0; j < EPT; ++j) {
+        const int e = threadIdx.x + j * kGemmThreads;
+        const int m = m0 + e / BN, n = n0 + e % BN;
+        if constexpr (!kWholeTile) {
+          if (m >= g.M || n >= g.N) continue;
+        }
+        f(kColConst ? o_first + (size_t)j * o_step : (size_t)m * g.ldo + n, vals[j]);
+      }
+    };
+    if (okind == 1) each([&](size_t o, float val) { split_f16_flag(val, g.out_h[o], g.out_l[o], over); });  // (saturating; reported once, below)
+    else if (okind == 2) each([&](size_t o, float val) { reinterpret_cast<bf16*>(g.out_h)[o] = (bf16)val; });
+  }
+  };
+  if (kColConst && m0 + BM <= g.M && n0 + BN <= g.N) emit(std::true_type{});
+  else emit(std::false_type{});
   report_range(over, g.ctrl);
 }
 

@@ -619,6 +619,68 @@ __global__ void wn_update_kernel(float* x, float* output, const float* rs, const
     output[i] = add_rn(o, rs[m * 2 * H + H + c]);
   }
 }
+// The same two kernels, four channels per thread (H % 4 == 0, fewer than 2^32 elements): 16-byte loads and stores, 8-byte
+// plane stores, one 32-bit division per four elements instead of a 64-bit one per element.  As one-element kernels they
+// were bound by their instruction streams (the division; tanhf + expf + an exact division per gate: ~100 instructions per
+// element), not by the 59 / 103 MB they stream.  kFast (the split-fp16 mode, whose GEMMs round these values to 22 bits
+// anyway): the gate on the hardware exp / rcp like the decoder's LSTM cell (common.h tanh_fast / sigmoid_fast); the
+// exact-fp32 mode keeps the library functions.
+typedef _Float16 f16x4v __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ void split4_store(const f32x4& v, f16* planes, size_t n, size_t i4) {
+  f16x4v hi, lo;
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    f16 h, l;
+    split_f16(v[e], h, l);
+    hi[e] = h;
+    lo[e] = l;
+  }
+  *reinterpret_cast<f16x4v*>(planes + 4 * i4) = hi;
+  *reinterpret_cast<f16x4v*>(planes + n + 4 * i4) = lo;
+}
+template <bool kFast>
+__global__ void wn_gate4_kernel(const float* xin, float* acts, f16* acts_p, uint32_t M, uint32_t H4) {
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= M * H4) return;
+  const uint32_t m = i / H4, c4 = i - m * H4;
+  const f32x4* row = reinterpret_cast<const f32x4*>(xin) + (size_t)m * 2 * H4;
+  const f32x4 a = row[c4], s = row[H4 + c4];
+  f32x4 v;
+#pragma unroll
+  for (int e = 0; e < 4; ++e) v[e] = kFast ? mul_rn(tanh_fast(a[e]), sigmoid_fast(s[e])) : mul_rn(tanhf(a[e]), sigmoid_f(s[e]));
+  reinterpret_cast<f32x4*>(acts)[i] = v;
+  if (acts_p) split4_store(v, acts_p, (size_t)M * H4 * 4, i);
+}
+__global__ void wn_update4_kernel(float* x, float* output, const float* rs, const float* mask, f16* x_p, f16* out_p, uint32_t M, uint32_t H4,
+                                  int last, int first) {
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= M * H4) return;
+  const uint32_t m = i / H4, c4 = i - m * H4;
+  const size_t n = (size_t)M * H4 * 4;
+  const float mk = mask[m];
+  f32x4 o = {0.f, 0.f, 0.f, 0.f};
+  if (!first) o = reinterpret_cast<const f32x4*>(output)[i];
+  f32x4 v;
+  if (last) {
+    const f32x4 r = reinterpret_cast<const f32x4*>(rs)[(size_t)m * H4 + c4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) v[e] = mul_rn(add_rn(o[e], r[e]), mk);
+    reinterpret_cast<f32x4*>(output)[i] = v;
+    if (out_p) split4_store(v, out_p, n, i);
+  } else {
+    const f32x4* row = reinterpret_cast<const f32x4*>(rs) + (size_t)m * 2 * H4;
+    const f32x4 r0 = row[c4], r1 = row[H4 + c4], xv = reinterpret_cast<const f32x4*>(x)[i];
+    f32x4 on;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      v[e] = mul_rn(add_rn(xv[e], r0[e]), mk);
+      on[e] = add_rn(o[e], r1[e]);
+    }
+    reinterpret_cast<f32x4*>(x)[i] = v;
+    if (x_p) split4_store(v, x_p, n, i);
+    reinterpret_cast<f32x4*>(output)[i] = on;
+  }
+}
 // modules.Flip (modules.py:374-381) + split: xf = flip(x); x0m = xf[:, :half] * mask
 __global__ void flip_split_kernel(const float* x, const float* mask, float* xf, float* x0m, f16* x0m_p, int M, int I) {
   const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -1006,10 +1068,14 @@ int ttsvits_flow_reverse(ttsvits_handle* h, const float* z, const int32_t* lengt
       const bool last = j == d.flow_wn_layers - 1;
       gemm_generic(fcx, hx, hx_p, Fh, Fh, blob + fb.in_w[j], (size_t)2 * Fh * d.flow_kernel * Fh, blob + fb.in_b[j], M, 2 * Fh, xin, nullptr, 2 * Fh, 0,
                    nullptr, nullptr, d.flow_kernel, T, st);
-      hipLaunchKernelGGL(wn_gate_kernel, grid1((size_t)M * Fh), dim3(256), 0, st, xin, acts, acts_p, M, Fh);
+      const bool vec4 = Fh % 4 == 0 && (size_t)M * Fh < ((size_t)1 << 32);
+      if (vec4 && fcx.split) hipLaunchKernelGGL(wn_gate4_kernel<true>, grid1((size_t)M * Fh / 4), dim3(256), 0, st, xin, acts, acts_p, (uint32_t)M, (uint32_t)Fh / 4);
+      else if (vec4) hipLaunchKernelGGL(wn_gate4_kernel<false>, grid1((size_t)M * Fh / 4), dim3(256), 0, st, xin, acts, acts_p, (uint32_t)M, (uint32_t)Fh / 4);
+      else hipLaunchKernelGGL(wn_gate_kernel, grid1((size_t)M * Fh), dim3(256), 0, st, xin, acts, acts_p, M, Fh);
       const int cr = last ? Fh : 2 * Fh;
       gemm_generic(fcx, acts, acts_p, Fh, Fh, blob + fb.rs_w[j], (size_t)cr * Fh, blob + fb.rs_b[j], M, cr, rs, nullptr, cr, 0, nullptr, nullptr, 1, T, st);
-      hipLaunchKernelGGL(wn_update_kernel, grid1((size_t)M * Fh), dim3(256), 0, st, hx, ho, rs, mask, hx_p, ho_p, M, Fh, last ? 1 : 0, j == 0 ? 1 : 0);
+      if (vec4) hipLaunchKernelGGL(wn_update4_kernel, grid1((size_t)M * Fh / 4), dim3(256), 0, st, hx, ho, rs, mask, hx_p, ho_p, (uint32_t)M, (uint32_t)Fh / 4, last ? 1 : 0, j == 0 ? 1 : 0);
+      else hipLaunchKernelGGL(wn_update_kernel, grid1((size_t)M * Fh), dim3(256), 0, st, hx, ho, rs, mask, hx_p, ho_p, M, Fh, last ? 1 : 0, j == 0 ? 1 : 0);
     }
     // m = post(h) * mask ; x1 = (x1 - m) * mask                                     :517, 529
     gemm_generic(fcx, ho, ho_p, Fh, Fh, blob + fb.post_w, (size_t)half * Fh, blob + fb.post_b, M, half, mm, nullptr, half, 0, mask, nullptr, 1, T, st);
