@@ -304,7 +304,7 @@ __global__ __launch_bounds__(kGemmThreads) void gemm_rows_kernel(GemmArgs g) {
     else if (okind == 2) each([&](size_t o, float val) { reinterpret_cast<bf16*>(g.out_h)[o] = (bf16)val; });
   }
   };
-  if (kColConst && m0 + BM <= g.M && n0 + BN <= g.N) emit(std::true_type{});
+  if (m0 + BM <= g.M && n0 + BN <= g.N) emit(std::true_type{});
   else emit(std::false_type{});
   report_range(over, g.ctrl);
 }

@@ -715,6 +715,49 @@ __global__ void couple_kernel(float* xf, const float* mm, const float* mask, int
   float* p = xf + m * I + half + c;
   *p = mul_rn(mul_rn(sub_rn(*p, mm[i]), 1.0f), mask[m]);
 }
+// flip+split, x0 residual and the coupling update, four channels per thread (I % 8 == 0, fewer than 2^32 elements)
+__global__ void flip_split4_kernel(const float* x, const float* mask, float* xf, float* x0m, f16* x0m_p, uint32_t M, uint32_t I4) {
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= M * I4) return;
+  const uint32_t m = i / I4, c4 = i - m * I4, half4 = I4 / 2;
+  const f32x4 s = reinterpret_cast<const f32x4*>(x)[(size_t)m * I4 + (I4 - 1 - c4)];
+  const f32x4 v = {s[3], s[2], s[1], s[0]};
+  reinterpret_cast<f32x4*>(xf)[i] = v;
+  if (c4 < half4) {
+    const float mk = mask[m];
+    f32x4 vm;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) vm[e] = mul_rn(v[e], mk);
+    const size_t o = (size_t)m * half4 + c4;
+    reinterpret_cast<f32x4*>(x0m)[o] = vm;
+    if (x0m_p) split4_store(vm, x0m_p, (size_t)M * half4 * 4, o);
+  }
+}
+__global__ void add_x04_kernel(float* enc, f16* enc_p, const float* xf, uint32_t M, uint32_t I4) {
+  const uint32_t half4 = I4 / 2;
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= M * half4) return;
+  const uint32_t m = i / half4, c4 = i - m * half4;
+  const f32x4 a = reinterpret_cast<const f32x4*>(enc)[i], b = reinterpret_cast<const f32x4*>(xf)[(size_t)m * I4 + c4];
+  f32x4 v;
+#pragma unroll
+  for (int e = 0; e < 4; ++e) v[e] = add_rn(a[e], b[e]);
+  reinterpret_cast<f32x4*>(enc)[i] = v;
+  if (enc_p) split4_store(v, enc_p, (size_t)M * half4 * 4, i);
+}
+__global__ void couple4_kernel(float* xf, const float* mm, const float* mask, uint32_t M, uint32_t I4) {
+  const uint32_t half4 = I4 / 2;
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= M * half4) return;
+  const uint32_t m = i / half4, c4 = i - m * half4;
+  f32x4* p = reinterpret_cast<f32x4*>(xf) + (size_t)m * I4 + half4 + c4;
+  const f32x4 a = *p, b = reinterpret_cast<const f32x4*>(mm)[i];
+  const float mk = mask[m];
+  f32x4 v;
+#pragma unroll
+  for (int e = 0; e < 4; ++e) v[e] = mul_rn(mul_rn(sub_rn(a[e], b[e]), 1.0f), mk);
+  *p = v;
+}
 __global__ void copy_f_kernel(const float* a, float* b, size_t n) {
   const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i < n) b[i] = a[i];
@@ -1056,11 +1099,14 @@ int ttsvits_flow_reverse(ttsvits_handle* h, const float* z, const int32_t* lengt
   const float* cur = z;
   for (int f = d.n_flows - 1; f >= 0; --f) {  // models.py:807-809: reversed(flows) = Flip, layer_f, ...
     const FlowBlob& fb = L.flow[f];
-    hipLaunchKernelGGL(flip_split_kernel, grid1((size_t)M * I), dim3(256), 0, st, cur, mask, xb, sw.xm, sw.xm_p, M, I);
+    const bool i4 = I % 8 == 0 && (size_t)M * I < ((size_t)1 << 32) && reinterpret_cast<uintptr_t>(cur) % 16 == 0;  // (cur may be the caller's z)
+    if (i4) hipLaunchKernelGGL(flip_split4_kernel, grid1((size_t)M * I / 4), dim3(256), 0, st, cur, mask, xb, sw.xm, sw.xm_p, (uint32_t)M, (uint32_t)I / 4);
+    else hipLaunchKernelGGL(flip_split_kernel, grid1((size_t)M * I), dim3(256), 0, st, cur, mask, xb, sw.xm, sw.xm_p, M, I);
     // x0_ = pre_transformer(x0 * mask, mask) + x0                                   models.py:508-509
     int rc = run_stack(h, fb.tf, sd, sw, mask, B, T, st);
     if (rc != TTSDEC_OK) return rc;
-    hipLaunchKernelGGL(add_x0_kernel, grid1((size_t)M * half), dim3(256), 0, st, sw.xm, sw.xm_p, xb, M, I);
+    if (i4) hipLaunchKernelGGL(add_x04_kernel, grid1((size_t)M * half / 4), dim3(256), 0, st, sw.xm, sw.xm_p, xb, (uint32_t)M, (uint32_t)I / 4);
+    else hipLaunchKernelGGL(add_x0_kernel, grid1((size_t)M * half), dim3(256), 0, st, sw.xm, sw.xm_p, xb, M, I);
     // h = pre(x0_) * mask                                                           :510
     gemm_generic(fcx, sw.xm, sw.xm_p, half, half, blob + fb.pre_w, (size_t)Fh * half, blob + fb.pre_b, M, Fh, hx, hx_p, Fh, 0, mask, nullptr, 1, T, st);
     // h = WN(h, mask)                                                               :511, modules.py:185-210
@@ -1079,7 +1125,8 @@ int ttsvits_flow_reverse(ttsvits_handle* h, const float* z, const int32_t* lengt
     }
     // m = post(h) * mask ; x1 = (x1 - m) * mask                                     :517, 529
     gemm_generic(fcx, ho, ho_p, Fh, Fh, blob + fb.post_w, (size_t)half * Fh, blob + fb.post_b, M, half, mm, nullptr, half, 0, mask, nullptr, 1, T, st);
-    hipLaunchKernelGGL(couple_kernel, grid1((size_t)M * half), dim3(256), 0, st, xb, mm, mask, M, I);
+    if (i4) hipLaunchKernelGGL(couple4_kernel, grid1((size_t)M * half / 4), dim3(256), 0, st, xb, mm, mask, (uint32_t)M, (uint32_t)I / 4);
+    else hipLaunchKernelGGL(couple_kernel, grid1((size_t)M * half), dim3(256), 0, st, xb, mm, mask, M, I);
     float* t = xa; xa = xb; xb = t;  // the coupled tensor becomes the next layer's input
     cur = xa;
   }
