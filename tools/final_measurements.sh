@@ -2,7 +2,7 @@
 # Runs on the GPU box (gpurun): the round's final numbers on the frozen sources.  Every rocprofv3 call has the program
 # itself after "--" and collects counters without any trace domain but --kernel-trace.
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
-O=gpurun_out/r2_final5
+O=gpurun_out/r2_final6
 mkdir -p $O
 timeout -k 10 600 python bench.py > $O/bench_default.json 2> $O/bench_default.err; echo "default rc=$?"
 timeout -k 10 300 python bench.py --batch 64 --no-cpu-baseline --no-extra-legs > $O/bench_batch64.json 2>/dev/null

@@ -58,7 +58,7 @@ struct LoaderW {
 };
 
 template <class Cfg, int AK, int EK>
-__global__ __launch_bounds__(kGemmThreads) void gemm_rows_kernel(GemmArgs g) {
+__global__ __launch_bounds__(kGemmThreads, Cfg::kWavesPerSimd) void gemm_rows_kernel(GemmArgs g) {
   bool live = true;
   if (g.ctrl != nullptr) {  // step kernel inside a decode call: "now" and the call's buffers come from *ctrl
     const Ctrl* c = g.ctrl;
@@ -329,6 +329,18 @@ static void launch_gemm_cfg(const GemmArgs& a, hipStream_t st) {
     // the Postnet at 256 x 600 frames.  Their 132-KiB output tile leaves one workgroup per CU where the 128x128 tile
     // fits two, and the second workgroup hides more latency than the bigger tile saves in staged bytes.)
     // large 16-bit GEMMs (Postnet convs): 128x128 tiles, half-depth stages (see TileCfg)
+    if constexpr (PREC == PREC_F16S && AK == A_PLAIN && EK == EPI_GENERIC) {
+      // short-K row GEMMs (the VITS2 1x1 convs, K = 192: six k32 tiles): the lean 64x64 tile, two workgroups per CU, so
+      // that one workgroup's loads and stores run beside the other's MFMAs - on the 128x128 tile these launches were
+      // 8.8 % MFMA-busy.  VITS2 pass 8.39 -> 8.25 ms (same box; TTSDEC_NO_LEAN_SKINNY=1 restores the big tile).
+      static const bool lean_skinny = getenv("TTSDEC_NO_LEAN_SKINNY") == nullptr;
+      if (lean_skinny && a.K <= 256 && a.M >= 2048) {
+        using Cfg = TileCfg<2, 2, 1, 4, PREC_F16S, 0, 1, 1, 1>;
+        dim3 grid((a.N + Cfg::BN - 1) / Cfg::BN, (a.M + Cfg::BM - 1) / Cfg::BM);
+        hipLaunchKernelGGL((gemm_rows_kernel<Cfg, AK, EK>), grid, dim3(kGemmThreads), 0, st, a);
+        return;
+      }
+    }
     if (a.N >= 128 && a.M >= 2048) {
       using Cfg = TileCfg<2, 2, 1, 4, PREC, 0, 2, 2, 1>;
       dim3 grid((a.N + Cfg::BN - 1) / Cfg::BN, (a.M + Cfg::BM - 1) / Cfg::BM);

@@ -57,6 +57,8 @@ struct TileCfg {
   static constexpr int NMW = WM * WN * WK;  // active MFMA waves (of the 4 in the workgroup)
   static constexpr int kWM = WM, kWN = WN, kWK = WK, kTM = TM, kTN = TN;
   static constexpr bool kBig = TM * TN > 1;
+  // waves per SIMD the register budget is set for: the lean tile is meant to run two 8-wave workgroups per CU (128 VGPRs)
+  static constexpr int kWavesPerSimd = (HK && TM * TN == 1) ? 4 : 2;
   static_assert(NMW == 4 || NMW == 2, "2 or 4 active MFMA waves per workgroup");
   static_assert(kBig || S >= 3, "ring needs at least 3 stages (fragment reads run one tile ahead of the MFMAs)");
   static_assert(!kBig || (PREC != PREC_F32 && WK == 1 && NMW == 4 && S >= 2), "big tiles: 16-bit modes, no intra-workgroup split-K");
