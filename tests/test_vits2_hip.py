@@ -72,7 +72,9 @@ def test_flow_reverse_golden(gv):
     _close(out, c["flow/out"], "flow out")
 
 
-@pytest.mark.parametrize("B,T,lengths", [(4, 120, [120, 77, 31, 1]), (2, 37, None)])
+# (T = 300: ten key tiles and nineteen value groups, so the dk = 96 attention kernel's rings of 2 tiles / 2 groups per wave are
+# refilled - at 120 tokens every wave's tiles fit the rings' first fill; T = 1000: the largest score tile that still fits LDS)
+@pytest.mark.parametrize("B,T,lengths", [(4, 120, [120, 77, 31, 1]), (2, 37, None), (2, 300, [300, 161]), (1, 1000, [983])])
 def test_text_encoder_default_dims_vs_oracle(B, T, lengths):
     d = V.Vits2Dims()
     wts = V.random_vits2_weights(d, seed=5)
