@@ -162,6 +162,37 @@ int ttsdec_destroy(ttsdec_handle* h);
 int ttsdec_set_precision(ttsdec_handle* h, int precision);
 int ttsdec_get_precision(const ttsdec_handle* h);
 
+/* Tuning and measurement options of a decoder handle.  The defaults (value -1) are the measured-best settings per batch size
+ * and arithmetic mode; nothing here changes results beyond the summation order of a GEMM's K segments (every setting is
+ * held to the same parity bar by tests/test_hip_parity.py::test_all_step_orders_and_layouts_vs_oracle).  Setting an
+ * option drops the handle's captured graph.  MEASUREMENT ONLY - not part of the drop-in surface.
+ * The environment variable TTSDEC_OPTIONS="name=value,name=value" (names below, lower case without the prefix) presets
+ * the options of every handle created afterwards; it is read once per ttsdec_create.  The only other environment
+ * variables the library reads, both measurement-only as well: TTSDEC_STAMPS=<file> (per-workgroup time stamps of the
+ * two-role launches of a decode call's last step, written to <file>; synchronises the stream) and
+ * TTSDEC_NO_LEAN_SKINNY=1 (short-K row GEMMs of the VITS2 path back on the 128 x 128 tile). */
+enum {
+  TTSDEC_OPT_GRAPH = 0,        /* "graph": 0 = launch every step kernel from the host instead of replaying a captured hipGraph  */
+  TTSDEC_OPT_OVERLAP,          /* "overlap": two-role launches 0 = none, 1 = frame || lstm_att, 2 = also attention || lstm_dec  */
+  TTSDEC_OPT_CHUNK_A,          /* "chunk_a": 0 = row-major fp16 activation planes instead of the chunked layout                */
+  TTSDEC_OPT_CHUNK_B,          /* "chunk_b": 0 = row-major LSTM weight planes                                                  */
+  TTSDEC_OPT_PROJ_REGW,        /* "proj_regw": 0 = mel/stop projection on the LDS-staged split-K GEMM                          */
+  TTSDEC_OPT_HEAD_PROJ,        /* "head_proj": 1 / 0 = that projection as a role at the head of the next step's first launch   */
+  TTSDEC_OPT_DEEP_RING,        /* "deep_ring": 1 = the lean LSTM tile refills its LDS ring one stage earlier                   */
+  TTSDEC_OPT_FILL_K,           /* "fill_k": K elements (multiple of 32) of the decoder LSTM's h_dec(t-1) segment contracted by
+                                * the attention LSTM's workgroups in the step's first launch; 0 = off                         */
+  TTSDEC_OPT_QUERY_REGW,       /* "query_regw": 1 = attention query GEMM on the register-weight kernel                         */
+  TTSDEC_OPT_PROFILE_ABLATION, /* "profile_ablation": ttsdec_profile_step only, kernel-internal ablation switches              */
+  TTSDEC_OPT_DEBUG_FLAGS,      /* "debug_flags": TEST HOOK. bit 0 / 1 / 2: the frame / attention / projection-head role of a
+                                * two-role launch does not signal its consumers, which then run into the bounded-spin
+                                * time-out (T_out[1] bit 2)                                                                   */
+  TTSDEC_OPT_SPIN_LIMIT,       /* "spin_limit": TEST HOOK. polls before a consumer role gives up (default 65536, ~30 ms)       */
+  TTSDEC_OPT_COUNT
+};
+int ttsdec_set_option(ttsdec_handle* h, int option, int value);
+int ttsdec_get_option(const ttsdec_handle* h, int option, int* value);
+const char* ttsdec_option_name(int option); /* NULL for an unknown option */
+
 /* Number of source tensors ttsdec_pack_weights expects for these dims. */
 int ttsdec_num_weight_tensors(const ttsdec_handle* h);
 /* Size of the packed weight blob (bytes, multiple of 256). */

@@ -1071,44 +1071,124 @@ def test_argument_rejection_through_the_c_abi(H):
 
 # --------------------------------------------------------------------------
 # every step order the library can run (the defaults pick one per batch size / mode; the rest are reachable through
-# the measurement switches read at handle creation) must give the reference's results
+# the tuning options of include/ttsdec.h, here preset through TTSDEC_OPTIONS, which every new handle reads) must give
+# the reference's results
 # --------------------------------------------------------------------------
-_STEP_SWITCHES = [
-    {}, {"TTSDEC_OVERLAP": "0"}, {"TTSDEC_OVERLAP": "1"}, {"TTSDEC_OVERLAP": "2"}, {"TTSDEC_NO_GRAPH": "1"},
-    {"TTSDEC_OVERLAP": "2", "TTSDEC_NO_GRAPH": "1"}, {"TTSDEC_CHUNK_A": "0"}, {"TTSDEC_CHUNK_B": "0"},
-    {"TTSDEC_CHUNK_A": "0", "TTSDEC_CHUNK_B": "0", "TTSDEC_OVERLAP": "2"}, {"TTSDEC_PROJ_REGW": "0"},
-    {"TTSDEC_HEAD_PROJ": "1"}, {"TTSDEC_HEAD_PROJ": "1", "TTSDEC_OVERLAP": "1"}, {"TTSDEC_HEAD_PROJ": "1", "TTSDEC_NO_GRAPH": "1"},
-    {"TTSDEC_HEAD_PROJ": "0"},
+_STEP_OPTIONS = [
+    {}, {"overlap": 0}, {"overlap": 1}, {"overlap": 2}, {"graph": 0},
+    {"overlap": 2, "graph": 0}, {"chunk_a": 0}, {"chunk_b": 0},
+    {"chunk_a": 0, "chunk_b": 0, "overlap": 2}, {"proj_regw": 0},
+    {"head_proj": 1}, {"head_proj": 1, "overlap": 1}, {"head_proj": 1, "graph": 0},
+    {"head_proj": 0},
+    {"deep_ring": 1}, {"deep_ring": 1, "overlap": 2, "graph": 0}, {"query_regw": 1}, {"query_regw": 1, "chunk_a": 0},
+    # the filler contraction (needs equal LSTM widths: the second dims below; elsewhere the option is inert)
+    {"fill_k": 64, "overlap": 2}, {"fill_k": 128, "overlap": 2}, {"fill_k": 96, "overlap": 2, "deep_ring": 1, "query_regw": 1},
+    {"fill_k": 128, "overlap": 2, "chunk_a": 0, "chunk_b": 0}, {"fill_k": 64, "overlap": 2, "head_proj": 0, "graph": 0},
 ]
 
 
 @pytest.mark.parametrize("prec", ["f32", "split_f16"])
-def test_all_step_orders_and_layouts_vs_oracle(H, prec, monkeypatch):
-    dims = O.DecoderDims(d_mel=80, d_pre=128, d_ctx=64, h_att=128, h_dec=192)  # (fused launches, chunked planes and the
-    wts = O.random_decoder_weights(dims, seed=21, nonzero_init_state=True)    #  register-weight projection all apply)
+@pytest.mark.parametrize("widths", [(128, 192), (128, 128)])
+def test_all_step_orders_and_layouts_vs_oracle(H, prec, widths, monkeypatch):
+    dims = O.DecoderDims(d_mel=80, d_pre=128, d_ctx=64, h_att=widths[0], h_dec=widths[1])  # (fused launches, chunked planes and the
+    wts = O.random_decoder_weights(dims, seed=21, nonzero_init_state=True)              #  register-weight projection all apply)
     T_ = 18  # >= 15 steps: the captured-graph path (unless switched off)
+    opts = [o for o in _STEP_OPTIONS if widths[0] == widths[1] or "fill_k" not in o]
+    if widths[0] == widths[1]:
+        opts = [o for o in opts if "fill_k" in o or not o or "deep_ring" in o or "query_regw" in o]
     for B in (3, 40, 70):  # stand-alone small tile / 64x8 lean tile / 64x16 lean tile of the two-role launches
         mem = O.synthetic_memory(B, 11, dims.d_ctx, lengths=[11] * (B - 1) + [4], seed=7)
         masks = O.synthetic_masks(T_, B, dims.d_pre, seed=9)
         oy, os_, ow = O.decode(wts, dims, mem, max_steps=T_ - 1, masks=masks)
-        for env in _STEP_SWITCHES:
+        for opt in opts:
             with monkeypatch.context() as mp:
-                for k, v in env.items():
-                    mp.setenv(k, v)
-                dec = H.make_decoder(dims, wts)  # a new module = a new handle, which reads the switches
+                mp.setenv("TTSDEC_OPTIONS", ",".join(f"{k}={v}" for k, v in opt.items()))
+                dec = H.make_decoder(dims, wts)  # a new module = a new handle, which reads the options
                 dec.precision = prec
+                eng = dec.engine(torch.device("cuda:0"))
+                for k, v in opt.items():
+                    assert eng.get_option(k) == v, (k, v)
                 y, s, w, fired = H.run_decoder_with_masks(dec, mem, masks, max_steps=T_ - 1)
-                if "TTSDEC_OVERLAP" in env and "TTSDEC_CHUNK_A" not in env:  # the switch really selects the launch sequence
+                if "overlap" in opt and "chunk_a" not in opt:  # the option really selects the launch sequence
                     from torch_tts_amd import _lib
-                    names = set(dec.engine(torch.device("cuda:0")).profile_step(mem.cuda(), 1, _lib.DROPOUT_OFF, None, 0))
-                    lv = int(env["TTSDEC_OVERLAP"])
+                    names = set(eng.profile_step(mem.cuda(), 1, _lib.DROPOUT_OFF, None, 0))
+                    lv = opt["overlap"]
                     fa = "prenet+lstm_att" in names or "proj+prenet+lstm_att" in names
-                    assert fa == (lv >= 1) and ("attention+lstm_dec" in names) == (lv >= 2), (env, names)
-                    if env.get("TTSDEC_HEAD_PROJ") == "1" and prec == "split_f16":
-                        assert "proj+prenet+lstm_att" in names and "proj" not in names, (env, names)
-            what = f"B={B} {prec} {env}"
+                    assert fa == (lv >= 1) and ("attention+lstm_dec" in names) == (lv >= 2), (opt, names)
+                    if opt.get("head_proj") == 1 and prec == "split_f16":
+                        assert "proj+prenet+lstm_att" in names and "proj" not in names, (opt, names)
+            what = f"B={B} {prec} {opt}"
             assert not fired and y.shape == oy.shape, what
             H.assert_close(y, oy, RTOL, ATOL, "y " + what)
             H.assert_close(s, os_, RTOL, ATOL, "s " + what)
             H.assert_close(w, ow, RTOL, ATOL, "w " + what)
             H.assert_argmax(w, ow, "argmax " + what)
+
+
+def test_set_option_on_a_live_handle_switches_the_launch_sequence(H):
+    """ttsdec_set_option between two calls on ONE handle (the captured graph is dropped): same results, other launches."""
+    from torch_tts_amd import _lib
+    dims = O.DecoderDims(d_mel=80, d_pre=128, d_ctx=64, h_att=128, h_dec=128)
+    wts = O.random_decoder_weights(dims, seed=4, nonzero_init_state=True)
+    B, T_ = 96, 20
+    mem = O.synthetic_memory(B, 9, dims.d_ctx, seed=3)
+    masks = O.synthetic_masks(T_, B, dims.d_pre, seed=5)
+    oy, os_, ow = O.decode(wts, dims, mem, max_steps=T_ - 1, masks=masks)
+    dec = H.make_decoder(dims, wts)
+    dec.precision = "split_f16"
+    eng = dec.engine(torch.device("cuda:0"))
+    seen = []
+    for opt in ({"overlap": 2, "fill_k": 0}, {"fill_k": 128}, {"fill_k": 64, "deep_ring": 1}, {"overlap": 0}, {"overlap": -1, "fill_k": -1, "deep_ring": -1}):
+        for k, v in opt.items():
+            eng.set_option(k, v)
+        y, s, w, fired = H.run_decoder_with_masks(dec, mem, masks, max_steps=T_ - 1)
+        seen.append(tuple(eng.profile_step(mem.cuda(), 1, _lib.DROPOUT_OFF, None, 0)))
+        H.assert_close(y, oy, RTOL, ATOL, f"y {opt}")
+        H.assert_argmax(w, ow, f"argmax {opt}")
+    assert "attention+lstm_dec" in seen[0] and "attention+lstm_dec" not in seen[3], seen
+    with pytest.raises(KeyError):
+        eng.set_option("no_such_option", 1)
+
+
+def test_role_timeout_flags_the_call_and_the_module_falls_back(H):
+    """The bounded spin of the two-role launches (common.h role_wait): a producer role that never signals (test hook
+    TTSDEC_OPT_DEBUG_FLAGS) makes the consumers give up - T_out[1] bit 2, the grid drains - and Decoder.forward does
+    not return that call's outputs: it switches the engine to one role per launch (option overlap = 0), warns and
+    repeats the call."""
+    from torch_tts_amd import _lib
+    dims = O.DecoderDims(d_mel=80, d_pre=128, d_ctx=64, h_att=128, h_dec=128)
+    wts = O.random_decoder_weights(dims, seed=4, nonzero_init_state=True)
+    B, T_ = 70, 4
+    mem = O.synthetic_memory(B, 9, dims.d_ctx, seed=3)
+    masks = O.synthetic_masks(T_, B, dims.d_pre, seed=5)
+    oy, os_, ow = O.decode(wts, dims, mem, max_steps=T_ - 1, masks=masks)
+    ny, ns, nw = O.decode(wts, dims, mem, max_steps=T_ - 1, dropout="off")
+    memd = mem.cuda()
+    for prec in ("f32", "split_f16"):
+        for bit in (1, 2, 4):  # the frame role / the attention role / the projection head role stays silent
+            if bit == 4 and prec == "f32":
+                continue  # (the head role exists in split-fp16 mode only)
+            dec = H.make_decoder(dims, wts)
+            dec.precision = prec
+            eng = dec.engine(torch.device("cuda:0"))
+            eng.set_option("overlap", 2)
+            eng.set_option("spin_limit", 64)
+            eng.set_option("debug_flags", bit)
+            y = torch.empty(B, T_, 80, device="cuda"); s = torch.empty(B, T_, device="cuda"); w = torch.empty(B, T_, 9, device="cuda")
+            t_out = torch.zeros(2, dtype=torch.int32, device="cuda")
+            eng.decode(memd, t_begin=0, n_steps=T_, stop_threshold=-2.0, check_stop=True, dropout_mode=_lib.DROPOUT_MASKS, masks=masks.cuda().contiguous(),
+                       seed=0, teacher=None, teacher_flags=None, y=y, s=s, w=w, t_out=t_out)
+            assert t_out.tolist()[1] & 4, (prec, bit, t_out.tolist())
+            dec.dropout_source = "off"
+            with pytest.warns(RuntimeWarning, match="producer role"), torch.no_grad():
+                y2, s2, w2 = dec(memd, None, None, max_steps=T_ - 1)
+            assert eng.get_option("overlap") == 0
+            H.assert_close(y2.cpu(), ny, RTOL, ATOL, f"y after the fallback ({prec}, bit {bit})")
+            H.assert_argmax(w2.cpu(), nw, "argmax after the fallback")
+            # the hook off again, two-role launches back on: the same handle decodes correctly
+            eng.set_option("debug_flags", 0)
+            eng.set_option("spin_limit", -1)
+            eng.set_option("overlap", 2)
+            y3, s3, w3, fired = H.run_decoder_with_masks(dec, mem, masks, max_steps=T_ - 1)
+            H.assert_close(y3, oy, RTOL, ATOL, "y after a timed-out call")
+            H.assert_argmax(w3, ow, "argmax after a timed-out call")

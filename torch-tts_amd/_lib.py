@@ -21,6 +21,17 @@ W_DECODER_COUNT = 21
 W_POSTNET_PER_LAYER = 5
 W_POSTNET2_PER_LAYER = 11
 
+
+def option_ids():
+    """name -> TTSDEC_OPT_* of the tuning / measurement options (include/ttsdec.h), as the library itself names them."""
+    lib, out, i = load(), {}, 0
+    while True:
+        n = lib.ttsdec_option_name(i)
+        if n is None:
+            return out
+        out[n.decode()] = i
+        i += 1
+
 # every symbol include/ttsdec.h declares
 SYMBOLS = (
     "ttsdec_version",
@@ -30,6 +41,9 @@ SYMBOLS = (
     "ttsdec_destroy",
     "ttsdec_set_precision",
     "ttsdec_get_precision",
+    "ttsdec_set_option",
+    "ttsdec_get_option",
+    "ttsdec_option_name",
     "ttsdec_num_weight_tensors",
     "ttsdec_packed_bytes",
     "ttsdec_pack_weights",
@@ -150,6 +164,12 @@ def load() -> C.CDLL:
         lib.ttsdec_set_precision.argtypes = [vp, i32]
         lib.ttsdec_get_precision.restype = i32
         lib.ttsdec_get_precision.argtypes = [vp]
+        lib.ttsdec_set_option.restype = i32
+        lib.ttsdec_set_option.argtypes = [vp, i32, i32]
+        lib.ttsdec_get_option.restype = i32
+        lib.ttsdec_get_option.argtypes = [vp, i32, C.POINTER(i32)]
+        lib.ttsdec_option_name.restype = C.c_char_p
+        lib.ttsdec_option_name.argtypes = [i32]
         lib.ttsdec_num_weight_tensors.restype = i32
         lib.ttsdec_num_weight_tensors.argtypes = [vp]
         lib.ttsdec_packed_bytes.restype = sz

@@ -55,14 +55,20 @@ def build(force: bool = False, verbose: bool = False) -> str:
     if not force and os.path.exists(LIB) and os.path.exists(stamp) and open(stamp).read().strip() == dig:
         return LIB
     hipcc = _hipcc()
-    objs = []
-    for src in SOURCES:
-        obj = os.path.join(LIBDIR, src.replace(".hip", ".o"))
+    objs = [os.path.join(LIBDIR, src.replace(".hip", ".o")) for src in SOURCES]
+
+    def compile_one(src, obj):
         cmd = [hipcc, *FLAGS, "-c", os.path.join(CSRC, src), "-o", obj]
         if verbose:
             print(" ".join(cmd), flush=True)
         subprocess.run(cmd, check=True)
-        objs.append(obj)
+
+    # the translation units are independent: one hipcc per source, side by side (each is itself single-threaded)
+    from concurrent.futures import ThreadPoolExecutor
+
+    with ThreadPoolExecutor(max_workers=min(len(SOURCES), os.cpu_count() or 1)) as pool:
+        for f in [pool.submit(compile_one, s, o) for s, o in zip(SOURCES, objs)]:
+            f.result()
     cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB, *objs]
     if verbose:
         print(" ".join(cmd), flush=True)

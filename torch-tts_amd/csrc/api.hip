@@ -76,18 +76,27 @@ struct ttsdec_handle {
   BlobLayout bl;
   const float* blob;
   std::string hip_err;
-  bool use_graph;   // replay a captured hipGraph instead of launching every kernel
+  bool use_graph;   // replay a captured hipGraph instead of launching every kernel (option "graph")
   // Two-role launches (fused_kernels.hip) where they apply: 1 = frame || lstm_att; 2 = also attention || lstm_dec;
   // 0 = off; -1 (default) = by batch size: level 2 up to 320 utterances, level 1 above.  Measured us per step for levels
   // 1 / 2 (end of round 2): B = 128 69.0 / 53.7, B = 192 66.2 / 59.5, B = 256 77.2 / 70.2.  Until the attention role's row sums
   // moved from ds_bpermute to DPP (common.h wave_sum) level 2 LOST from 192 utterances on (B = 256: 80.8 / 86.1): the role's
   // LDS-path shuffles queued behind the co-resident LSTM workgroup's LDS traffic, the attention workgroups finished late and
   // every LSTM workgroup waited for the slowest of them.  (Split-fp16; exact fp32: see overlap_level.)
-  // TTSDEC_OVERLAP=0/1/2 or TTSDEC_NO_OVERLAP=1 (measurement switches).
+  // Option "overlap" = 0 / 1 / 2.
   int overlap;
-  bool chunk_a, chunk_b;  // chunked layout of the activation planes / LSTM weight planes; TTSDEC_CHUNK_A/B=0 (measurement)
-  bool proj_regw;         // mel/stop projection on the register-weight kernel where it applies; TTSDEC_PROJ_REGW=0 (measurement)
+  bool chunk_a, chunk_b;  // chunked layout of the activation planes / LSTM weight planes (options "chunk_a" / "chunk_b")
+  bool proj_regw;         // mel/stop projection on the register-weight kernel where it applies (option "proj_regw")
+  int opt_graph, opt_chunk_a, opt_chunk_b, opt_proj_regw;  // the options behind those four: -1 = default (on), 0, 1
   int head_proj;          // that projection as a role at the head of the NEXT step's frame launch: 1 / 0, -1 = by batch size; TTSDEC_HEAD_PROJ
+  int deep_ring;          // lean LSTM tile refilled one stage earlier (gemm_tile.h DEEP): 1 / 0, -1 = default
+  int fill_k;             // K elements of the decoder LSTM's h_dec(t-1) segment contracted by the attention LSTM's workgroups of
+                          // the step's FIRST launch (kernels.h LstmArgs::fill_k): multiple of 32, 0 = off, -1 = default
+  int query_regw;         // attention query on the register-weight GEMM kernel (frame_body.h proj_body): 1 / 0, -1 = default
+  int profile_ablation;   // ttsdec_profile_step only: the kernels' dbg switches (measurement ablations)
+  int debug_flags;        // test hooks, copied into Ctrl::debug_flags: bit 0 = the frame role does not signal, bit 1 = the attention
+                          // role does not, bit 2 = the projection head role does not (drives the bounded-spin time-out path)
+  int spin_limit;         // polls before a role gives up waiting (common.h role_wait); 0 = kRoleSpinLimit
   hipStream_t cap_stream;
   bool streams_ready;
   // one cached graph: valid for exactly this (workspace, blob, B, L, precision)
@@ -250,7 +259,7 @@ WsLayout make_ws_layout(const ttsdec_dims& d, int B, int Lm) {
   }
   W.jparts = take((size_t)kProjSplit * b * proj_ldp(d));
   W.pa = take(b * 4 * d.h_att);
-  W.pd = take(b * 4 * d.h_dec);
+  W.pd = take(bp * 4 * d.h_dec);  // (also the parked accumulators of the filler contraction: whole 64-row tiles)
   W.total = off;
   return W;
 }
@@ -359,6 +368,11 @@ bool split_ok(const ttsdec_dims& d) { return !((d.d_pre | d.d_ctx | d.h_att | d.
 // launch order of one step: the Prod cell attends between its two LSTMs, the Taco2 cell after both
 const StepOrder& step_order(const ttsdec_handle* h, int B);
 bool head_proj(const ttsdec_handle* h, int B);
+int filler_k(const ttsdec_handle* h, int B);
+int query_parts(const ttsdec_handle* h, int prec);
+int& option_ref(ttsdec_handle* h, int o);
+void apply_env_options(ttsdec_handle* h);
+void drop_graph(ttsdec_handle* h);
 int lstm_prec(const ttsdec_handle* h) {
   return (h->precision == TTSDEC_PREC_SPLIT_F16 && split_ok(h->d) && h->wmax_dec < kSplitMax) ? 1 : 0;
 }
@@ -460,13 +474,40 @@ void launch_node(const ttsdec_handle* h, const StepBufs& sb, const StepIo& io, N
       a.K = k0 + D + H;
       a.dep_n = frame_grid_size(B, P); a.dep_seg = 2; a.dep_which = 0;
       a.live_lag = 1;  // (same launch as the frame kernel: see lstm_body)
+      if (const int kf = filler_k(h, B)) {
+        // filler: the leading kf columns of the DECODER LSTM's h_dec(t-1) segment (decoder_cell.py:191), on this launch's
+        // workgroups while they would wait for the frame role; the decoder LSTM of the step's last launch starts from the sums
+        const void *hd = prec ? (const void*)sb.h_dec_h[p] : sb.h_dec[p], *hdl = prec ? (const void*)sb.h_dec_l[p] : sb.h_dec[p];
+        const f16 *dh = plane(ck ? bl.dec_hh_ch : bl.dec_hh_h), *dl = plane(ck ? bl.dec_hh_cl : bl.dec_hh_l);
+        const int wld = ck ? Hd / kChunkK : Hd;
+        a.fa = act(make_seg1(hd, Hd, kf)); a.fa_lo = act(make_seg1(hdl, Hd, kf));
+        a.fw = make_seg1(prec ? (const void*)dh : (const void*)(blob + bl.dec_hh), wld, kf);
+        a.fw_lo = make_seg1(prec ? (const void*)dl : (const void*)(blob + bl.dec_hh), wld, kf);
+        if (ck) { a.fw.mpad = 1; a.fw_lo.mpad = 1; }
+        a.fill_k = kf; a.fill_out = sb.pd;
+      }
     } else if (part == PART_GATED) {
       // [h_att | h_dec | ctx]: ctx is written by the attention role of the same launch
-      a.a = act(make_seg3(x0, k0, k0, x2, H, H, x1, D, D)); a.a_lo = act(make_seg3(x0l, k0, k0, x2l, H, H, x1l, D, D));
-      a.w = make_seg3(W0(false), wld_ih, k0, W2(false), wld_hh, H, W1(false), wld_ih, D);
-      a.w_lo = make_seg3(W0(true), wld_ih, k0, W2(true), wld_hh, H, W1(true), wld_ih, D);
-      a.K = k0 + D + H;
-      a.dep_n = B; a.dep_seg = 2; a.dep_which = 1;
+      const int kf = filler_k(h, B);  // leading columns of the h_dec segment already contracted by the step's first launch
+      if (kf >= H) {
+        a.a = act(make_seg2(x0, k0, k0, x1, D, D)); a.a_lo = act(make_seg2(x0l, k0, k0, x1l, D, D));
+        a.w = make_seg2(W0(false), wld_ih, k0, W1(false), wld_ih, D);
+        a.w_lo = make_seg2(W0(true), wld_ih, k0, W1(true), wld_ih, D);
+        a.dep_seg = 1;
+      } else {
+        // element offset of column kf: activation planes (chunked: whole chunks of all padded rows), weight planes (chunked:
+        // chunk kf / 32 of unit block 0), fp32 operands (row-major)
+        const size_t ao = prec ? (mpad > 0 ? (size_t)(kf / kChunkK) * mpad * kChunkK : (size_t)kf) : (size_t)kf;
+        const size_t wo = ck ? (size_t)kf * 64 : (size_t)kf;
+        auto offp = [&](const void* q, size_t o) { return prec ? (const void*)((const f16*)q + o) : (const void*)((const float*)q + o); };
+        a.a = act(make_seg3(x0, k0, k0, offp(x2, ao), H, H - kf, x1, D, D)); a.a_lo = act(make_seg3(x0l, k0, k0, offp(x2l, ao), H, H - kf, x1l, D, D));
+        a.w = make_seg3(W0(false), wld_ih, k0, offp(W2(false), wo), wld_hh, H - kf, W1(false), wld_ih, D);
+        a.w_lo = make_seg3(W0(true), wld_ih, k0, offp(W2(true), wo), wld_hh, H - kf, W1(true), wld_ih, D);
+        a.dep_seg = 2;
+      }
+      a.K = k0 + D + H - kf;
+      a.dep_n = B; a.dep_which = 1;
+      if (kf > 0) a.acc_init = sb.pd;
     } else if (which == 0 ? part == PART_EARLY : part == PART_LATE) {
       // [ctx (| h_att)]: the attention LSTM's early part, or the decoder LSTM's late part (ctx alone)
       const int kh = which == 0 ? H : 0;
@@ -490,13 +531,14 @@ void launch_node(const ttsdec_handle* h, const StepBufs& sb, const StepIo& io, N
     a.h_out = which ? sb.h_dec[1 - p] : sb.h_att[1 - p];
     a.M = B; a.H = H; a.pz = d.p_zoneout; a.ctrl = ctrl; a.slot = io.slot; a.dbg = io.dbg;
     a.tag = which;
+    a.deep = h->deep_ring > 0;
     return a;
   };
   auto attn_args = [&]() {
     AttnArgs a;
     memset(&a, 0, sizeof(a));
     if (prec) { a.ctx_h = sb.ctx_h; a.ctx_l = sb.ctx_l; a.out_mpad = mpad; }
-    a.memory = io.memory; a.q = sb.q; a.q_parts = query_split(d); a.q_stride = (size_t)B * D;
+    a.memory = io.memory; a.q = sb.q; a.q_parts = query_parts(h, prec); a.q_stride = (size_t)B * D;
     a.w_prev = sb.w[p]; a.w_new = sb.w[1 - p]; a.w_out = io.w; a.ctx = sb.ctx;
     a.B = B; a.L = io.L; a.D = D; a.t_rel = io.t_rel; a.t_stride = io.t_stride; a.ctrl = ctrl; a.slot = io.slot;
     return a;
@@ -577,6 +619,16 @@ void launch_node(const ttsdec_handle* h, const StepBufs& sb, const StepIo& io, N
       }
       g.ksplit = query_split(d); g.kchunk = g.K / g.ksplit; g.split_stride = (size_t)B * D;
       g.ctrl = ctrl; g.slot = io.slot; g.t = io.t;
+      if (query_parts(h, prec) != query_split(d) || (prec && h->query_regw > 0 && proj_split(g.K) == g.ksplit)) {
+        // the same slabs from the register-weight kernel (frame_body.h proj_body)
+        ProjArgs pa;
+        memset(&pa, 0, sizeof(pa));
+        pa.a = g.a; pa.a_lo = g.a_lo; pa.W = g.W; pa.W_lo = g.W_lo; pa.ldw = g.ldw; pa.prec = g.prec;
+        pa.M = B; pa.N = D; pa.K = g.K; pa.ksplit = query_parts(h, prec); pa.split_stride = (size_t)B * D;
+        pa.out = sb.q; pa.ldo = D; pa.ctrl = ctrl; pa.slot = io.slot; pa.mode = PROJ_STEP;
+        launch_proj(pa, st);
+        break;
+      }
       launch_gemm(g, A_PLAIN, EPI_PLAIN, st);
       break;
     }
@@ -667,6 +719,21 @@ bool head_proj(const ttsdec_handle* h, int B) {
   if (!overlap_level(h, B) || !proj_regw(h, lstm_prec(h))) return false;
   return h->head_proj != 0;  // (-1 = default = on)
 }
+// The filler contraction (kernels.h LstmArgs::fill_k): both LSTMs on the 64 x 64 lean tile of the two-role launches with equal
+// grids (same hidden width, more than 64 utterances), every K tile whole.
+int filler_k(const ttsdec_handle* h, int B) {
+  const ttsdec_dims& d = h->d;
+  if (h->fill_k <= 0 || overlap_level(h, B) < 2 || d.h_att != d.h_dec || B <= 64 || (d.h_dec & 31)) return 0;
+  const int kf = h->fill_k & ~31;
+  return kf < d.h_dec ? kf : d.h_dec;
+}
+// slabs of the attention query: the register-weight kernel's own split where it serves the query, else the LDS-staged GEMM's
+int query_parts(const ttsdec_handle* h, int prec) {
+  const ttsdec_dims& d = h->d;
+  const int ps = proj_split(query_k(d));
+  if (prec && h->query_regw > 0 && ps > 0 && ps <= kQuerySplit && !((d.h_att | d.h_dec) & 7)) return ps;
+  return query_split(d);
+}
 const StepOrder& step_order(const ttsdec_handle* h, int B) {
   const ttsdec_dims& d = h->d;
   if (const int lv = overlap_level(h, B)) {
@@ -732,6 +799,53 @@ int ensure_graph(ttsdec_handle* h, const StepBufs& sb, const void* ws, int B, in
   return TTSDEC_OK;
 }
 
+
+// ---- options (include/ttsdec.h TTSDEC_OPT_*) ----
+const char* const kOptionNames[TTSDEC_OPT_COUNT] = {"graph", "overlap", "chunk_a", "chunk_b", "proj_regw", "head_proj", "deep_ring",
+                                                    "fill_k", "query_regw", "profile_ablation", "debug_flags", "spin_limit"};
+int& option_ref(ttsdec_handle* h, int o) {
+  switch (o) {
+    case TTSDEC_OPT_OVERLAP: return h->overlap;
+    case TTSDEC_OPT_CHUNK_A: return h->opt_chunk_a;
+    case TTSDEC_OPT_CHUNK_B: return h->opt_chunk_b;
+    case TTSDEC_OPT_PROJ_REGW: return h->opt_proj_regw;
+    case TTSDEC_OPT_HEAD_PROJ: return h->head_proj;
+    case TTSDEC_OPT_DEEP_RING: return h->deep_ring;
+    case TTSDEC_OPT_FILL_K: return h->fill_k;
+    case TTSDEC_OPT_QUERY_REGW: return h->query_regw;
+    case TTSDEC_OPT_PROFILE_ABLATION: return h->profile_ablation;
+    case TTSDEC_OPT_DEBUG_FLAGS: return h->debug_flags;
+    case TTSDEC_OPT_SPIN_LIMIT: return h->spin_limit;
+    default: return h->opt_graph;
+  }
+}
+// the derived switches the launch code reads (-1 = library default)
+void refresh_options(ttsdec_handle* h) {
+  h->use_graph = h->opt_graph != 0;
+  h->chunk_a = h->opt_chunk_a != 0;
+  h->chunk_b = h->opt_chunk_b != 0;
+  h->proj_regw = h->opt_proj_regw != 0;
+  drop_graph(h);  // a captured graph bakes the launch sequence in
+}
+void apply_env_options(ttsdec_handle* h) {
+  if (const char* e = getenv("TTSDEC_OPTIONS")) {
+    std::string str(e);
+    size_t pos = 0;
+    while (pos < str.size()) {
+      size_t end = str.find(',', pos);
+      if (end == std::string::npos) end = str.size();
+      const std::string item = str.substr(pos, end - pos);
+      const size_t eq = item.find('=');
+      if (eq != std::string::npos) {
+        const std::string name = item.substr(0, eq);
+        for (int o = 0; o < TTSDEC_OPT_COUNT; ++o)
+          if (name == kOptionNames[o]) option_ref(h, o) = atoi(item.c_str() + eq + 1);
+      }
+      pos = end + 1;
+    }
+  }
+  refresh_options(h);
+}
 }  // namespace
 
 extern "C" {
@@ -769,22 +883,14 @@ int ttsdec_create(const ttsdec_dims* dims, ttsdec_handle** out) {
   h->graph = nullptr;
   h->g_ws = h->g_blob = nullptr;
   h->wmax_dec = h->wmax_post = 0.f;
-  // Measurement switch: TTSDEC_NO_GRAPH=1 launches every step kernel from the host instead of
-  // replaying the captured graph.  (A two-stream schedule that ran the LSTMs' early K segments
-  // beside the small critical-path kernels was built and measured SLOWER on MI355X - 126 vs 96 us
-  // per step at B=256: the early GEMM's 256 workgroups hold every CU's LDS, so the small kernels
-  // queue behind them - and was removed; see DESIGN.md.)
-  const char* e2 = getenv("TTSDEC_NO_GRAPH");
-  h->use_graph = !(e2 && atoi(e2));
-  const char *e3 = getenv("TTSDEC_NO_OVERLAP"), *e3b = getenv("TTSDEC_OVERLAP");
-  h->overlap = (e3 && atoi(e3)) ? 0 : (e3b ? atoi(e3b) : -1);
-  const char *e4 = getenv("TTSDEC_CHUNK_A"), *e5 = getenv("TTSDEC_CHUNK_B");
-  h->chunk_a = !(e4 && !atoi(e4));
-  h->chunk_b = !(e5 && !atoi(e5));
-  const char* e6 = getenv("TTSDEC_PROJ_REGW");
-  h->proj_regw = !(e6 && !atoi(e6));
-  const char* e7 = getenv("TTSDEC_HEAD_PROJ");
-  h->head_proj = e7 ? atoi(e7) : -1;
+  // Tuning / measurement options (include/ttsdec.h TTSDEC_OPT_*): library defaults, then the process-wide
+  // TTSDEC_OPTIONS="name=value,..." (read here, once per handle), then ttsdec_set_option.
+  // (A two-stream schedule that ran the LSTMs' early K segments beside the small critical-path kernels was built and
+  // measured SLOWER on MI355X - 126 vs 96 us per step at B=256: the early GEMM's 256 workgroups hold every CU's LDS, so
+  // the small kernels queue behind them - and was removed; see DESIGN.md.)
+  for (int o = 0; o < TTSDEC_OPT_COUNT; ++o) option_ref(h, o) = -1;
+  h->profile_ablation = 0; h->debug_flags = 0; h->spin_limit = 0;
+  apply_env_options(h);
   h->device = current_device_or_minus1();
   *out = h;
   return TTSDEC_OK;
@@ -815,6 +921,21 @@ int ttsdec_get_precision(const ttsdec_handle* h) {
   if (!h) return TTSDEC_ERR_INVALID_ARG;
   return lstm_prec(h) ? TTSDEC_PREC_SPLIT_F16 : TTSDEC_PREC_F32;
 }
+
+int ttsdec_set_option(ttsdec_handle* h, int option, int value) {
+  if (!h || option < 0 || option >= TTSDEC_OPT_COUNT) return TTSDEC_ERR_INVALID_ARG;
+  option_ref(h, option) = value;
+  refresh_options(h);
+  return TTSDEC_OK;
+}
+
+int ttsdec_get_option(const ttsdec_handle* h, int option, int* value) {
+  if (!h || !value || option < 0 || option >= TTSDEC_OPT_COUNT) return TTSDEC_ERR_INVALID_ARG;
+  *value = option_ref(const_cast<ttsdec_handle*>(h), option);
+  return TTSDEC_OK;
+}
+
+const char* ttsdec_option_name(int option) { return (option >= 0 && option < TTSDEC_OPT_COUNT) ? kOptionNames[option] : nullptr; }
 
 size_t ttsdec_packed_bytes(const ttsdec_handle* h) { return h ? h->bl.total * sizeof(float) : 0; }
 
@@ -999,6 +1120,8 @@ int ttsdec_decode(ttsdec_handle* h, const float* memory, int B, int L, int t_beg
   ca.dropout_mode = dropout_mode; ca.teacher_T = teacher_T; ca.stop_thr = stop_threshold; ca.seed = seed;
   ca.memory = memory; ca.masks = masks; ca.teacher = teacher; ca.teacher_flags = teacher_flags;
   ca.y = y; ca.s = s; ca.w = w;
+  ca.debug_flags = h->debug_flags > 0 ? h->debug_flags : 0;
+  ca.spin_limit = h->spin_limit > 0 ? h->spin_limit : kRoleSpinLimit;
   // measurement only: TTSDEC_STAMPS=<file> collects per-workgroup time stamps of the two-role launches of the
   // call's last step and writes them to <file> (synchronises; never set in production)
   static unsigned long long* g_stamps = nullptr;
@@ -1311,7 +1434,7 @@ int ttsdec_profile_step(ttsdec_handle* h, const float* memory, int B, int L, int
   io.dropout_mode = dropout_mode; io.masks = masks; io.seed = seed;
   io.y = y; io.s = s; io.w = w; io.use_ctrl = false;
   io.t = 1; io.t_rel = 1; io.t_stride = 2; io.finalize = 1;  // a mid-sequence step: the frame kernel also finishes step 0's frame
-  if (const char* e = getenv("TTSDEC_PROFILE_ABLATION")) io.dbg = atoi(e);  // measurement only
+  io.dbg = h->profile_ablation > 0 ? h->profile_ablation : 0;  // measurement only (option "profile_ablation")
   hipEvent_t e0, e1;
   HIP_TRY(h, hipEventCreate(&e0));
   HIP_TRY(h, hipEventCreate(&e1));

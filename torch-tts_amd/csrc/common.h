@@ -48,7 +48,10 @@ struct Ctrl {
   unsigned int dep_proj;
   // measurement only (TTSDEC_STAMPS=1): per-workgroup wall-clock stamps of the two-role launches, else nullptr
   unsigned long long* stamps;
-  int pad[26];
+  // test hooks (include/ttsdec.h TTSDEC_OPT_DEBUG_FLAGS / _SPIN_LIMIT): bit 0 = the frame role does not signal, bit 1 = the
+  // attention role does not, bit 2 = the projection head role does not; polls before role_wait gives up
+  int debug_flags, spin_limit;
+  int pad[24];
 };
 // stamps[(kind * 1024 + block) * 8 + k]; kind 0 = frame || lstm_att, 1 = attention || lstm_dec;
 // k: 0 = role << 32 | HW_ID, 1 = XCC_ID, 2 = start, 3 = gate reached, 4 = gate passed, 5 = end (s_memrealtime, 10 ns units)
@@ -316,7 +319,7 @@ __device__ __forceinline__ void role_wait(const unsigned int* counter, unsigned 
   int spins = 0;
   while (__hip_atomic_load(counter, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
     __builtin_amdgcn_s_sleep(16);
-    if (++spins > kRoleSpinLimit) {
+    if (++spins > (ctrl != nullptr ? ctrl->spin_limit : kRoleSpinLimit)) {
       if (ctrl != nullptr) atomicOr(&ctrl->range_err, 2);
       break;
     }

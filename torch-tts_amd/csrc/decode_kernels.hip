@@ -573,6 +573,8 @@ __global__ void set_call_kernel(Ctrl* c, CallArgs a) {
   c->dep_attn = 0;
   c->dep_proj = 0;
   c->stamps = a.stamps;
+  c->debug_flags = a.debug_flags;
+  c->spin_limit = a.spin_limit;
 }
 void launch_set_call(Ctrl* ctrl, const CallArgs& a, hipStream_t st) {
   hipLaunchKernelGGL(set_call_kernel, dim3(1), dim3(1), 0, st, ctrl, a);

@@ -486,7 +486,7 @@ __device__ __forceinline__ void frame_body(FrameArgs g, float* lds, int bx, int 
   }
   report_range(over, g.ctrl);
   if (tid == 0) stamp(st, 0, 6, now_rt());  // x_pre stores issued
-  if (g.dep_signal && g.ctrl != nullptr) {
+  if (g.dep_signal && g.ctrl != nullptr && !(g.ctrl->debug_flags & 1)) {
     role_signal(&g.ctrl->dep_frame);  // the attention LSTM of this launch waits for x_pre
     if (tid == 0) stamp(st, 0, 5, now_rt());
   }
@@ -610,7 +610,7 @@ __device__ __forceinline__ void proj_body(ProjArgs g, float* red, int id) {
     if (signal) store_wt(slab + (size_t)m * g.ldo + n, v);  // read by the frame role of this very launch
     else slab[(size_t)m * g.ldo + n] = v;
   }
-  if (signal) role_signal(&g.ctrl->dep_proj);
+  if (signal && !(g.ctrl->debug_flags & 4)) role_signal(&g.ctrl->dep_proj);
 }
 
 

@@ -76,7 +76,9 @@ struct RoleGate {
 // requests them after it instead - 20 live registers fewer across the loop, to stay within 128 VGPRs.
 // kWhole: the caller only ever runs whole cells (mode 0, no sequence mode): the parked partial sums and their registers
 // drop out, which is what lets the lean tile of the two-role launches request the rest of the operands early.
-template <class Cfg, bool kEarlyEpi = true, bool kWhole = false>
+// kFill: the kernel may be asked to run a filler contraction first (LstmArgs::fill_k) or to start from parked accumulators
+// (LstmArgs::acc_init): the 64 x 64 lean tile of the two-role launches.
+template <class Cfg, bool kEarlyEpi = true, bool kWhole = false, bool kFill = false>
 __device__ __forceinline__ void lstm_body(LstmArgs g, float* smem, int bx, int by) {
   if constexpr (kWhole) { g.mode = 0; g.seq_lens = nullptr; g.seq_out = nullptr; }
   bool live = true;
@@ -120,6 +122,15 @@ __device__ __forceinline__ void lstm_body(LstmArgs g, float* smem, int bx, int b
     ph[j] = ok ? g.h_prev[idx] : 0.f;
   }
   };
+  const int acc_blk = (by * ((H + BU - 1) / BU) + bx) * (BM * BN);  // this tile's block of parked accumulators (AccIo)
+  if constexpr (kFill) if (g.fill_k > 0) {
+    // filler: part of another cell's contraction on this workgroup's tile coordinates, accumulators parked in fill_out
+    const LoaderPlain<EB> fa{g.fa, g.fa_lo, m0, g.M};
+    const LoaderWLstm<BU, EB> fb{g.fw, g.fw_lo, u0, g.H};
+    AccIo park;
+    park.store = g.fill_out + acc_blk;
+    gemm_tile<Cfg>(fa, fb, smem, live, g.dbg, NoGate(), park);
+  }
   if constexpr (kEarlyEpi) load_epi();
 
   const LoaderPlain<EB> la{g.a, g.a_lo, m0, g.M};
@@ -139,7 +150,11 @@ __device__ __forceinline__ void lstm_body(LstmArgs g, float* smem, int bx, int b
       gate.target = (unsigned int)(g.ctrl->t_cur + g.slot - g.ctrl->t_call + 1) * (unsigned int)g.dep_n;
     }
   }
-  gemm_tile<Cfg>(la, lb, smem, live, g.dbg, gate);
+  AccIo aio;
+  if constexpr (kFill) {
+    if (g.acc_init != nullptr) aio.init = g.acc_init + acc_blk;
+  }
+  gemm_tile<Cfg>(la, lb, smem, live, g.dbg, gate, aio);
   if (!live) return;
   if constexpr (!kEarlyEpi) load_epi();
 
@@ -372,7 +387,7 @@ __device__ __forceinline__ void attn_body(AttnArgs g, float* part, int b) {
       if (g.ctx_h != nullptr) split_f16_checked(s, g.ctx_h[o], g.ctx_l[o], g.ctrl);
     }
   }
-  if (g.dep_signal && g.ctrl != nullptr) {
+  if (g.dep_signal && g.ctrl != nullptr && !(g.ctrl->debug_flags & 2)) {
     role_signal(&g.ctrl->dep_attn);  // the decoder LSTM of this launch waits for ctx
     if (threadIdx.x == 0) stamp(st, 1, 5, now_rt());
   }

@@ -98,51 +98,72 @@ class Decoder(PackedWeightsMixin, nn.Module):
             # teacher-forcing coin flips still come from the host generator, like the reference
             stream = MaskStream(B, self.decoder_cell.dim_pre, 0.0, p_no_forcing=p_no_forcing, teacher_steps=total_steps)
 
-        ys: List[torch.Tensor] = []
-        ss: List[torch.Tensor] = []
-        wsl: List[torch.Tensor] = []
-        flags_all = torch.ones(total_steps if x is not None else 0, dtype=torch.uint8)
-        t_out = torch.zeros(2, dtype=torch.int32, device=device)
-        t = 0
-        produced = 0
         chunk = max(2, int(self.chunk_steps) + (int(self.chunk_steps) & 1))  # even: ttsdec_decode ties buffer parity to t_begin
-        while True:
-            n = chunk if cap is None else min(cap - t, chunk if total_steps is None else cap - t)
-            if n <= 0:
-                break
-            masks_dev = None
-            if stream is not None:
-                masks, flags = stream.draw(n)
-                if mode == _lib.DROPOUT_MASKS:
-                    masks_dev = masks.to(device, non_blocking=False)
-                if x is not None:
-                    flags_all[t : t + n] = flags
-            flags_dev = flags_all.to(device) if teacher is not None else None
-            y = torch.empty(B, n * r, dm, dtype=torch.float32, device=device)
-            s = torch.empty(B, n * r, dtype=torch.float32, device=device)
-            w = torch.empty(B, n, L, dtype=torch.float32, device=device)
-            eng.decode(
-                memory, t_begin=t, n_steps=n, stop_threshold=float(self.stop_threshold), check_stop=check_stop,
-                dropout_mode=mode, masks=masks_dev, seed=int(self.dropout_seed), teacher=teacher,
-                teacher_flags=flags_dev, y=y, s=s, w=w, t_out=t_out,
-            )
-            done, flags = (int(v) for v in t_out.tolist())  # the one host sync of this chunk
-            fired = flags & 1
-            if flags & 4:
-                raise RuntimeError("decode step: a two-role launch timed out waiting for its producer role (GPU shared or stalled); results discarded")
-            if flags & 2:
-                raise RuntimeError(
-                    "split_f16 precision: an activation (input/teacher frame, PreNet output or context) exceeded the fp16 "
-                    "range (|x| > 65504) and was saturated; set decoder.precision = 'f32' for such inputs"
+
+        def run():
+            """The chunked decode from step 0.  Returns None when a two-role launch timed out (its outputs are invalid)."""
+            ys: List[torch.Tensor] = []
+            ss: List[torch.Tensor] = []
+            wsl: List[torch.Tensor] = []
+            flags_all = torch.ones(total_steps if x is not None else 0, dtype=torch.uint8)
+            t_out = torch.zeros(2, dtype=torch.int32, device=device)
+            t = 0
+            produced = 0
+            while True:
+                n = chunk if cap is None else min(cap - t, chunk if total_steps is None else cap - t)
+                if n <= 0:
+                    break
+                masks_dev = None
+                if stream is not None:
+                    masks, flags = stream.draw(n)
+                    if mode == _lib.DROPOUT_MASKS:
+                        masks_dev = masks.to(device, non_blocking=False)
+                    if x is not None:
+                        flags_all[t : t + n] = flags
+                flags_dev = flags_all.to(device) if teacher is not None else None
+                y = torch.empty(B, n * r, dm, dtype=torch.float32, device=device)
+                s = torch.empty(B, n * r, dtype=torch.float32, device=device)
+                w = torch.empty(B, n, L, dtype=torch.float32, device=device)
+                eng.decode(
+                    memory, t_begin=t, n_steps=n, stop_threshold=float(self.stop_threshold), check_stop=check_stop,
+                    dropout_mode=mode, masks=masks_dev, seed=int(self.dropout_seed), teacher=teacher,
+                    teacher_flags=flags_dev, y=y, s=s, w=w, t_out=t_out,
                 )
-            k = done - t
-            ys.append(y[:, : k * r])
-            ss.append(s[:, : k * r])
-            wsl.append(w[:, :k])
-            produced = done
-            t += n
-            if fired or (cap is not None and t >= cap):
-                break
+                done, flags = (int(v) for v in t_out.tolist())  # the one host sync of this chunk
+                fired = flags & 1
+                if flags & 4:
+                    return None
+                if flags & 2:
+                    raise RuntimeError(
+                        "split_f16 precision: an activation (input/teacher frame, PreNet output or context) exceeded the fp16 "
+                        "range (|x| > 65504) and was saturated; set decoder.precision = 'f32' for such inputs"
+                    )
+                k = done - t
+                ys.append(y[:, : k * r])
+                ss.append(s[:, : k * r])
+                wsl.append(w[:, :k])
+                produced = done
+                t += n
+                if fired or (cap is not None and t >= cap):
+                    break
+            return ys, ss, wsl, produced
+
+        out = run()
+        if out is None:
+            # A consumer role of a two-role launch gave up waiting for its producer role (bounded spin: the GPU is shared or
+            # stalled so badly that the roles were not co-resident).  The state in the workspace is unusable, but a decode
+            # call restarts from its inputs: switch this engine to one role per launch and run the call again.
+            import warnings
+
+            warnings.warn("decode step: a two-role launch timed out waiting for its producer role; "
+                          "this engine now runs one role per launch (option overlap = 0) and the call is repeated", RuntimeWarning)
+            eng.set_option("overlap", 0)
+            if stream is not None:
+                stream.restart()
+            out = run()
+            if out is None:
+                raise RuntimeError("decode step: a launch timed out waiting for its producer role even with one role per launch; results discarded")
+        ys, ss, wsl, produced = out
         if stream is not None:
             stream.rewind_to(produced)
         y = ys[0] if len(ys) == 1 else torch.cat(ys, dim=1)

@@ -152,6 +152,15 @@ class Engine:
     def precision(self) -> str:
         return {_lib.PREC_F32: "f32", _lib.PREC_SPLIT_F16: "split_f16"}[self._lib.ttsdec_get_precision(self._h)]
 
+    # ---- tuning / measurement options (include/ttsdec.h TTSDEC_OPT_*; -1 = library default) ----
+    def set_option(self, name: str, value: int) -> None:
+        _lib.check(self._lib.ttsdec_set_option(self._h, _lib.option_ids()[name], int(value)), f"ttsdec_set_option({name})")
+
+    def get_option(self, name: str) -> int:
+        v = C.c_int(0)
+        _lib.check(self._lib.ttsdec_get_option(self._h, _lib.option_ids()[name], C.byref(v)), f"ttsdec_get_option({name})")
+        return int(v.value)
+
     # ---- weights ----
     def pack(self, tensors: Sequence[Optional[Tensor]]) -> Tensor:
         """tensors: in TTSDEC_W_* order (None = not owned by the calling module)."""

@@ -28,6 +28,7 @@ class MaskStream:
         self.teacher_steps = teacher_steps  # total steps of the teacher-forced run, or None
         self.gen = generator
         self._states: List[torch.Tensor] = []  # generator state after each drawn step
+        self._start = self._get_state()        # ... and before the first one (restart)
         self.steps_drawn = 0
 
     def _get_state(self) -> torch.Tensor:
@@ -64,6 +65,12 @@ class MaskStream:
         if w0 == w1:
             masks = masks.view(n_steps, 2, self.B, w1)
         return masks, flags
+
+    def restart(self) -> None:
+        """Back to before the first draw: the same draws come again (a decode call that is repeated)."""
+        self._set_state(self._start)
+        self._states.clear()
+        self.steps_drawn = 0
 
     def rewind_to(self, steps_used: int) -> None:
         """Leave the generator as if only `steps_used` steps had ever been drawn."""
