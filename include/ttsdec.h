@@ -178,10 +178,6 @@ enum {
   TTSDEC_OPT_CHUNK_B,          /* "chunk_b": 0 = row-major LSTM weight planes                                                  */
   TTSDEC_OPT_PROJ_REGW,        /* "proj_regw": 0 = mel/stop projection on the LDS-staged split-K GEMM                          */
   TTSDEC_OPT_HEAD_PROJ,        /* "head_proj": 1 / 0 = that projection as a role at the head of the next step's first launch   */
-  TTSDEC_OPT_DEEP_RING,        /* "deep_ring": 1 = the lean LSTM tile refills its LDS ring one stage earlier                   */
-  TTSDEC_OPT_FILL_K,           /* "fill_k": K elements (multiple of 32) of the decoder LSTM's h_dec(t-1) segment contracted by
-                                * the attention LSTM's workgroups in the step's first launch; 0 = off                         */
-  TTSDEC_OPT_QUERY_REGW,       /* "query_regw": 1 = attention query GEMM on the register-weight kernel                         */
   TTSDEC_OPT_PROFILE_ABLATION, /* "profile_ablation": ttsdec_profile_step only, kernel-internal ablation switches              */
   TTSDEC_OPT_DEBUG_FLAGS,      /* "debug_flags": TEST HOOK. bit 0 / 1 / 2: the frame / attention / projection-head role of a
                                 * two-role launch does not signal its consumers, which then run into the bounded-spin

@@ -1080,22 +1080,15 @@ _STEP_OPTIONS = [
     {"chunk_a": 0, "chunk_b": 0, "overlap": 2}, {"proj_regw": 0},
     {"head_proj": 1}, {"head_proj": 1, "overlap": 1}, {"head_proj": 1, "graph": 0},
     {"head_proj": 0},
-    {"deep_ring": 1}, {"deep_ring": 1, "overlap": 2, "graph": 0}, {"query_regw": 1}, {"query_regw": 1, "chunk_a": 0},
-    # the filler contraction (needs equal LSTM widths: the second dims below; elsewhere the option is inert)
-    {"fill_k": 64, "overlap": 2}, {"fill_k": 128, "overlap": 2}, {"fill_k": 96, "overlap": 2, "deep_ring": 1, "query_regw": 1},
-    {"fill_k": 128, "overlap": 2, "chunk_a": 0, "chunk_b": 0}, {"fill_k": 64, "overlap": 2, "head_proj": 0, "graph": 0},
 ]
 
 
 @pytest.mark.parametrize("prec", ["f32", "split_f16"])
-@pytest.mark.parametrize("widths", [(128, 192), (128, 128)])
-def test_all_step_orders_and_layouts_vs_oracle(H, prec, widths, monkeypatch):
-    dims = O.DecoderDims(d_mel=80, d_pre=128, d_ctx=64, h_att=widths[0], h_dec=widths[1])  # (fused launches, chunked planes and the
-    wts = O.random_decoder_weights(dims, seed=21, nonzero_init_state=True)              #  register-weight projection all apply)
+def test_all_step_orders_and_layouts_vs_oracle(H, prec, monkeypatch):
+    dims = O.DecoderDims(d_mel=80, d_pre=128, d_ctx=64, h_att=128, h_dec=192)  # (fused launches, chunked planes and the
+    wts = O.random_decoder_weights(dims, seed=21, nonzero_init_state=True)    #  register-weight projection all apply)
     T_ = 18  # >= 15 steps: the captured-graph path (unless switched off)
-    opts = [o for o in _STEP_OPTIONS if widths[0] == widths[1] or "fill_k" not in o]
-    if widths[0] == widths[1]:
-        opts = [o for o in opts if "fill_k" in o or not o or "deep_ring" in o or "query_regw" in o]
+    opts = _STEP_OPTIONS
     for B in (3, 40, 70):  # stand-alone small tile / 64x8 lean tile / 64x16 lean tile of the two-role launches
         mem = O.synthetic_memory(B, 11, dims.d_ctx, lengths=[11] * (B - 1) + [4], seed=7)
         masks = O.synthetic_masks(T_, B, dims.d_pre, seed=9)
@@ -1128,7 +1121,7 @@ def test_all_step_orders_and_layouts_vs_oracle(H, prec, widths, monkeypatch):
 def test_set_option_on_a_live_handle_switches_the_launch_sequence(H):
     """ttsdec_set_option between two calls on ONE handle (the captured graph is dropped): same results, other launches."""
     from torch_tts_amd import _lib
-    dims = O.DecoderDims(d_mel=80, d_pre=128, d_ctx=64, h_att=128, h_dec=128)
+    dims = O.DecoderDims(d_mel=80, d_pre=128, d_ctx=64, h_att=128, h_dec=192)
     wts = O.random_decoder_weights(dims, seed=4, nonzero_init_state=True)
     B, T_ = 96, 20
     mem = O.synthetic_memory(B, 9, dims.d_ctx, seed=3)
@@ -1138,14 +1131,14 @@ def test_set_option_on_a_live_handle_switches_the_launch_sequence(H):
     dec.precision = "split_f16"
     eng = dec.engine(torch.device("cuda:0"))
     seen = []
-    for opt in ({"overlap": 2, "fill_k": 0}, {"fill_k": 128}, {"fill_k": 64, "deep_ring": 1}, {"overlap": 0}, {"overlap": -1, "fill_k": -1, "deep_ring": -1}):
+    for opt in ({"overlap": 2}, {"head_proj": 0}, {"overlap": 1}, {"overlap": 0}, {"overlap": -1, "head_proj": -1}):
         for k, v in opt.items():
             eng.set_option(k, v)
         y, s, w, fired = H.run_decoder_with_masks(dec, mem, masks, max_steps=T_ - 1)
         seen.append(tuple(eng.profile_step(mem.cuda(), 1, _lib.DROPOUT_OFF, None, 0)))
         H.assert_close(y, oy, RTOL, ATOL, f"y {opt}")
         H.assert_argmax(w, ow, f"argmax {opt}")
-    assert "attention+lstm_dec" in seen[0] and "attention+lstm_dec" not in seen[3], seen
+    assert "attention+lstm_dec" in seen[0] and "proj" in seen[1] and "attention+lstm_dec" not in seen[3], seen
     with pytest.raises(KeyError):
         eng.set_option("no_such_option", 1)
 
@@ -1156,7 +1149,7 @@ def test_role_timeout_flags_the_call_and_the_module_falls_back(H):
     not return that call's outputs: it switches the engine to one role per launch (option overlap = 0), warns and
     repeats the call."""
     from torch_tts_amd import _lib
-    dims = O.DecoderDims(d_mel=80, d_pre=128, d_ctx=64, h_att=128, h_dec=128)
+    dims = O.DecoderDims(d_mel=80, d_pre=128, d_ctx=64, h_att=128, h_dec=192)  # (h_dec + d_ctx = 256: the projection head role applies)
     wts = O.random_decoder_weights(dims, seed=4, nonzero_init_state=True)
     B, T_ = 70, 4
     mem = O.synthetic_memory(B, 9, dims.d_ctx, seed=3)

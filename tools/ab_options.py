@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Same-process A/B of the decoder's tuning options (include/ttsdec.h TTSDEC_OPT_*) on LJSpeech dims.
 
-    python tools/ab_options.py --batch 256 --variants "base:" "deep:deep_ring=1" "fill:fill_k=1024,deep_ring=1"
+    python tools/ab_options.py --batch 256 --variants "base:" "gate:lstm_start_gate=1" "nohead:head_proj=0"
 
 Every variant is a set of options applied to ONE engine (ttsdec_set_option drops the captured graph); the variants are timed in
 interleaved rounds (cdna_hip_programming.md rule 24) on a 600-frame Philox decode, and each variant's outputs are compared with

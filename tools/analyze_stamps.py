@@ -6,7 +6,8 @@ from collections import Counter
 
 import numpy as np
 
-a = np.fromfile(sys.argv[1], dtype=np.uint64).reshape(2, 1024, 8)
+a = np.fromfile(sys.argv[1], dtype=np.uint64).reshape(-1, 1024, 8)
+t0_kind0 = None
 for kind, name in ((0, "frame || lstm_att"), (1, "attention || lstm_dec")):
     s = a[kind]
     used = s[:, 2] > 0
@@ -17,6 +18,12 @@ for kind, name in ((0, "frame || lstm_att"), (1, "attention || lstm_dec")):
     hw = (s[:, 0] & 0xFFFFFFFF).astype(int)
     cu = ((s[:, 1].astype(int) & 0xF) << 16) | (hw & 0xFF00)  # xcc | se/sh/cu bits of HW_ID
     t0 = int(s[:, 2].min())
+    if kind == 0:
+        if s[:, 7].any():
+            t0 = min(t0, int(s[:, 7][s[:, 7] > 0].min()))
+        if a.shape[0] > 2 and (a[2][:, 2] > 0).any():
+            t0 = min(t0, int(a[2][:, 2][a[2][:, 2] > 0].min()))  # the projection head role starts the launch
+        t0_kind0 = t0
     us = lambda col: (s[:, col].astype(np.int64) - t0) / 100.0
     print(f"== {name}: {used.sum()} workgroups stamped")
     for r, rn in ((0, "producer"), (1, "lstm")):
@@ -26,7 +33,7 @@ for kind, name in ((0, "frame || lstm_att"), (1, "attention || lstm_dec")):
         st, en = us(2)[m], us(5)[m]
         print(f"  {rn:8s} n={m.sum():4d} start {st.min():6.2f}..{st.max():6.2f}  end {en.min():6.2f}..{en.max():6.2f} (mean {en.mean():6.2f})")
         if r == 0 and kind == 0:  # frame role: 3 = previous step's frame finished, 4 = layer 0 done, 6 = x_pre stores issued
-            for col, what in ((3, "frame(t-1) finished"), (4, "layer 0 done"), (6, "x_pre stores issued")):
+            for col, what in ((7, "entry (before the wait)"), (3, "frame(t-1) finished"), (4, "layer 0 done"), (6, "x_pre stores issued")):
                 v = us(col)[m]
                 ok = s[:, col][m] > 0
                 if ok.any():
@@ -42,3 +49,11 @@ for kind, name in ((0, "frame || lstm_att"), (1, "attention || lstm_dec")):
     prod_per_cu = Counter(v for (c, r), v in per_cu.items() if r == 0)
     both = sum(1 for c in set(cu) if per_cu.get((c, 0), 0) and per_cu.get((c, 1), 0))
     print(f"  CUs seen {len(set(cu))}; lstm workgroups per CU {dict(lstm_per_cu)}; producer workgroups per CU {dict(prod_per_cu)}; CUs holding both roles {both}")
+
+if a.shape[0] > 2 and (a[2][:, 2] > 0).any() and t0_kind0 is not None:
+    s = a[2][a[2][:, 2] > 0]
+    us = lambda col: (s[:, col].astype(np.int64) - t0_kind0) / 100.0
+    print(f"== projection head role of the frame || lstm_att launch: {len(s)} workgroups (us from the launch's first stamp)")
+    for col, what in ((2, "entry"), (3, "control block + operands arrived"), (4, "partial tile reduced"), (5, "signalled")):
+        v = us(col)
+        print(f"           {what:34s} {v.min():6.2f}..{v.max():6.2f} (mean {v.mean():6.2f})")

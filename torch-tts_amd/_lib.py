@@ -7,7 +7,8 @@ import os
 import threading
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(HERE, "lib", "libttsdec.so")
+# (TTSDEC_LIB: another build of the same library, for same-box A/B measurements of two source states - tools/ only)
+LIB_PATH = os.environ.get("TTSDEC_LIB") or os.path.join(HERE, "lib", "libttsdec.so")
 
 # error codes / enums (mirrors include/ttsdec.h)
 OK = 0

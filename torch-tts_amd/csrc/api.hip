@@ -89,10 +89,6 @@ struct ttsdec_handle {
   bool proj_regw;         // mel/stop projection on the register-weight kernel where it applies (option "proj_regw")
   int opt_graph, opt_chunk_a, opt_chunk_b, opt_proj_regw;  // the options behind those four: -1 = default (on), 0, 1
   int head_proj;          // that projection as a role at the head of the NEXT step's frame launch: 1 / 0, -1 = by batch size; TTSDEC_HEAD_PROJ
-  int deep_ring;          // lean LSTM tile refilled one stage earlier (gemm_tile.h DEEP): 1 / 0, -1 = default
-  int fill_k;             // K elements of the decoder LSTM's h_dec(t-1) segment contracted by the attention LSTM's workgroups of
-                          // the step's FIRST launch (kernels.h LstmArgs::fill_k): multiple of 32, 0 = off, -1 = default
-  int query_regw;         // attention query on the register-weight GEMM kernel (frame_body.h proj_body): 1 / 0, -1 = default
   int profile_ablation;   // ttsdec_profile_step only: the kernels' dbg switches (measurement ablations)
   int debug_flags;        // test hooks, copied into Ctrl::debug_flags: bit 0 = the frame role does not signal, bit 1 = the attention
                           // role does not, bit 2 = the projection head role does not (drives the bounded-spin time-out path)
@@ -259,7 +255,7 @@ WsLayout make_ws_layout(const ttsdec_dims& d, int B, int Lm) {
   }
   W.jparts = take((size_t)kProjSplit * b * proj_ldp(d));
   W.pa = take(b * 4 * d.h_att);
-  W.pd = take(bp * 4 * d.h_dec);  // (also the parked accumulators of the filler contraction: whole 64-row tiles)
+  W.pd = take(b * 4 * d.h_dec);
   W.total = off;
   return W;
 }
@@ -368,8 +364,6 @@ bool split_ok(const ttsdec_dims& d) { return !((d.d_pre | d.d_ctx | d.h_att | d.
 // launch order of one step: the Prod cell attends between its two LSTMs, the Taco2 cell after both
 const StepOrder& step_order(const ttsdec_handle* h, int B);
 bool head_proj(const ttsdec_handle* h, int B);
-int filler_k(const ttsdec_handle* h, int B);
-int query_parts(const ttsdec_handle* h, int prec);
 int& option_ref(ttsdec_handle* h, int o);
 void apply_env_options(ttsdec_handle* h);
 void drop_graph(ttsdec_handle* h);
@@ -474,40 +468,13 @@ void launch_node(const ttsdec_handle* h, const StepBufs& sb, const StepIo& io, N
       a.K = k0 + D + H;
       a.dep_n = frame_grid_size(B, P); a.dep_seg = 2; a.dep_which = 0;
       a.live_lag = 1;  // (same launch as the frame kernel: see lstm_body)
-      if (const int kf = filler_k(h, B)) {
-        // filler: the leading kf columns of the DECODER LSTM's h_dec(t-1) segment (decoder_cell.py:191), on this launch's
-        // workgroups while they would wait for the frame role; the decoder LSTM of the step's last launch starts from the sums
-        const void *hd = prec ? (const void*)sb.h_dec_h[p] : sb.h_dec[p], *hdl = prec ? (const void*)sb.h_dec_l[p] : sb.h_dec[p];
-        const f16 *dh = plane(ck ? bl.dec_hh_ch : bl.dec_hh_h), *dl = plane(ck ? bl.dec_hh_cl : bl.dec_hh_l);
-        const int wld = ck ? Hd / kChunkK : Hd;
-        a.fa = act(make_seg1(hd, Hd, kf)); a.fa_lo = act(make_seg1(hdl, Hd, kf));
-        a.fw = make_seg1(prec ? (const void*)dh : (const void*)(blob + bl.dec_hh), wld, kf);
-        a.fw_lo = make_seg1(prec ? (const void*)dl : (const void*)(blob + bl.dec_hh), wld, kf);
-        if (ck) { a.fw.mpad = 1; a.fw_lo.mpad = 1; }
-        a.fill_k = kf; a.fill_out = sb.pd;
-      }
     } else if (part == PART_GATED) {
       // [h_att | h_dec | ctx]: ctx is written by the attention role of the same launch
-      const int kf = filler_k(h, B);  // leading columns of the h_dec segment already contracted by the step's first launch
-      if (kf >= H) {
-        a.a = act(make_seg2(x0, k0, k0, x1, D, D)); a.a_lo = act(make_seg2(x0l, k0, k0, x1l, D, D));
-        a.w = make_seg2(W0(false), wld_ih, k0, W1(false), wld_ih, D);
-        a.w_lo = make_seg2(W0(true), wld_ih, k0, W1(true), wld_ih, D);
-        a.dep_seg = 1;
-      } else {
-        // element offset of column kf: activation planes (chunked: whole chunks of all padded rows), weight planes (chunked:
-        // chunk kf / 32 of unit block 0), fp32 operands (row-major)
-        const size_t ao = prec ? (mpad > 0 ? (size_t)(kf / kChunkK) * mpad * kChunkK : (size_t)kf) : (size_t)kf;
-        const size_t wo = ck ? (size_t)kf * 64 : (size_t)kf;
-        auto offp = [&](const void* q, size_t o) { return prec ? (const void*)((const f16*)q + o) : (const void*)((const float*)q + o); };
-        a.a = act(make_seg3(x0, k0, k0, offp(x2, ao), H, H - kf, x1, D, D)); a.a_lo = act(make_seg3(x0l, k0, k0, offp(x2l, ao), H, H - kf, x1l, D, D));
-        a.w = make_seg3(W0(false), wld_ih, k0, offp(W2(false), wo), wld_hh, H - kf, W1(false), wld_ih, D);
-        a.w_lo = make_seg3(W0(true), wld_ih, k0, offp(W2(true), wo), wld_hh, H - kf, W1(true), wld_ih, D);
-        a.dep_seg = 2;
-      }
-      a.K = k0 + D + H - kf;
-      a.dep_n = B; a.dep_which = 1;
-      if (kf > 0) a.acc_init = sb.pd;
+      a.a = act(make_seg3(x0, k0, k0, x2, H, H, x1, D, D)); a.a_lo = act(make_seg3(x0l, k0, k0, x2l, H, H, x1l, D, D));
+      a.w = make_seg3(W0(false), wld_ih, k0, W2(false), wld_hh, H, W1(false), wld_ih, D);
+      a.w_lo = make_seg3(W0(true), wld_ih, k0, W2(true), wld_hh, H, W1(true), wld_ih, D);
+      a.K = k0 + D + H;
+      a.dep_n = B; a.dep_seg = 2; a.dep_which = 1;
     } else if (which == 0 ? part == PART_EARLY : part == PART_LATE) {
       // [ctx (| h_att)]: the attention LSTM's early part, or the decoder LSTM's late part (ctx alone)
       const int kh = which == 0 ? H : 0;
@@ -531,14 +498,13 @@ void launch_node(const ttsdec_handle* h, const StepBufs& sb, const StepIo& io, N
     a.h_out = which ? sb.h_dec[1 - p] : sb.h_att[1 - p];
     a.M = B; a.H = H; a.pz = d.p_zoneout; a.ctrl = ctrl; a.slot = io.slot; a.dbg = io.dbg;
     a.tag = which;
-    a.deep = h->deep_ring > 0;
     return a;
   };
   auto attn_args = [&]() {
     AttnArgs a;
     memset(&a, 0, sizeof(a));
     if (prec) { a.ctx_h = sb.ctx_h; a.ctx_l = sb.ctx_l; a.out_mpad = mpad; }
-    a.memory = io.memory; a.q = sb.q; a.q_parts = query_parts(h, prec); a.q_stride = (size_t)B * D;
+    a.memory = io.memory; a.q = sb.q; a.q_parts = query_split(d); a.q_stride = (size_t)B * D;
     a.w_prev = sb.w[p]; a.w_new = sb.w[1 - p]; a.w_out = io.w; a.ctx = sb.ctx;
     a.B = B; a.L = io.L; a.D = D; a.t_rel = io.t_rel; a.t_stride = io.t_stride; a.ctrl = ctrl; a.slot = io.slot;
     return a;
@@ -619,16 +585,6 @@ void launch_node(const ttsdec_handle* h, const StepBufs& sb, const StepIo& io, N
       }
       g.ksplit = query_split(d); g.kchunk = g.K / g.ksplit; g.split_stride = (size_t)B * D;
       g.ctrl = ctrl; g.slot = io.slot; g.t = io.t;
-      if (query_parts(h, prec) != query_split(d) || (prec && h->query_regw > 0 && proj_split(g.K) == g.ksplit)) {
-        // the same slabs from the register-weight kernel (frame_body.h proj_body)
-        ProjArgs pa;
-        memset(&pa, 0, sizeof(pa));
-        pa.a = g.a; pa.a_lo = g.a_lo; pa.W = g.W; pa.W_lo = g.W_lo; pa.ldw = g.ldw; pa.prec = g.prec;
-        pa.M = B; pa.N = D; pa.K = g.K; pa.ksplit = query_parts(h, prec); pa.split_stride = (size_t)B * D;
-        pa.out = sb.q; pa.ldo = D; pa.ctrl = ctrl; pa.slot = io.slot; pa.mode = PROJ_STEP;
-        launch_proj(pa, st);
-        break;
-      }
       launch_gemm(g, A_PLAIN, EPI_PLAIN, st);
       break;
     }
@@ -719,21 +675,6 @@ bool head_proj(const ttsdec_handle* h, int B) {
   if (!overlap_level(h, B) || !proj_regw(h, lstm_prec(h))) return false;
   return h->head_proj != 0;  // (-1 = default = on)
 }
-// The filler contraction (kernels.h LstmArgs::fill_k): both LSTMs on the 64 x 64 lean tile of the two-role launches with equal
-// grids (same hidden width, more than 64 utterances), every K tile whole.
-int filler_k(const ttsdec_handle* h, int B) {
-  const ttsdec_dims& d = h->d;
-  if (h->fill_k <= 0 || overlap_level(h, B) < 2 || d.h_att != d.h_dec || B <= 64 || (d.h_dec & 31)) return 0;
-  const int kf = h->fill_k & ~31;
-  return kf < d.h_dec ? kf : d.h_dec;
-}
-// slabs of the attention query: the register-weight kernel's own split where it serves the query, else the LDS-staged GEMM's
-int query_parts(const ttsdec_handle* h, int prec) {
-  const ttsdec_dims& d = h->d;
-  const int ps = proj_split(query_k(d));
-  if (prec && h->query_regw > 0 && ps > 0 && ps <= kQuerySplit && !((d.h_att | d.h_dec) & 7)) return ps;
-  return query_split(d);
-}
 const StepOrder& step_order(const ttsdec_handle* h, int B) {
   const ttsdec_dims& d = h->d;
   if (const int lv = overlap_level(h, B)) {
@@ -801,8 +742,8 @@ int ensure_graph(ttsdec_handle* h, const StepBufs& sb, const void* ws, int B, in
 
 
 // ---- options (include/ttsdec.h TTSDEC_OPT_*) ----
-const char* const kOptionNames[TTSDEC_OPT_COUNT] = {"graph", "overlap", "chunk_a", "chunk_b", "proj_regw", "head_proj", "deep_ring",
-                                                    "fill_k", "query_regw", "profile_ablation", "debug_flags", "spin_limit"};
+const char* const kOptionNames[TTSDEC_OPT_COUNT] = {"graph",     "overlap",          "chunk_a",     "chunk_b",   "proj_regw",
+                                                    "head_proj", "profile_ablation", "debug_flags", "spin_limit"};
 int& option_ref(ttsdec_handle* h, int o) {
   switch (o) {
     case TTSDEC_OPT_OVERLAP: return h->overlap;
@@ -810,9 +751,6 @@ int& option_ref(ttsdec_handle* h, int o) {
     case TTSDEC_OPT_CHUNK_B: return h->opt_chunk_b;
     case TTSDEC_OPT_PROJ_REGW: return h->opt_proj_regw;
     case TTSDEC_OPT_HEAD_PROJ: return h->head_proj;
-    case TTSDEC_OPT_DEEP_RING: return h->deep_ring;
-    case TTSDEC_OPT_FILL_K: return h->fill_k;
-    case TTSDEC_OPT_QUERY_REGW: return h->query_regw;
     case TTSDEC_OPT_PROFILE_ABLATION: return h->profile_ablation;
     case TTSDEC_OPT_DEBUG_FLAGS: return h->debug_flags;
     case TTSDEC_OPT_SPIN_LIMIT: return h->spin_limit;
@@ -1128,8 +1066,8 @@ int ttsdec_decode(ttsdec_handle* h, const float* memory, int B, int L, int t_beg
   const char* stamp_file = getenv("TTSDEC_STAMPS");
   ca.stamps = nullptr;
   if (stamp_file && *stamp_file) {
-    if (!g_stamps) { HIP_TRY(h, hipMalloc(&g_stamps, 2 * 1024 * 8 * sizeof(unsigned long long))); }
-    HIP_TRY(h, hipMemsetAsync(g_stamps, 0, 2 * 1024 * 8 * sizeof(unsigned long long), st));
+    if (!g_stamps) { HIP_TRY(h, hipMalloc(&g_stamps, kStampKinds * 1024 * 8 * sizeof(unsigned long long))); }
+    HIP_TRY(h, hipMemsetAsync(g_stamps, 0, kStampKinds * 1024 * 8 * sizeof(unsigned long long), st));
     ca.stamps = g_stamps;
   }
   launch_set_call(sb.ctrl, ca, st);
@@ -1154,7 +1092,7 @@ int ttsdec_decode(ttsdec_handle* h, const float* memory, int B, int L, int t_beg
   if (use_frame(d)) launch_node(h, sb, io, N_FIN, st);  // the last step's frame: y, s, stop rule, next input
   launch_finish(sb.ctrl, T_out, st);
   if (ca.stamps) {
-    std::string buf(2 * 1024 * 8 * sizeof(unsigned long long), '\0');
+    std::string buf(kStampKinds * 1024 * 8 * sizeof(unsigned long long), '\0');
     HIP_TRY(h, hipStreamSynchronize(st));
     HIP_TRY(h, hipMemcpy(&buf[0], ca.stamps, buf.size(), hipMemcpyDeviceToHost));
     if (FILE* f = fopen(stamp_file, "wb")) { fwrite(buf.data(), 1, buf.size(), f); fclose(f); }

@@ -53,7 +53,9 @@ struct Ctrl {
   int debug_flags, spin_limit;
   int pad[24];
 };
-// stamps[(kind * 1024 + block) * 8 + k]; kind 0 = frame || lstm_att, 1 = attention || lstm_dec;
+constexpr int kStampKinds = 3;
+// stamps[(kind * 1024 + block) * 8 + k]; kind 0 = frame || lstm_att, 1 = attention || lstm_dec, 2 = the projection role at the head of
+// kind 0's launch (k: 2 = entry, 3 = control block and operands arrived, 4 = partial tile reduced, 5 = signalled);
 // k: 0 = role << 32 | HW_ID, 1 = XCC_ID, 2 = start, 3 = gate reached, 4 = gate passed, 5 = end (s_memrealtime, 10 ns units)
 // `st` = Ctrl::stamps, loaded ONCE by the caller (stamps_of): a load in front of every stamp is a vector-memory wait in the
 // middle of the code being measured - and was, in the gate of the two-role launches, a microsecond on their critical path.
@@ -314,7 +316,8 @@ __device__ __forceinline__ void role_signal(unsigned int* counter) {
   if (threadIdx.x == 0) __hip_atomic_fetch_add(counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 constexpr int kRoleSpinLimit = 1 << 16;  // x ~0.45 us of s_sleep: ~30 ms, far beyond any producer's run time
-__device__ __forceinline__ void role_wait(const unsigned int* counter, unsigned int target, Ctrl* ctrl) {
+// the poll alone: for a consumer that takes every handed-off byte with sc1 loads (load_wt), or that only wants to know
+__device__ __forceinline__ void role_poll(const unsigned int* counter, unsigned int target, Ctrl* ctrl) {
   if (target == 0) return;
   int spins = 0;
   while (__hip_atomic_load(counter, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
@@ -324,9 +327,18 @@ __device__ __forceinline__ void role_wait(const unsigned int* counter, unsigned 
       break;
     }
   }
+}
+__device__ __forceinline__ void role_wait(const unsigned int* counter, unsigned int target, Ctrl* ctrl) {
+  if (target == 0) return;
+  role_poll(counter, target, ctrl);
   __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 }
+// A handed-off fp32 value read past this CU's vector L1 (global_load_dword sc1): with EVERY load of the handed-off bytes of
+// this form, every store of them write-through and drained before the counter add (role_signal), and the loads issued by the
+// polling wave after its poll matched and by the other waves after a workgroup barrier behind it, the consumer needs no
+// agent-scope acquire - 1.7 us less per hop (MI355X_MICROARCH.md, "Hand-offs measured with sc1 loads in place of the acquire").
+__device__ __forceinline__ float load_wt(const float* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 
 // Workgroup barrier for data exchanged through LDS: waits for this wave's LDS traffic only.  __syncthreads() also drains
 // the wave's outstanding GLOBAL loads and stores (s_waitcnt vmcnt(0)) - behind freshly issued stores that is a whole write

@@ -64,6 +64,7 @@ __device__ __forceinline__ void frame_body(FrameArgs g, float* lds, int bx, int 
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, l32 = lane & 31, half = lane >> 5;
   const int m0 = by * kFrameRows, n0 = bx * kFrameCols;
   const bool writer = bx == 0;
+  const unsigned long long t_entry = now_rt();  // (measurement only: stamped below)
 
   // ---- weight fragments (independent of the control block) ----
   // lane (n = l32, half) holds a contiguous K run of weight row n: [half*K0H, +K0H) for layer 0,
@@ -124,7 +125,11 @@ __device__ __forceinline__ void frame_body(FrameArgs g, float* lds, int bx, int 
         const bool ok = fm < g.M && n < NJ;
         const size_t idx = ok ? (size_t)fm * g.ldp + n : 0;
 #pragma unroll
-        for (int z = 0; z < kMaxParts; ++z) pz[i][z] = g.parts[z * g.part_stride + idx];
+        for (int z = 0; z < kMaxParts; ++z) {
+          // (head role's slabs: written by other workgroups of this very launch - sc1 loads, see the wait below)
+          if constexpr (kHead) pz[i][z] = load_wt(g.parts + z * g.part_stride + idx);
+          else pz[i][z] = g.parts[z * g.part_stride + idx];
+        }
         pbias[i] = g.proj_bias[ok ? n : 0];
       }
 #pragma unroll
@@ -175,8 +180,10 @@ __device__ __forceinline__ void frame_body(FrameArgs g, float* lds, int bx, int 
 
   if constexpr (kHead) {
     if (finalize && g.wait_n > 0 && g.ctrl != nullptr) {
-      // step t-1's projection is complete when (t - t_call) steps x wait_n workgroups have signalled
-      if (wave == 0) role_wait(&g.ctrl->dep_proj, (unsigned int)t_rel * (unsigned int)g.wait_n, g.ctrl);
+      // step t-1's projection is complete when (t - t_call) steps x wait_n workgroups have signalled.  No acquire: the slabs
+      // were stored write-through and drained before each signal (proj_body), and every load of them below is an sc1 load
+      // issued behind this poll (wave 0) or behind the barrier that wave 0 then joins (common.h load_wt)
+      if (wave == 0) role_poll(&g.ctrl->dep_proj, (unsigned int)t_rel * (unsigned int)g.wait_n, g.ctrl);
       lds_barrier();
     }
     load_parts();
@@ -186,6 +193,7 @@ __device__ __forceinline__ void frame_body(FrameArgs g, float* lds, int bx, int 
     stamp(st, 0, 0, __builtin_amdgcn_s_getreg((4 << 0) | (0 << 6) | (31 << 11)));
     stamp(st, 0, 1, __builtin_amdgcn_s_getreg((20 << 0) | (0 << 6) | (3 << 11)));
     stamp(st, 0, 2, now_rt());
+    stamp(st, 0, 7, t_entry);
   }
   // ---- epilogue operands of both PreNet layers, requested early ----
   // split-fp16 consumers read x_pre's planes, never its fp32 form: 4 columns per thread, one 8-byte store per plane - when the
@@ -518,6 +526,7 @@ __device__ __forceinline__ void proj_body(ProjArgs g, float* red, int id) {
   const int nx = (g.N + kProjTile - 1) / kProjTile, ny = (g.M + kProjTile - 1) / kProjTile;
   const int n0 = (id % nx) * kProjTile, m0 = ((id / nx) % ny) * kProjTile, z = id / (nx * ny);
   const int spw = g.K / (128 * g.ksplit);  // k16 steps per wave, <= kProjNS
+  const unsigned long long t_entry = now_rt();  // (measurement only: TTSDEC_STAMPS)
   // this lane's K run: slice z, the wave's share of it, the lane half's half of that - 8 * spw consecutive k
   const int kbeg = ((z * 8 + wave) * 2 + half) * spw * 8;
 
@@ -539,6 +548,27 @@ __device__ __forceinline__ void proj_body(ProjArgs g, float* red, int id) {
         if (j < 2 * spw) wf[j] = sf[j];
     }
   }
+  // ---- activations: row m0 + l32, the same K run (A and W only have to agree on which k a lane element means).  Requested
+  // BEFORE the control block is looked at, like the weights: they are the previous launch's outputs, and a wait for the
+  // control block is a wait for every load issued before it (one in-order queue) - with the activations behind that wait the
+  // role paid two memory round trips in series, each several us beside the LSTM role's tile stream ----
+  f16x8 ah[F16 ? kProjNS : 1], al[F16 ? kProjNS : 1];
+  f32x4 af[F16 ? 1 : 2 * kProjNS];
+  {
+    const int m = m0 + l32 < g.M ? m0 + l32 : g.M - 1;
+    if constexpr (F16) {
+#pragma unroll
+      for (int j = 0; j < kProjNS; ++j)
+        if (j < spw) {
+          ah[j] = *(gf16x8*)seg_elem_ptr<2>(g.a, m, kbeg + 8 * j);
+          al[j] = *(gf16x8*)seg_elem_ptr<2>(g.a_lo, m, kbeg + 8 * j);
+        }
+    } else {
+#pragma unroll
+      for (int j = 0; j < 2 * kProjNS; ++j)
+        if (j < 2 * spw) af[j] = *(gf32x4*)seg_elem_ptr<4>(g.a, m, kbeg + 4 * j);
+    }
+  }
   bool signal = false;
   if (g.ctrl != nullptr) {
     const Ctrl* c = g.ctrl;
@@ -552,19 +582,12 @@ __device__ __forceinline__ void proj_body(ProjArgs g, float* red, int id) {
     if (!live) return;
     signal = g.mode == PROJ_HEAD;
   }
+  const stamp_ptr st = signal ? stamps_of(g.ctrl) : (stamp_ptr) nullptr;
+  const unsigned long long t_ctrl = now_rt();
 
-  // ---- activations: row m0 + l32, the same K run (A and W only have to agree on which k a lane element means) ----
   f32x16 acc = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
   {
-    const int m = m0 + l32 < g.M ? m0 + l32 : g.M - 1;
     if constexpr (F16) {
-      f16x8 ah[kProjNS], al[kProjNS];
-#pragma unroll
-      for (int j = 0; j < kProjNS; ++j)
-        if (j < spw) {
-          ah[j] = *(gf16x8*)seg_elem_ptr<2>(g.a, m, kbeg + 8 * j);
-          al[j] = *(gf16x8*)seg_elem_ptr<2>(g.a_lo, m, kbeg + 8 * j);
-        }
       f32x16 acc2 = acc;
 #pragma unroll
       for (int j = 0; j < kProjNS; ++j)
@@ -576,10 +599,6 @@ __device__ __forceinline__ void proj_body(ProjArgs g, float* red, int id) {
 #pragma unroll
       for (int i = 0; i < 16; ++i) acc[i] = fmaf(acc2[i], 1.0f / kSplitScale, acc[i]);
     } else {
-      f32x4 af[2 * kProjNS];
-#pragma unroll
-      for (int j = 0; j < 2 * kProjNS; ++j)
-        if (j < 2 * spw) af[j] = *(gf32x4*)seg_elem_ptr<4>(g.a, m, kbeg + 4 * j);
 #pragma unroll
       for (int j = 0; j < 2 * kProjNS; ++j)
         if (j < 2 * spw) {
@@ -610,7 +629,16 @@ __device__ __forceinline__ void proj_body(ProjArgs g, float* red, int id) {
     if (signal) store_wt(slab + (size_t)m * g.ldo + n, v);  // read by the frame role of this very launch
     else slab[(size_t)m * g.ldo + n] = v;
   }
+  const unsigned long long t_red = now_rt();
   if (signal && !(g.ctrl->debug_flags & 4)) role_signal(&g.ctrl->dep_proj);
+  if (tid == 0 && st != nullptr) {
+    stamp(st, 2, 0, __builtin_amdgcn_s_getreg((4 << 0) | (0 << 6) | (31 << 11)));
+    stamp(st, 2, 1, __builtin_amdgcn_s_getreg((20 << 0) | (0 << 6) | (3 << 11)));
+    stamp(st, 2, 2, t_entry);
+    stamp(st, 2, 3, t_ctrl);
+    stamp(st, 2, 4, t_red);
+    stamp(st, 2, 5, now_rt());
+  }
 }
 
 

@@ -36,29 +36,25 @@ namespace ttsdec {
 //              has to share a CU and the LSTM keeps the stand-alone small-batch tile (128 KiB of LDS, three tiles in
 //              flight - a batch-1 LSTM is a pure weight stream and lives on bytes in flight; the lean tiles' 48 KiB
 //              took 16.4 us for the attention LSTM at B = 1 against 10.9 us).
-// DEEP: the ring refilled one stage earlier (gemm_tile.h): five tiles in flight out of five stages.
-template <int PREC, int DEEP>
+template <int PREC>
 struct LeanTiles;
-template <int DEEP>
-struct LeanTiles<PREC_F16S, DEEP> {
-  using Lean64x16 = TileCfg<2, 2, 1, 5, PREC_F16S, 0, 1, 1, 1, DEEP>;
-  using Lean64x8 = TileCfg<2, 1, 1, 5, PREC_F16S, 0, 1, 1, 1, DEEP>;
-  using SmallFat = TileCfg<1, 1, 2, 4, PREC_F16S, 0, 1, 1, 0, DEEP>;
+template <>
+struct LeanTiles<PREC_F16S> {
+  using Lean64x16 = TileCfg<2, 2, 1, 5, PREC_F16S, 0, 1, 1, 1>;
+  using Lean64x8 = TileCfg<2, 1, 1, 5, PREC_F16S, 0, 1, 1, 1>;
+  using SmallFat = TileCfg<1, 1, 2, 4, PREC_F16S>;
 };
-template <int DEEP>
-struct LeanTiles<PREC_F32, DEEP> {
-  using Lean64x16 = TileCfg<2, 2, 1, 5, PREC_F32, 0, 1, 1, 0, DEEP>;
-  using Lean64x8 = TileCfg<2, 1, 1, 5, PREC_F32, 0, 1, 1, 0, DEEP>;
-  using SmallFat = TileCfg<1, 1, 4, 4, PREC_F32, 0, 1, 1, 0, DEEP>;
+template <>
+struct LeanTiles<PREC_F32> {
+  using Lean64x16 = TileCfg<2, 2, 1, 5, PREC_F32>;
+  using Lean64x8 = TileCfg<2, 1, 1, 5, PREC_F32>;
+  using SmallFat = TileCfg<1, 1, 4, 4, PREC_F32>;
 };
 constexpr int kLean8MaxRows = 64;
 constexpr int kSmallFatMaxRows = 32;
-static_assert(LeanTiles<PREC_F16S, 0>::Lean64x16::kLdsBytes <= 80 * 1024 && LeanTiles<PREC_F32, 0>::Lean64x16::kLdsBytes <= 80 * 1024 &&
-                  LeanTiles<PREC_F16S, 0>::Lean64x8::kLdsBytes <= 80 * 1024 && LeanTiles<PREC_F32, 0>::Lean64x8::kLdsBytes <= 80 * 1024,
+static_assert(LeanTiles<PREC_F16S>::Lean64x16::kLdsBytes <= 80 * 1024 && LeanTiles<PREC_F32>::Lean64x16::kLdsBytes <= 80 * 1024 &&
+                  LeanTiles<PREC_F16S>::Lean64x8::kLdsBytes <= 80 * 1024 && LeanTiles<PREC_F32>::Lean64x8::kLdsBytes <= 80 * 1024,
               "lean tiles: two workgroups per CU");
-// the filler contraction (LstmArgs::fill_k) exists on the 64 x 64 lean tile only: one MFMA wave layout in both launches
-template <class Cfg>
-constexpr bool is_lean64x16() { return Cfg::BM == 64 && Cfg::BN == 64 && Cfg::kWK == 1 && !Cfg::kBig; }
 
 template <int A, int B>
 constexpr int cmax() { return A > B ? A : B; }
@@ -88,7 +84,7 @@ __global__ __launch_bounds__(kGemmThreads, WPE) void frame_lstm_kernel(FrameArgs
     frame_body<K0H, PH, PREC, 6, WPE == 4, kHead>(f, smem, id % frame_cols, id / frame_cols);
   } else {
     const int j = id - n_frame;
-    lstm_body<Cfg, true, true, is_lean64x16<Cfg>()>(l, smem, j % lstm_cols, j / lstm_cols);
+    lstm_body<Cfg, true, true>(l, smem, j % lstm_cols, j / lstm_cols);
   }
 }
 
@@ -102,7 +98,7 @@ __global__ __launch_bounds__(kGemmThreads, WPE) void attn_lstm_kernel(AttnArgs a
     attn_body<NJ>(a, smem, id);
   } else {
     const int j = id - n_attn;
-    lstm_body<Cfg, true, true, is_lean64x16<Cfg>()>(l, smem, j % lstm_cols, j / lstm_cols);
+    lstm_body<Cfg, true, true>(l, smem, j % lstm_cols, j / lstm_cols);
   }
 }
 
@@ -110,7 +106,7 @@ __global__ __launch_bounds__(kGemmThreads, WPE) void attn_lstm_kernel(AttnArgs a
 template <class Cfg>
 __global__ __launch_bounds__(kGemmThreads, 4) void lstm_lean_kernel(LstmArgs l) {
   __shared__ __attribute__((aligned(16))) float smem[Cfg::kLdsFloats];
-  lstm_body<Cfg, false, false, is_lean64x16<Cfg>()>(l, smem, blockIdx.x, blockIdx.y);
+  lstm_body<Cfg, false>(l, smem, blockIdx.x, blockIdx.y);
 }
 
 static_assert(kFrameThreads == kGemmThreads && kAttnThreads == kGemmThreads, "roles share one block size");
@@ -129,9 +125,9 @@ static LeanKind lean_kind(int M, int n_producer, int H) {
   return M <= kLean8MaxRows ? LEAN_64x8 : LEAN_64x16;
 }
 
-template <int K0H, int PH, int PREC, bool kHead, int DEEP>
+template <int K0H, int PH, int PREC, bool kHead>
 static void launch_frame_lstm_ph(const FrameArgs& f, const LstmArgs& l, const ProjArgs& pj, hipStream_t st) {
-  using TL = LeanTiles<PREC, DEEP>;
+  using TL = LeanTiles<PREC>;
   const int fcols = (f.P + kFrameCols - 1) / kFrameCols, frows = (f.M + kFrameRows - 1) / kFrameRows;
   const int n_frame = fcols * frows, n_proj = kHead ? proj_grid_size(pj.M, pj.N, pj.ksplit) : 0;
   const LeanKind kind = lean_kind(l.M, n_proj + n_frame, l.H);
@@ -149,13 +145,8 @@ template <bool kHead>
 static void launch_frame_lstm_any(const FrameArgs& f, const LstmArgs& l, const ProjArgs& pj, hipStream_t st) {
   if (f.M <= 0) return;
   const bool f16 = l.prec == 1;
-  auto go = [&](auto deep) {
-    constexpr int DEEP = decltype(deep)::value;
-    if (f.Ph == 256) { if (f16) launch_frame_lstm_ph<40, 256, PREC_F16S, kHead, DEEP>(f, l, pj, st); else launch_frame_lstm_ph<40, 256, PREC_F32, kHead, DEEP>(f, l, pj, st); }
-    else { if (f16) launch_frame_lstm_ph<40, 128, PREC_F16S, kHead, DEEP>(f, l, pj, st); else launch_frame_lstm_ph<40, 128, PREC_F32, kHead, DEEP>(f, l, pj, st); }
-  };
-  if (l.deep) go(std::integral_constant<int, 1>{});
-  else go(std::integral_constant<int, 0>{});
+  if (f.Ph == 256) { if (f16) launch_frame_lstm_ph<40, 256, PREC_F16S, kHead>(f, l, pj, st); else launch_frame_lstm_ph<40, 256, PREC_F32, kHead>(f, l, pj, st); }
+  else { if (f16) launch_frame_lstm_ph<40, 128, PREC_F16S, kHead>(f, l, pj, st); else launch_frame_lstm_ph<40, 128, PREC_F32, kHead>(f, l, pj, st); }
 }
 void launch_frame_lstm(const FrameArgs& f, const LstmArgs& l, hipStream_t st) {
   ProjArgs none;
@@ -164,9 +155,9 @@ void launch_frame_lstm(const FrameArgs& f, const LstmArgs& l, hipStream_t st) {
 }
 void launch_proj_frame_lstm(const ProjArgs& pj, const FrameArgs& f, const LstmArgs& l, hipStream_t st) { launch_frame_lstm_any<true>(f, l, pj, st); }
 
-template <int NJ, int PREC, int DEEP>
+template <int NJ, int PREC>
 static void launch_attn_lstm_nj(const AttnArgs& a, const LstmArgs& l, hipStream_t st) {
-  using TL = LeanTiles<PREC, DEEP>;
+  using TL = LeanTiles<PREC>;
   const LeanKind kind = lean_kind(l.M, a.B, l.H);
   const int lcols = kind == LEAN_64x16 ? (l.H + 15) / 16 : (l.H + 7) / 8;
   const int lrows = kind == SMALL_FAT ? (l.M + 31) / 32 : (l.M + 63) / 64;
@@ -178,31 +169,21 @@ static void launch_attn_lstm_nj(const AttnArgs& a, const LstmArgs& l, hipStream_
 void launch_attn_lstm(const AttnArgs& a, const LstmArgs& l, hipStream_t st) {
   if (a.B <= 0) return;
   const bool f16 = l.prec == 1;
-  auto go = [&](auto deep) {
-    constexpr int DEEP = decltype(deep)::value;
-    if (a.D / 4 <= 64) { if (f16) launch_attn_lstm_nj<1, PREC_F16S, DEEP>(a, l, st); else launch_attn_lstm_nj<1, PREC_F32, DEEP>(a, l, st); }
-    else { if (f16) launch_attn_lstm_nj<2, PREC_F16S, DEEP>(a, l, st); else launch_attn_lstm_nj<2, PREC_F32, DEEP>(a, l, st); }
-  };
-  if (l.deep) go(std::integral_constant<int, 1>{});
-  else go(std::integral_constant<int, 0>{});
+  if (a.D / 4 <= 64) { if (f16) launch_attn_lstm_nj<1, PREC_F16S>(a, l, st); else launch_attn_lstm_nj<1, PREC_F32>(a, l, st); }
+  else { if (f16) launch_attn_lstm_nj<2, PREC_F16S>(a, l, st); else launch_attn_lstm_nj<2, PREC_F32>(a, l, st); }
 }
 
 void launch_lstm_lean(const LstmArgs& l, hipStream_t st) {
   if (l.M <= 0) return;
   const bool small = l.M <= kLean8MaxRows;
   dim3 grid(small ? (l.H + 7) / 8 : (l.H + 15) / 16, (l.M + 63) / 64), block(kGemmThreads);
-  auto go = [&](auto deep) {
-    constexpr int DEEP = decltype(deep)::value;
-    if (l.prec == 1) {
-      if (small) hipLaunchKernelGGL((lstm_lean_kernel<typename LeanTiles<PREC_F16S, DEEP>::Lean64x8>), grid, block, 0, st, l);
-      else hipLaunchKernelGGL((lstm_lean_kernel<typename LeanTiles<PREC_F16S, DEEP>::Lean64x16>), grid, block, 0, st, l);
-    } else {
-      if (small) hipLaunchKernelGGL((lstm_lean_kernel<typename LeanTiles<PREC_F32, DEEP>::Lean64x8>), grid, block, 0, st, l);
-      else hipLaunchKernelGGL((lstm_lean_kernel<typename LeanTiles<PREC_F32, DEEP>::Lean64x16>), grid, block, 0, st, l);
-    }
-  };
-  if (l.deep) go(std::integral_constant<int, 1>{});
-  else go(std::integral_constant<int, 0>{});
+  if (l.prec == 1) {
+    if (small) hipLaunchKernelGGL((lstm_lean_kernel<LeanTiles<PREC_F16S>::Lean64x8>), grid, block, 0, st, l);
+    else hipLaunchKernelGGL((lstm_lean_kernel<LeanTiles<PREC_F16S>::Lean64x16>), grid, block, 0, st, l);
+  } else {
+    if (small) hipLaunchKernelGGL((lstm_lean_kernel<LeanTiles<PREC_F32>::Lean64x8>), grid, block, 0, st, l);
+    else hipLaunchKernelGGL((lstm_lean_kernel<LeanTiles<PREC_F32>::Lean64x16>), grid, block, 0, st, l);
+  }
 }
 
 }  // namespace ttsdec

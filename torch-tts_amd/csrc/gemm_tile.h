@@ -51,13 +51,8 @@ namespace ttsdec {
 // HK = 1 with TM = TN = 1 is the "lean" 64x64 tile (16 KiB stages of 32 k, fragments still read one tile
 // ahead: <= 80 KiB of LDS and <= 128 VGPRs), built so that TWO workgroups fit a CU - the tile of the LSTMs
 // that run beside another role's workgroups in one launch (fused_kernels.hip).
-// DEEP = 1 (small tiles): the ring is refilled one stage earlier - tile t + S goes into the stage of tile t as soon as every
-// MFMA wave holds tile t's fragments in registers (they are read a whole tile ahead), instead of tile t + S - 1 into the
-// stage tile t - 1 left: S tiles in flight out of S stages.  The lean tile (5 x 16 KiB) is bound by its bytes in flight.
-template <int WM, int WN, int WK, int S, int PREC = PREC_F32, int AUXB = 0, int TM = 1, int TN = 1, int HK = 0, int DEEP = 0>
+template <int WM, int WN, int WK, int S, int PREC = PREC_F32, int AUXB = 0, int TM = 1, int TN = 1, int HK = 0>
 struct TileCfg {
-  static constexpr int kDeep = DEEP;
-  static_assert(!DEEP || TM * TN == 1, "deep refill: small tiles only");
   static constexpr int kAuxB = AUXB;  // cache-policy bits of the B (weight) operand's LDS-DMA: 2 = nt (streamed once)
   static constexpr int NMW = WM * WN * WK;  // active MFMA waves (of the 4 in the workgroup)
   static constexpr int kWM = WM, kWN = WN, kWK = WK, kTM = TM, kTN = TN;
@@ -98,9 +93,8 @@ struct TileCfg {
   static constexpr int kLdsBytes = kRingAll > kOutBytes ? kRingAll : kOutBytes;
   static constexpr int kLdsFloats = kLdsBytes / 4;
   // loads left in flight when the tile whose fragments are read NEXT (one ahead of the MFMAs) has landed
-  static constexpr int kWaitCnt = (kBig ? S - 2 : S - 3 + DEEP) * NLOADS;
-  static constexpr int kPrologueTiles = S - 1 + DEEP;
-  static_assert((S - 2 + DEEP) * NLOADS <= 63 && (S - 1 + DEEP) * NLOADS <= 63, "vmcnt field");
+  static constexpr int kWaitCnt = (kBig ? S - 2 : S - 3) * NLOADS;
+  static_assert((S - 2) * NLOADS <= 63, "vmcnt field");
   static_assert(kLdsBytes <= 160 * 1024, "LDS per workgroup");
   // 16-byte column swizzle: rows are packed 256/ROWB to an LDS bank row; the 16 lanes of a ds_read_b128
   // group (16 consecutive rows, same column) must land in 16 distinct 16-byte slots
@@ -143,28 +137,20 @@ __device__ __forceinline__ void wait_vmcnt() {
 // Cfg::LDO, summed over the WK slices, visible to all threads.
 // Gate (optional): gate.seg is the index of a K segment whose A operand is produced by OTHER workgroups of the
 // same launch.  Right before the first tile of that segment is issued, ONE wave (the first loader wave) calls
-// gate.wait() - poll + acquire, which invalidates this CU's vector L1 for everybody - and the whole workgroup
-// crosses one extra barrier, so no wave loads the segment earlier.  (One poller per workgroup: 1024 waves
+// gate.wait() - the poll; with kAuxA = 0 also an agent-scope acquire, which invalidates this CU's vector L1 for
+// everybody - and the whole workgroup crosses one extra barrier, so no wave loads the segment earlier.  (One poller per workgroup: 1024 waves
 // polling one counter saturated its memory channel and slowed the producers - 110 vs 88 us per step.)
 // gate.seg = -1: no gate.
+// kAuxA: cache policy of the A operand's LDS-DMA (16 = sc1: past this CU's vector L1, for operands handed over inside the launch).
 struct NoGate {
+  static constexpr int kAuxA = 0;
   int seg = -1;
   __device__ __forceinline__ void wait() const {}
 };
 
-// Accumulators in and out of a small tile (WK = 1), in the MFMA's own lane layout: block[((wave * 4 + r4) * 64 + lane) * 4 + e]
-// is accumulator register 4 * r4 + e of that lane - 16 bytes per lane, 1 KiB per wave instruction, 16 KiB per 64 x 64 tile.
-// init != nullptr: the accumulators start from that block instead of zero (the part of the contraction an EARLIER launch
-// already did: the same tile shape there, hence the same layout).  store != nullptr: the finished accumulators go to that
-// block and the LDS out tile is not written.
-struct AccIo {
-  const float* init = nullptr;
-  float* store = nullptr;
-};
-
 template <class Cfg, class LoaderA, class LoaderB, class Gate = NoGate>
 __device__ __forceinline__ void gemm_tile(const LoaderA& la, const LoaderB& lb, float* smem, bool live = true,
-                                          int dbg = 0, const Gate gate = Gate(), const AccIo aio = AccIo()) {
+                                          int dbg = 0, const Gate gate = Gate()) {
   // `live` (does this launch have anything to do?) typically comes from a control-block load
   // that is still in flight: it is first looked at AFTER the loader waves have issued their
   // prologue DMAs, so its latency hides under theirs.  A dead launch drains and falls through.
@@ -191,8 +177,7 @@ __device__ __forceinline__ void gemm_tile(const LoaderA& la, const LoaderB& lb, 
     if (wave8 == 4) gate.wait();
     __builtin_amdgcn_s_barrier();
   };
-  constexpr int PT = Cfg::kPrologueTiles;  // tiles in flight before the loop; in the loop tile t + PT is issued at step t
-  if (gate_tile >= 0 && gate_tile < PT) gate_sync();  // (the segment starts inside the prologue tiles)
+  if (gate_tile >= 0 && gate_tile < S - 1) gate_sync();  // (the segment starts inside the prologue tiles)
 
   f32x16 acc, acc2;
 #pragma unroll
@@ -205,15 +190,6 @@ __device__ __forceinline__ void gemm_tile(const LoaderA& la, const LoaderB& lb, 
   const int wm = wave / (WK_ * WN_);
   const int half = lane >> 5;
   const int l32 = lane & 31;
-  if (aio.init != nullptr && live && !is_loader && wave < Cfg::NMW) {
-    const f32x4* src = reinterpret_cast<const f32x4*>(aio.init) + wave * 4 * 64 + lane;
-#pragma unroll
-    for (int r4 = 0; r4 < 4; ++r4) {
-      const f32x4 v = src[r4 * 64];
-#pragma unroll
-      for (int e = 0; e < 4; ++e) acc[4 * r4 + e] = v[e];
-    }
-  }
 
   if (is_loader) {
     // =========================== loader waves ===========================
@@ -274,7 +250,9 @@ __device__ __forceinline__ void gemm_tile(const LoaderA& la, const LoaderB& lb, 
             ptr = (partial && kpos + ca[i] >= seg_len) ? zero_addr() : ptr;
           char* dst = st + p * Cfg::kPlaneABytes + (wave * NA + i) * 1024;
           if (Cfg::kDummy && (wave * NA + i) * 1024 >= Cfg::kPlaneABytes) dst = lds + Cfg::kDummyOff + wave * 1024;
-          __builtin_amdgcn_global_load_lds((global_void*)ptr, (lds_void*)dst, 16, 0, 0);
+          // (size and cache-policy arguments of the builtin must be literals)
+          if constexpr (Gate::kAuxA == 16) __builtin_amdgcn_global_load_lds((global_void*)ptr, (lds_void*)dst, 16, 0, 16);
+          else __builtin_amdgcn_global_load_lds((global_void*)ptr, (lds_void*)dst, 16, 0, 0);
           cura[p][i] += inca[i];
         }
       }
@@ -321,21 +299,21 @@ __device__ __forceinline__ void gemm_tile(const LoaderA& la, const LoaderB& lb, 
       }
     };
 
-    // tiles 0 .. PT-1 in flight
+    // tiles 0 .. S-2 in flight
 #pragma unroll
-    for (int t = 0; t < PT; ++t) issue_tile();
+    for (int t = 0; t < S - 1; ++t) issue_tile();
     const int nk_run = live ? nk : 0;
     if (live && !Cfg::kBig) {
-      wait_vmcnt<(PT - 1) * Cfg::NLOADS>();  // tile 0 landed
-      __builtin_amdgcn_s_barrier();          // B0
+      wait_vmcnt<(S - 2) * Cfg::NLOADS>();  // tile 0 landed
+      __builtin_amdgcn_s_barrier();         // B0
     }
     for (int t = 0; t < nk_run; ++t) {
       // small tiles: this wave's part of tile t+1 has landed (fragments are read one tile ahead);
       // big tiles: tile t has landed (fragments are read right after this barrier)
       wait_vmcnt<Cfg::kWaitCnt>();
-      __builtin_amdgcn_s_barrier();       // the MFMA waves are done reading the stage tile t-1 (deep refill: tile t) occupied
-      if (t + PT == gate_tile) gate_sync();
-      if (dbg != 3) issue_tile();         // tile t+PT into that stage (dbg 3: measurement ablation)
+      __builtin_amdgcn_s_barrier();       // the MFMA waves are done reading the stage tile t-1 occupied
+      if (t + S - 1 == gate_tile) gate_sync();
+      if (dbg != 3) issue_tile();         // tile t+S-1 into that stage (dbg 3: measurement ablation)
     }
     wait_vmcnt<0>();  // trailing zero-block loads must land before the ring is reused
   } else {
@@ -348,7 +326,7 @@ __device__ __forceinline__ void gemm_tile(const LoaderA& la, const LoaderB& lb, 
         __builtin_amdgcn_s_barrier();
         for (int t = 0; t < nk; ++t) {
           __builtin_amdgcn_s_barrier();
-          if (t + PT == gate_tile) gate_sync();
+          if (t + S - 1 == gate_tile) gate_sync();
         }
       }
     } else if constexpr (Cfg::kBig) {
@@ -379,7 +357,7 @@ __device__ __forceinline__ void gemm_tile(const LoaderA& la, const LoaderB& lb, 
       const int nk_run = live ? nk : 0;
       for (int t = 0; t < nk_run; ++t) {
         __builtin_amdgcn_s_barrier();  // tile t is in LDS
-        if (t + PT == gate_tile) gate_sync();
+        if (t + S - 1 == gate_tile) gate_sync();
         const char* st = lds + rstage * Cfg::kStageBytes;
         rstage = (rstage + 1 == S) ? 0 : rstage + 1;
         f16x8 ah[TM][NS], al[TM][NS], bh[TN][NS], bl[TN][NS];
@@ -458,13 +436,11 @@ __device__ __forceinline__ void gemm_tile(const LoaderA& la, const LoaderB& lb, 
       };
       auto tile_step = [&](auto cur_c, int t) {
         constexpr int cur = decltype(cur_c)::value;
-        // tile t's fragments were requested a whole tile ago: retire them (no stall), in a form the compiler's
-        // wait-count model sees, so it does not later drain the next reads.  Deep refill: BEFORE the barrier, because
-        // behind it the loaders overwrite tile t's stage.
-        if constexpr (Cfg::kDeep) __builtin_amdgcn_s_waitcnt(0xC07F);  // lgkmcnt(0) only
         __builtin_amdgcn_s_barrier();        // B(t+1): tile t+1 is in LDS
-        if (t + PT == gate_tile) gate_sync();
-        if constexpr (!Cfg::kDeep) __builtin_amdgcn_s_waitcnt(0xC07F);
+        if (t + S - 1 == gate_tile) gate_sync();
+        // tile t's fragments were requested a whole tile ago: retire them here (no stall), in a
+        // form the compiler's wait-count model sees, so it does not later drain the next reads
+        __builtin_amdgcn_s_waitcnt(0xC07F);  // lgkmcnt(0) only
         read_frags(std::integral_constant<int, cur ^ 1>{});
         __builtin_amdgcn_sched_barrier(0);
         if (dbg != 4) {  // dbg 4: measurement ablation (no MFMAs)
@@ -512,10 +488,9 @@ __device__ __forceinline__ void gemm_tile(const LoaderA& la, const LoaderB& lb, 
       };
       auto tile_step = [&](auto cur_c, int t) {
         constexpr int cur = decltype(cur_c)::value;
-        if constexpr (Cfg::kDeep) __builtin_amdgcn_s_waitcnt(0xC07F);  // lgkmcnt(0) only (see the fp32 path)
         __builtin_amdgcn_s_barrier();
-        if (t + PT == gate_tile) gate_sync();
-        if constexpr (!Cfg::kDeep) __builtin_amdgcn_s_waitcnt(0xC07F);
+        if (t + S - 1 == gate_tile) gate_sync();
+        __builtin_amdgcn_s_waitcnt(0xC07F);  // lgkmcnt(0) only (see the fp32 path)
         read_frags(std::integral_constant<int, cur ^ 1>{});
         // Interleave the next tile's fragment reads with this tile's MFMAs (two ds_read_b128 per MFMA gap are
         // nearly free, MI355X_MICROARCH.md LDS section).  With all reads pinned in front of the chain the
@@ -571,24 +546,11 @@ __device__ __forceinline__ void gemm_tile(const LoaderA& la, const LoaderB& lb, 
   // accumulators -> LDS out tile (aliases the ring).
   // C/D map of the 32x32 MFMA: col = lane & 31, row = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5).
   if (!Cfg::kBig && !is_loader && wave < Cfg::NMW) {
-    if (aio.store != nullptr) {
-      if (live) {
-        f32x4* dst = reinterpret_cast<f32x4*>(aio.store) + wave * 4 * 64 + lane;
+    float* out = smem + wk * BM * LDO;
 #pragma unroll
-        for (int r4 = 0; r4 < 4; ++r4) {
-          f32x4 v;
-#pragma unroll
-          for (int e = 0; e < 4; ++e) v[e] = acc[4 * r4 + e];
-          dst[r4 * 64] = v;
-        }
-      }
-    } else {
-      float* out = smem + wk * BM * LDO;
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int row = wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
-        out[row * LDO + wn * 32 + l32] = acc[r];
-      }
+    for (int r = 0; r < 16; ++r) {
+      const int row = wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+      out[row * LDO + wn * 32 + l32] = acc[r];
     }
   }
   __syncthreads();

@@ -109,16 +109,6 @@ struct LstmArgs {
   // Two-role launch: K segment dep_seg of the A operand is produced by the other role's dep_n workgroups of this
   // very launch (dep_which 0: frame kernel -> Ctrl::dep_frame, 1: attention -> Ctrl::dep_attn); dep_n = 0: no gate.
   int dep_n, dep_seg, dep_which;
-  // Filler (lean 64 x 64 tile of the two-role launches only).  fill_k > 0: BEFORE its own cell this workgroup contracts
-  // fa x fw (fill_k elements of K: a leading part of ANOTHER cell's K axis whose operands are ready - the decoder LSTM's
-  // h_dec(t-1) segment, run by the attention LSTM's workgroups while they would otherwise wait for the frame role) and
-  // parks the raw accumulators of its 64 x 64 tile in fill_out (gemm_tile.h AccIo layout, 4096 floats per workgroup).
-  // acc_init != nullptr: this cell's accumulators start from such parked sums instead of zero.
-  Seg3 fa, fa_lo, fw, fw_lo;
-  int fill_k;
-  int deep;  // lean tile: refill the LDS ring one stage earlier (gemm_tile.h TileCfg DEEP)
-  float* fill_out;
-  const float* acc_init;
 };
 void launch_lstm(const LstmArgs& a, hipStream_t st);
 void launch_lstm_pair(const LstmArgs& a0, const LstmArgs& a1, hipStream_t st);  // two same-shape fp32 cells, one launch

@@ -58,7 +58,14 @@ struct LoaderWLstm {
 };
 
 // smem: Cfg::kLdsFloats floats of LDS (the caller's ONE shared array); (bx, by): unit block / row block.
-struct RoleGate {
+// SC1 (the LSTM roles of the two-role launches): every A-operand tile is taken by sc1 LDS-DMA - past this CU's vector L1, served
+// by L2 / the fabric - so the gate is the poll alone: the producers store the handed-off planes write-through and drain them
+// before they signal (role_signal), the polling wave issues its loads behind its poll and the other waves behind the
+// barrier it then joins (gemm_tile gate_sync).  The agent-scope acquire it replaces (buffer_inv sc1 + the wait for it) took
+// the critical path of both launches 1-2.5 us per step (time stamps: gate reached -> passed).
+template <bool SC1>
+struct RoleGateT {
+  static constexpr int kAuxA = SC1 ? 16 : 0;
   int seg;
   const unsigned int* counter;
   unsigned int target;
@@ -67,7 +74,8 @@ struct RoleGate {
   stamp_ptr st;  // (loaded by the caller, once: see common.h stamp)
   __device__ __forceinline__ void wait() const {
     stamp(st, kind, 3, now_rt());
-    role_wait(counter, target, ctrl);
+    if constexpr (SC1) role_poll(counter, target, ctrl);
+    else role_wait(counter, target, ctrl);
     stamp(st, kind, 4, now_rt());
   }
 };
@@ -76,9 +84,7 @@ struct RoleGate {
 // requests them after it instead - 20 live registers fewer across the loop, to stay within 128 VGPRs.
 // kWhole: the caller only ever runs whole cells (mode 0, no sequence mode): the parked partial sums and their registers
 // drop out, which is what lets the lean tile of the two-role launches request the rest of the operands early.
-// kFill: the kernel may be asked to run a filler contraction first (LstmArgs::fill_k) or to start from parked accumulators
-// (LstmArgs::acc_init): the 64 x 64 lean tile of the two-role launches.
-template <class Cfg, bool kEarlyEpi = true, bool kWhole = false, bool kFill = false>
+template <class Cfg, bool kEarlyEpi = true, bool kWhole = false>
 __device__ __forceinline__ void lstm_body(LstmArgs g, float* smem, int bx, int by) {
   if constexpr (kWhole) { g.mode = 0; g.seq_lens = nullptr; g.seq_out = nullptr; }
   bool live = true;
@@ -122,20 +128,11 @@ __device__ __forceinline__ void lstm_body(LstmArgs g, float* smem, int bx, int b
     ph[j] = ok ? g.h_prev[idx] : 0.f;
   }
   };
-  const int acc_blk = (by * ((H + BU - 1) / BU) + bx) * (BM * BN);  // this tile's block of parked accumulators (AccIo)
-  if constexpr (kFill) if (g.fill_k > 0) {
-    // filler: part of another cell's contraction on this workgroup's tile coordinates, accumulators parked in fill_out
-    const LoaderPlain<EB> fa{g.fa, g.fa_lo, m0, g.M};
-    const LoaderWLstm<BU, EB> fb{g.fw, g.fw_lo, u0, g.H};
-    AccIo park;
-    park.store = g.fill_out + acc_blk;
-    gemm_tile<Cfg>(fa, fb, smem, live, g.dbg, NoGate(), park);
-  }
   if constexpr (kEarlyEpi) load_epi();
 
   const LoaderPlain<EB> la{g.a, g.a_lo, m0, g.M};
   const LoaderWLstm<BU, EB> lb{g.w, g.w_lo, u0, g.H};
-  RoleGate gate;
+  RoleGateT<kWhole> gate;  // (kWhole = a role of a two-role launch)
   const stamp_ptr st = g.dep_n > 0 ? stamps_of(g.ctrl) : (stamp_ptr) nullptr;  // measurement only (TTSDEC_STAMPS)
   gate.seg = -1; gate.counter = nullptr; gate.target = 0; gate.ctrl = g.ctrl; gate.kind = g.dep_which; gate.st = st;
   if (threadIdx.x == 0) {
@@ -150,11 +147,7 @@ __device__ __forceinline__ void lstm_body(LstmArgs g, float* smem, int bx, int b
       gate.target = (unsigned int)(g.ctrl->t_cur + g.slot - g.ctrl->t_call + 1) * (unsigned int)g.dep_n;
     }
   }
-  AccIo aio;
-  if constexpr (kFill) {
-    if (g.acc_init != nullptr) aio.init = g.acc_init + acc_blk;
-  }
-  gemm_tile<Cfg>(la, lb, smem, live, g.dbg, gate, aio);
+  gemm_tile<Cfg>(la, lb, smem, live, g.dbg, gate);
   if (!live) return;
   if constexpr (!kEarlyEpi) load_epi();
 
