@@ -57,6 +57,7 @@ struct WsLayout {  // offsets in bytes
   size_t xpre_h, xpre_l, ctx_h, ctx_l, h_att_h[2], h_att_l[2], h_dec_h[2], h_dec_l[2];  // split-fp16 planes
   size_t jparts;  // split-K partial sums of the mel/stop projection [kProjSplit][B, proj_ldp]
   size_t pa, pd;  // fp32 partial gate sums [B, 4H] of the two LSTMs' early parts (two-role step)
+  size_t dep, dep_bytes;  // arrival counters of the two-role launches: [DEP_KINDS][32-row blocks][kDepLine] (common.h)
   size_t total;
 };
 
@@ -256,6 +257,8 @@ WsLayout make_ws_layout(const ttsdec_dims& d, int B, int Lm) {
   W.jparts = take((size_t)kProjSplit * b * proj_ldp(d));
   W.pa = take(b * 4 * d.h_att);
   W.pd = take(b * 4 * d.h_dec);
+  W.dep_bytes = (size_t)DEP_KINDS * ((B + 31) / 32) * kDepLine * sizeof(unsigned int);
+  W.dep = take(W.dep_bytes / sizeof(float));
   W.total = off;
   return W;
 }
@@ -303,6 +306,8 @@ struct StepBufs {
   f16 *xpre_h, *xpre_l, *ctx_h, *ctx_l, *h_att_h[2], *h_att_l[2], *h_dec_h[2], *h_dec_l[2];
   float* jparts;
   float *pa, *pd;
+  unsigned int* dep;
+  int dep_blocks;  // 32-row blocks of the batch: dep + kind * dep_blocks * kDepLine is a hand-off kind's counter array
 };
 
 StepBufs carve(const WsLayout& W, void* ws) {
@@ -322,6 +327,8 @@ StepBufs carve(const WsLayout& W, void* ws) {
   }
   s.jparts = f(W.jparts);
   s.pa = f(W.pa); s.pd = f(W.pd);
+  s.dep = reinterpret_cast<unsigned int*>(p + W.dep);
+  s.dep_blocks = (int)(W.dep_bytes / (DEP_KINDS * kDepLine * sizeof(unsigned int)));
   return s;
 }
 
@@ -396,6 +403,7 @@ void launch_node(const ttsdec_handle* h, const StepBufs& sb, const StepIo& io, N
   // chunked operand layout of the split-fp16 planes (0 = row-major)
   const int mpad = (prec && chunk_ok(d) && h->chunk_a) ? rows_pad(B) : 0;
   auto act = [&](Seg3 s) { return chunked(s, mpad); };  // an activation-plane segment list in the layout in use
+  auto dep = [&](int kind) { return sb.dep + (size_t)kind * sb.dep_blocks * kDepLine; };  // a hand-off kind's arrival counters
 
   auto frame_args = [&](bool fin_only) {
     FrameArgs f;
@@ -466,7 +474,8 @@ void launch_node(const ttsdec_handle* h, const StepBufs& sb, const StepIo& io, N
       a.w = make_seg3(W1(false), wld_ih, D, W2(false), wld_hh, H, W0(false), wld_ih, k0);
       a.w_lo = make_seg3(W1(true), wld_ih, D, W2(true), wld_hh, H, W0(true), wld_ih, k0);
       a.K = k0 + D + H;
-      a.dep_n = frame_grid_size(B, P); a.dep_seg = 2; a.dep_which = 0;
+      a.dep_n = frame_grid_size(32, P); a.dep_seg = 2; a.dep_which = 0;  // (the frame workgroups of one 32-row block)
+      a.dep_cnt = dep(DEP_FRAME);
       a.live_lag = 1;  // (same launch as the frame kernel: see lstm_body)
     } else if (part == PART_GATED) {
       // [h_att | h_dec | ctx]: ctx is written by the attention role of the same launch
@@ -474,7 +483,8 @@ void launch_node(const ttsdec_handle* h, const StepBufs& sb, const StepIo& io, N
       a.w = make_seg3(W0(false), wld_ih, k0, W2(false), wld_hh, H, W1(false), wld_ih, D);
       a.w_lo = make_seg3(W0(true), wld_ih, k0, W2(true), wld_hh, H, W1(true), wld_ih, D);
       a.K = k0 + D + H;
-      a.dep_n = B; a.dep_seg = 2; a.dep_which = 1;
+      a.dep_n = 32; a.dep_rows = 1; a.dep_seg = 2; a.dep_which = 1;  // (one attention workgroup per batch row)
+      a.dep_cnt = dep(DEP_ATTN);
     } else if (which == 0 ? part == PART_EARLY : part == PART_LATE) {
       // [ctx (| h_att)]: the attention LSTM's early part, or the decoder LSTM's late part (ctx alone)
       const int kh = which == 0 ? H : 0;
@@ -517,13 +527,13 @@ void launch_node(const ttsdec_handle* h, const StepBufs& sb, const StepIo& io, N
       break;
     case N_FA: {
       FrameArgs f = frame_args(false);
-      f.dep_signal = 1;
+      f.dep_signal = 1; f.dep_cnt = dep(DEP_FRAME);
       launch_frame_lstm(f, lstm_args(0, PART_GATED), st);
       break;
     }
     case N_TD: {
       AttnArgs a = attn_args();
-      a.dep_signal = 1;
+      a.dep_signal = 1; a.dep_cnt = dep(DEP_ATTN);
       launch_attn_lstm(a, lstm_args(1, PART_GATED), st);
       break;
     }
@@ -621,8 +631,9 @@ void launch_node(const ttsdec_handle* h, const StepBufs& sb, const StepIo& io, N
         pa.mode = node == N_JFA ? PROJ_HEAD : (node == N_JFIN ? PROJ_FINAL : PROJ_STEP);
         if (node == N_JFA) {
           FrameArgs f = frame_args(false);
-          f.dep_signal = 1;
-          f.wait_n = proj_grid_size(pa.M, pa.N, pa.ksplit);
+          f.dep_signal = 1; f.dep_cnt = dep(DEP_FRAME);
+          pa.dep_cnt = f.wait_cnt = dep(DEP_PROJ);
+          f.wait_n = proj_grid_size(32, pa.N, pa.ksplit);  // (the projection workgroups of one 32-row block)
           launch_proj_frame_lstm(pa, f, lstm_args(0, PART_GATED), st);
         } else {
           launch_proj(pa, st);
@@ -1071,6 +1082,7 @@ int ttsdec_decode(ttsdec_handle* h, const float* memory, int B, int L, int t_beg
     ca.stamps = g_stamps;
   }
   launch_set_call(sb.ctrl, ca, st);
+  HIP_TRY(h, hipMemsetAsync(sb.dep, 0, W.dep_bytes, st));  // arrival counters count from the call's first step
 
   StepIo io;
   memset(&io, 0, sizeof(io));

@@ -41,11 +41,7 @@ struct Ctrl {
   float *y, *s, *w;
   int range_err;  // bit 0: split-fp16 mode, an activation entering a 16-bit GEMM was outside the fp16 range (saturated);
                   // bit 1: a two-role launch gave up waiting for its producer role (results of the call are invalid)
-  // Two-role launches (fused_kernels.hip): arrival counters of the producer roles, zeroed at the start of every
-  // ttsdec_decode call; after step t of the call they read (t - t_call + 1) * (producer workgroups per step).
-  unsigned int dep_frame, dep_attn;
-  // ... and of the projection role at the head of the frame launch: after step t of the call (t - t_call) * (its workgroups)
-  unsigned int dep_proj;
+  unsigned int unused_dep[3];  // (the arrival counters of the two-role launches live in the workspace: kernels.h DepCounters)
   // measurement only (TTSDEC_STAMPS=1): per-workgroup wall-clock stamps of the two-role launches, else nullptr
   unsigned long long* stamps;
   // test hooks (include/ttsdec.h TTSDEC_OPT_DEBUG_FLAGS / _SPIN_LIMIT): bit 0 = the frame role does not signal, bit 1 = the
@@ -315,22 +311,35 @@ __device__ __forceinline__ void role_signal(unsigned int* counter) {
   __syncthreads();
   if (threadIdx.x == 0) __hip_atomic_fetch_add(counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
-constexpr int kRoleSpinLimit = 1 << 16;  // x ~0.45 us of s_sleep: ~30 ms, far beyond any producer's run time
-// the poll alone: for a consumer that takes every handed-off byte with sc1 loads (load_wt), or that only wants to know
-__device__ __forceinline__ void role_poll(const unsigned int* counter, unsigned int target, Ctrl* ctrl) {
-  if (target == 0) return;
+constexpr int kRoleSpinLimit = 1 << 17;  // x ~0.25 us of s_sleep + the poll's round trip: > 30 ms, far beyond any producer's run time
+// Arrival counters of the two-role launches (in the workspace, zeroed by every ttsdec_decode call): one per 32-ROW BLOCK of the
+// batch and hand-off kind, each on a 128-byte line of its own.  A consumer waits for the producers of ITS rows only - 8 frame
+// workgroups instead of all 32, 12 projection workgroups instead of 96, 64 attention workgroups instead of 256 - so no
+// workgroup waits for the slowest producer of the whole chip, and no counter takes more than 64 adds per step (96 adds to
+// ONE word took the projection role's signal ~1.5 us; MI355X_MICROARCH.md "fanin").
+constexpr int kDepLine = 32;  // unsigned ints per counter line
+enum DepKind { DEP_FRAME = 0, DEP_ATTN = 1, DEP_PROJ = 2, DEP_KINDS = 3 };
+// the poll alone: for a consumer that takes every handed-off byte with sc1 loads (load_wt), or that only wants to know.
+// Two counters (c1 may be nullptr): a consumer whose rows span two of the producers' 32-row blocks.
+__device__ __forceinline__ void role_poll(const unsigned int* c0, unsigned int target0, Ctrl* ctrl, const unsigned int* c1 = nullptr,
+                                          unsigned int target1 = 0) {
+  if (target0 == 0 && (c1 == nullptr || target1 == 0)) return;
   int spins = 0;
-  while (__hip_atomic_load(counter, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
-    __builtin_amdgcn_s_sleep(16);
+  for (;;) {
+    const unsigned int v0 = __hip_atomic_load(c0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const unsigned int v1 = c1 != nullptr ? __hip_atomic_load(c1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : target1;
+    if (v0 >= target0 && v1 >= target1) break;
+    __builtin_amdgcn_s_sleep(8);
     if (++spins > (ctrl != nullptr ? ctrl->spin_limit : kRoleSpinLimit)) {
       if (ctrl != nullptr) atomicOr(&ctrl->range_err, 2);
       break;
     }
   }
 }
-__device__ __forceinline__ void role_wait(const unsigned int* counter, unsigned int target, Ctrl* ctrl) {
-  if (target == 0) return;
-  role_poll(counter, target, ctrl);
+__device__ __forceinline__ void role_wait(const unsigned int* counter, unsigned int target, Ctrl* ctrl, const unsigned int* c1 = nullptr,
+                                          unsigned int target1 = 0) {
+  if (target == 0 && (c1 == nullptr || target1 == 0)) return;
+  role_poll(counter, target, ctrl, c1, target1);
   __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 }

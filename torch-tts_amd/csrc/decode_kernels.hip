@@ -569,9 +569,6 @@ __global__ void set_call_kernel(Ctrl* c, CallArgs a) {
   c->y = a.y;
   c->s = a.s;
   c->w = a.w;
-  c->dep_frame = 0;
-  c->dep_attn = 0;
-  c->dep_proj = 0;
   c->stamps = a.stamps;
   c->debug_flags = a.debug_flags;
   c->spin_limit = a.spin_limit;

@@ -183,7 +183,7 @@ __device__ __forceinline__ void frame_body(FrameArgs g, float* lds, int bx, int 
       // step t-1's projection is complete when (t - t_call) steps x wait_n workgroups have signalled.  No acquire: the slabs
       // were stored write-through and drained before each signal (proj_body), and every load of them below is an sc1 load
       // issued behind this poll (wave 0) or behind the barrier that wave 0 then joins (common.h load_wt)
-      if (wave == 0) role_poll(&g.ctrl->dep_proj, (unsigned int)t_rel * (unsigned int)g.wait_n, g.ctrl);
+      if (wave == 0) role_poll(g.wait_cnt + by * kDepLine, (unsigned int)t_rel * (unsigned int)g.wait_n, g.ctrl);
       lds_barrier();
     }
     load_parts();
@@ -495,7 +495,7 @@ __device__ __forceinline__ void frame_body(FrameArgs g, float* lds, int bx, int 
   report_range(over, g.ctrl);
   if (tid == 0) stamp(st, 0, 6, now_rt());  // x_pre stores issued
   if (g.dep_signal && g.ctrl != nullptr && !(g.ctrl->debug_flags & 1)) {
-    role_signal(&g.ctrl->dep_frame);  // the attention LSTM of this launch waits for x_pre
+    role_signal(g.dep_cnt + by * kDepLine);  // the attention LSTM workgroups of these rows wait for x_pre
     if (tid == 0) stamp(st, 0, 5, now_rt());
   }
 }
@@ -630,7 +630,7 @@ __device__ __forceinline__ void proj_body(ProjArgs g, float* red, int id) {
     else slab[(size_t)m * g.ldo + n] = v;
   }
   const unsigned long long t_red = now_rt();
-  if (signal && !(g.ctrl->debug_flags & 4)) role_signal(&g.ctrl->dep_proj);
+  if (signal && !(g.ctrl->debug_flags & 4)) role_signal(g.dep_cnt + (m0 / kProjTile) * kDepLine);  // (32-row blocks: the frame role's)
   if (tid == 0 && st != nullptr) {
     stamp(st, 2, 0, __builtin_amdgcn_s_getreg((4 << 0) | (0 << 6) | (31 << 11)));
     stamp(st, 2, 1, __builtin_amdgcn_s_getreg((20 << 0) | (0 << 6) | (3 << 11)));

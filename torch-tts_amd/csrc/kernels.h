@@ -106,9 +106,11 @@ struct LstmArgs {
   int dbg;  // measurement ablations (ttsdec_profile_step only): 1 = every load reads the zero block
   int tag;  // 1 = the decoder LSTM of a decode step (separate kernel symbol for profilers), else 0
   int live_lag;  // 1: this cell runs in the same launch as the frame kernel of its step (see lstm_body)
-  // Two-role launch: K segment dep_seg of the A operand is produced by the other role's dep_n workgroups of this
-  // very launch (dep_which 0: frame kernel -> Ctrl::dep_frame, 1: attention -> Ctrl::dep_attn); dep_n = 0: no gate.
-  int dep_n, dep_seg, dep_which;
+  // Two-role launch: K segment dep_seg of the A operand is produced by the other role of this very launch (dep_which 0: frame
+  // kernel, 1: attention), which signals the arrival counters dep_cnt[32-row block * kDepLine] (common.h): per step dep_n
+  // arrivals per block, or - dep_rows = 1 - one per batch row of the block.  dep_n = 0: no gate.
+  int dep_n, dep_seg, dep_which, dep_rows;
+  unsigned int* dep_cnt;
 };
 void launch_lstm(const LstmArgs& a, hipStream_t st);
 void launch_lstm_pair(const LstmArgs& a0, const LstmArgs& a1, hipStream_t st);  // two same-shape fp32 cells, one launch
@@ -126,7 +128,8 @@ struct AttnArgs {
   f16 *ctx_h, *ctx_l;   // optional split-fp16 planes of ctx
   int out_mpad;         // > 0: chunked layout of those planes (common.h Seg3)
   int ctx_only;         // 1: no weight update, just ctx = sum_l w_prev[l] * memory[l] (decoder_cell.py:118)
-  int dep_signal;       // 1: two-role launch - every workgroup signals Ctrl::dep_attn after its last store
+  int dep_signal;       // 1: two-role launch - every workgroup signals dep_cnt[(b / 32) * kDepLine] after its last store
+  unsigned int* dep_cnt;
   int B, L, D, t_rel, t_stride;
   Ctrl* ctrl;  // != nullptr: memory, w_out, t_rel, t_stride come from *ctrl
   int slot;
@@ -173,8 +176,11 @@ struct FrameArgs {
   int slot;
   int t;    // ctrl == nullptr
   int dbg;  // measurement ablations (ttsdec_profile_step only): bit 1 = no layer-0 MFMAs, bit 2 = no layer-1 MFMAs
-  int dep_signal;  // 1: two-role launch - every workgroup signals Ctrl::dep_frame after its last store
-  int wait_n;      // > 0: the partial sums come from wait_n projection-role workgroups at the head of this very launch (Ctrl::dep_proj)
+  int dep_signal;  // 1: two-role launch - every workgroup signals dep_cnt[row block * kDepLine] after its last store
+  unsigned int* dep_cnt;
+  int wait_n;      // > 0: the partial sums of a row block come from wait_n projection-role workgroups at the head of this very
+                   // launch, which signal wait_cnt[row block * kDepLine]
+  unsigned int* wait_cnt;
 };
 bool frame_supported(int d_mel, int r, int Ph, int P);
 void launch_frame(const FrameArgs& a, hipStream_t st);
@@ -197,9 +203,10 @@ struct ProjArgs {
   int slot;
   // mode 0: a launch of its own at the end of step t = ctrl->t_cur + slot.  mode 1 (PROJ_HEAD): a ROLE at the head of step t's
   // frame launch, computing step t-1's projection - live like that launch's finalize phase (t-1 <= stop_t, t > t_call) - whose
-  // slabs are stored write-through and signalled through Ctrl::dep_proj.  mode 2 (PROJ_FINAL): the projection of the call's
+  // slabs are stored write-through and signalled through dep_cnt[32-row block * kDepLine].  mode 2 (PROJ_FINAL): the projection of the call's
   // last step, a launch of its own in front of the end-of-call frame launch.
   int mode;
+  unsigned int* dep_cnt;
 };
 enum ProjMode { PROJ_STEP = 0, PROJ_HEAD = 1, PROJ_FINAL = 2 };
 int proj_split(int K);  // the ksplit of this kernel for K, or 0 when it does not cover K

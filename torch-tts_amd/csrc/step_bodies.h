@@ -67,15 +67,15 @@ template <bool SC1>
 struct RoleGateT {
   static constexpr int kAuxA = SC1 ? 16 : 0;
   int seg;
-  const unsigned int* counter;
-  unsigned int target;
+  const unsigned int *counter, *counter1;  // the arrival counters of this workgroup's (up to two) 32-row blocks
+  unsigned int target, target1;
   Ctrl* ctrl;
   int kind;
   stamp_ptr st;  // (loaded by the caller, once: see common.h stamp)
   __device__ __forceinline__ void wait() const {
     stamp(st, kind, 3, now_rt());
-    if constexpr (SC1) role_poll(counter, target, ctrl);
-    else role_wait(counter, target, ctrl);
+    if constexpr (SC1) role_poll(counter, target, ctrl, counter1, target1);
+    else role_wait(counter, target, ctrl, counter1, target1);
     stamp(st, kind, 4, now_rt());
   }
 };
@@ -134,7 +134,7 @@ __device__ __forceinline__ void lstm_body(LstmArgs g, float* smem, int bx, int b
   const LoaderWLstm<BU, EB> lb{g.w, g.w_lo, u0, g.H};
   RoleGateT<kWhole> gate;  // (kWhole = a role of a two-role launch)
   const stamp_ptr st = g.dep_n > 0 ? stamps_of(g.ctrl) : (stamp_ptr) nullptr;  // measurement only (TTSDEC_STAMPS)
-  gate.seg = -1; gate.counter = nullptr; gate.target = 0; gate.ctrl = g.ctrl; gate.kind = g.dep_which; gate.st = st;
+  gate.seg = -1; gate.counter = gate.counter1 = nullptr; gate.target = gate.target1 = 0; gate.ctrl = g.ctrl; gate.kind = g.dep_which; gate.st = st;
   if (threadIdx.x == 0) {
     stamp(st, g.dep_which, 0, (1ull << 32) | __builtin_amdgcn_s_getreg((4 << 0) | (0 << 6) | (31 << 11)));
     stamp(st, g.dep_which, 1, __builtin_amdgcn_s_getreg((20 << 0) | (0 << 6) | (3 << 11)));
@@ -143,8 +143,21 @@ __device__ __forceinline__ void lstm_body(LstmArgs g, float* smem, int bx, int b
   if (g.dep_n > 0) {
     gate.seg = g.dep_seg;
     if (g.ctrl != nullptr) {  // (no control block = profiling: the producers' data is whatever the last launch left)
-      gate.counter = g.dep_which ? &g.ctrl->dep_attn : &g.ctrl->dep_frame;
-      gate.target = (unsigned int)(g.ctrl->t_cur + g.slot - g.ctrl->t_call + 1) * (unsigned int)g.dep_n;
+      // the 32-row blocks this tile's rows [m0, m0 + BM) lie in: one (BM = 32) or two (BM = 64); arrivals per block and step:
+      // dep_n, or the block's number of batch rows (dep_rows)
+      static_assert(BM == 32 || BM == 64, "gated LSTM tiles span one or two 32-row blocks");
+      const unsigned int steps = (unsigned int)(g.ctrl->t_cur + g.slot - g.ctrl->t_call + 1);
+      auto per_block = [&](int rb) {
+        const int rows = g.M - 32 * rb;
+        return rows <= 0 ? 0u : (unsigned int)(g.dep_rows ? (rows < 32 ? rows : 32) : g.dep_n);
+      };
+      const int rb = m0 / 32;
+      gate.counter = g.dep_cnt + rb * kDepLine;
+      gate.target = steps * per_block(rb);
+      if (BM == 64 && per_block(rb + 1) > 0) {
+        gate.counter1 = g.dep_cnt + (rb + 1) * kDepLine;
+        gate.target1 = steps * per_block(rb + 1);
+      }
     }
   }
   gemm_tile<Cfg>(la, lb, smem, live, g.dbg, gate);
@@ -381,7 +394,7 @@ __device__ __forceinline__ void attn_body(AttnArgs g, float* part, int b) {
     }
   }
   if (g.dep_signal && g.ctrl != nullptr && !(g.ctrl->debug_flags & 2)) {
-    role_signal(&g.ctrl->dep_attn);  // the decoder LSTM of this launch waits for ctx
+    role_signal(g.dep_cnt + (b / 32) * kDepLine);  // the decoder LSTM workgroups of these rows wait for ctx
     if (threadIdx.x == 0) stamp(st, 1, 5, now_rt());
   }
 }
