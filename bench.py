@@ -212,7 +212,7 @@ def bench_vits2(args, T, torch, dist, dev, world, rank):
                      "peak_note": "dense f16 MFMA peak (2500 TFLOP/s) / 3 products per fp32 product",
                      "traffic": None, "alg_flops_per_utterance": {"text_encoder": f_te, "flow_reverse": f_fl}},
     }
-    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+    if rank == 0 and not args.no_cpu_baseline:
         from oracle import vits2_oracle as V
 
         d = V.Vits2Dims()
@@ -342,58 +342,85 @@ class Workload:
         }
 
     def roofline(self, B, precision, decode_step_ms):
-        """Roofline record of the dominant step kernel: HIP events inside the library, on the launch stream."""
+        """Roofline record of the decode STEP (north_star's quantity) and of every launch in it, from in-loop times.
+
+        frac = algorithmic bytes of one step / the step's time inside the timed loop / 8 TB/s.  The per-launch times come from
+        the same captured-graph loop run once more with workgroup 0 of every step kernel storing its start time
+        (ttsdec_profile_loop; one 8-byte store per launch): each entry is the span from a launch's start to the next launch's
+        start inside the replayed graph - the launch's duration in the loop plus the gap behind it - so the entries add up to
+        that loop's step time, which is printed next to the timed loop's.
+        Exact fp32 is bound by the fp32 matrix pipe above ~46 utterances: that leg reports the FLOP fraction as
+        its roofline and the HBM fraction beside it."""
         args, _lib = self.args, self._lib
         io = self.inputs(B)
         self.eng.set_precision(precision)
-        kms = self.eng.profile_step(io["mem"], iters=50, dropout_mode=_lib.DROPOUT_PHILOX, masks=None, seed=123)
-        bytes_k = step_bytes(B, args.mem_len, LJSPEECH["model"]["decoder"])  # (byte model of the LJSpeech cell)
-        # Two-role step (csrc/fused_kernels.hip): each LSTM shares a launch with the small kernel in front of it;
-        # the launch's algorithmic bytes are the sum of its two roles'.
+        dd = LJSPEECH["model"]["decoder"]  # (byte / FLOP model of the LJSpeech cell)
+        bytes_k = step_bytes(B, args.mem_len, dd)
         alg = dict(bytes_k)
         alg.update({"prenet0": 0, "prenet1": 0})
 
         def alg_bytes(name):  # "a+b+c" = one launch running those roles: the sum of their bytes
             return sum(alg.get(part, 0) for part in name.split("+"))
-        per_kernel, alone = {}, {}
-        for name, ms in kms.items():
-            if name.endswith("(alone)"):
-                alone[name] = round(ms, 5)
-                continue
+
+        loop_ms, loop_step_ms = self.eng.profile_loop(io["mem"], n_steps=600, dropout_mode=_lib.DROPOUT_PHILOX, masks=None, seed=123)
+        alone_ms = self.eng.profile_step(io["mem"], iters=50, dropout_mode=_lib.DROPOUT_PHILOX, masks=None, seed=123)
+        # HBM-side traffic per launch from the PMC passes: those cannot be collected inside this process (rocprofv3 --pmc,
+        # separate passes), so the figures come from the committed capture - and only when that capture was taken on exactly
+        # these kernel sources (digest match), else null
+        traffic, traffic_src = {}, None
+        for fn in ("r03_traffic.json",):
+            try:
+                tj = json.load(open(os.path.join(ROOT, "profiles", fn)))
+                if tj.get("sources_digest") == sources_digest() and tj.get("precision") == precision and tj.get("batch") == B:
+                    traffic = {k: v.get("hbm_bytes") for k, v in tj["per_launch"].items()}
+                    traffic_src = {"file": "profiles/" + fn, "sources_digest": tj["sources_digest"], "commit": tj.get("captured_at_commit")}
+            except Exception:
+                pass
+        per_kernel = {}
+        for name, ms in loop_ms.items():
             key = "prenet" if name in ("prenet0", "prenet1") else name
-            ent = per_kernel.setdefault(key, {"ms": 0.0, "alg_bytes": alg_bytes(key)})
-            ent["ms"] += ms
-        for ent in per_kernel.values():
-            ent["GBps"] = round(ent["alg_bytes"] / (ent["ms"] * 1e-3) / 1e9, 1)
-            ent["ms"] = round(ent["ms"], 5)
-        # the dominant kernel: the longest launch; launches within 5 % of it count as tied and the one that moves the
-        # most algorithmic bytes is reported (frame || lstm_att and lstm_dec take 26.7 and 26.6 us at B = 256)
-        top = max(v["ms"] for v in per_kernel.values())
-        dom = max((k for k, v in per_kernel.items() if v["ms"] >= 0.95 * top), key=lambda k: per_kernel[k]["alg_bytes"])
-        # HBM traffic of the dominant kernel from the PMC passes: those cannot be collected inside this process
-        # (rocprofv3 --pmc, separate passes), so the figure comes from the committed capture - and only when that
-        # capture was taken on exactly these kernel sources (digest match), else null
-        traffic, traffic_src = None, None
-        try:
-            tj = json.load(open(os.path.join(ROOT, "profiles", "r02_traffic.json")))
-            if tj.get("sources_digest") == sources_digest() and tj.get("precision") == precision and tj.get("batch") == B:
-                traffic = tj["per_launch"].get(dom, {}).get("hbm_bytes")
-                traffic_src = {"file": "profiles/r02_traffic.json", "sources_digest": tj["sources_digest"], "commit": tj.get("captured_at_commit")}
-        except Exception:
-            pass
-        return {
-            "bound": "hbm", "kernel": dom, "achieved": per_kernel[dom]["GBps"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
-            "frac": round(per_kernel[dom]["GBps"] / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_capture": traffic_src,
-            "alg_bytes_per_launch": per_kernel[dom]["alg_bytes"], "kernel_ms": per_kernel[dom]["ms"],
-            "decode_step": {
-                "alg_bytes": bytes_k["step"], "ms_in_loop": round(decode_step_ms, 5),
-                "GBps": round(bytes_k["step"] / (decode_step_ms * 1e-3) / 1e9, 1),
-                "frac": round(bytes_k["step"] / (decode_step_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
-                "sum_kernel_ms": round(sum(v["ms"] for v in per_kernel.values()), 5),
+            ent = per_kernel.setdefault(key, {"ms_in_loop": 0.0, "alg_bytes": alg_bytes(key), "ms_alone": 0.0})
+            ent["ms_in_loop"] += ms
+            ent["ms_alone"] += alone_ms.get(name, 0.0)
+        for key, ent in per_kernel.items():
+            ent["GBps"] = round(ent["alg_bytes"] / (ent["ms_in_loop"] * 1e-3) / 1e9, 1)
+            ent["frac"] = round(ent["GBps"] / HBM_PEAK_GBS, 4)
+            ent["traffic"] = traffic.get(key)
+            ent["traffic_over_alg"] = round(traffic[key] / ent["alg_bytes"], 3) if traffic.get(key) and ent["alg_bytes"] else None
+            ent["ms_in_loop"], ent["ms_alone"] = round(ent["ms_in_loop"], 5), round(ent["ms_alone"], 5)
+        # FLOPs of one step (SURVEY 8d): 2 per weight of the five GEMM groups + the two passes over `memory`
+        P, D, Ha, Hd, M = dd["dim_pre"], 512, dd["dim_rnn"][0], dd["dim_rnn"][1], 80
+        n_w = P * M + P * P + 4 * Ha * (P + D + Ha) + D * Ha + 4 * Hd * (Ha + D + Hd) + (M + 1) * (Hd + D)
+        flops = B * (2 * n_w + 4 * args.mem_len * D)
+        step_s = decode_step_ms * 1e-3
+        hbm_gbs = bytes_k["step"] / step_s / 1e9
+        if precision == "f32":
+            pipe, pipe_peak, pipe_flops = "fp32 matrix instruction (v_mfma_f32_32x32x2_f32)", 157.3, flops
+        else:
+            pipe, pipe_peak, pipe_flops = "f16 matrix instruction, 3 products per fp32 product (split-fp16)", F16_MFMA_PEAK_TFLOPS, 3 * flops
+        tflops = pipe_flops / step_s / 1e12
+        t_hbm, t_pipe = bytes_k["step"] / (HBM_PEAK_GBS * 1e9), pipe_flops / (pipe_peak * 1e12)
+        hbm = {"bound": "hbm", "achieved": round(hbm_gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(hbm_gbs / HBM_PEAK_GBS, 4),
+               "alg_bytes_per_step": bytes_k["step"], "roofline_us": round(t_hbm * 1e6, 2)}
+        mfma = {"bound": "mfma", "achieved": round(tflops, 2), "peak": pipe_peak, "unit": "TFLOP/s", "frac": round(tflops / pipe_peak, 4),
+                "pipe": pipe, "alg_flops_per_step": flops, "pipe_flops_per_step": pipe_flops, "roofline_us": round(t_pipe * 1e6, 2)}
+        top = dict(hbm if t_hbm >= t_pipe else mfma)  # the roofline that binds this leg; the other one rides beside it
+        step_traffic = sum(v for v in (per_kernel[k]["traffic"] for k in per_kernel) if v) if traffic and all(per_kernel[k]["traffic"] for k in per_kernel) else None
+        top.update({
+            "kernel": "decode step = " + " -> ".join(loop_ms.keys()) + " (every launch listed under per_kernel; none singled out)",
+            "traffic": step_traffic, "traffic_capture": traffic_src,
+            "step_us_in_loop": round(decode_step_ms * 1e3, 3),
+            "other_roofline": mfma if t_hbm >= t_pipe else hbm,
+            "in_loop_check": {
+                "timed_loop_step_us": round(decode_step_ms * 1e3, 3), "stamped_loop_step_us": round(loop_step_ms * 1e3, 3),
+                "sum_per_kernel_us": round(sum(v["ms_in_loop"] for v in per_kernel.values()) * 1e3, 3),
+                "stamped_over_timed": round(loop_step_ms / decode_step_ms, 4),
+                "how": "ttsdec_profile_loop: the same captured-graph decode with workgroup 0 of every step kernel storing its start time "
+                       "(s_memrealtime); an entry = start-to-next-start span inside the last graph replay = the launch plus the gap behind it",
             },
             "per_kernel": per_kernel,
-            **({"roles_alone_ms": alone} if alone else {}),
-        }
+        })
+        return top
 
     def cpu_baseline_and_parity(self, B, precisions, postnets):
         """The oracle (a port of the reference's CPU path) timed on this box's host cores, on the timed inputs
@@ -548,10 +575,10 @@ def main():
             "what": what, "value": leg["value"], "unit": "mel-frames/s", "ms_per_step": leg["ms_per_step"], "steps": args.steps,
             "warmup": args.warmup, "dtype": DTYPE_TEXT[leg["lstm_precision"]] + POSTNET_TEXT[pp], "rtf": leg["rtf"],
             "decode_only_frames_per_s": leg["decode_only_frames_per_s"], "global_batch": leg["global_batch"],
-            "roofline": {k: rf[k] for k in ("bound", "kernel", "achieved", "peak", "unit", "frac", "traffic", "alg_bytes_per_launch", "kernel_ms", "decode_step")},
+            "roofline": rf,
         }
 
-    if rank == 0 and world == 1 and lj and not args.no_cpu_baseline:
+    if rank == 0 and lj and not args.no_cpu_baseline:  # (rank 0's shard and host cores, whatever the world size)
         precs, posts = [args.precision], [args.postnet]
         if not args.no_extra_legs and not (args.precision == "f32" and args.postnet == "f32"):
             precs.append("f32"); posts.append("f32")

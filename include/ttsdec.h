@@ -178,6 +178,8 @@ enum {
   TTSDEC_OPT_CHUNK_B,          /* "chunk_b": 0 = row-major LSTM weight planes                                                  */
   TTSDEC_OPT_PROJ_REGW,        /* "proj_regw": 0 = mel/stop projection on the LDS-staged split-K GEMM                          */
   TTSDEC_OPT_HEAD_PROJ,        /* "head_proj": 1 / 0 = that projection as a role at the head of the next step's first launch   */
+  TTSDEC_OPT_QUERY_ROLE,       /* "query_role": 1 / 0 = the attention query GEMM as a job of the attention role's workgroups
+                                * (overlap 2, at most 256 utterances) instead of a launch of its own                          */
   TTSDEC_OPT_PROFILE_ABLATION, /* "profile_ablation": ttsdec_profile_step only, kernel-internal ablation switches              */
   TTSDEC_OPT_DEBUG_FLAGS,      /* "debug_flags": TEST HOOK. bit 0 / 1 / 2: the frame / attention / projection-head role of a
                                 * two-role launch does not signal its consumers, which then run into the bounded-spin
@@ -288,6 +290,16 @@ int ttsdec_profile_step(ttsdec_handle* h, const float* memory, int B, int L, int
                         const uint8_t* masks, uint64_t seed, float* y, float* s, float* w, void* workspace,
                         size_t workspace_bytes, void* stream, float* ms_out, const char** names_out, int n_out,
                         int* n_kernels);
+
+/* Measurement aid for bench.py: the step's launches timed INSIDE the replayed graph of the step loop.  Runs one ordinary
+ * decode call of n_steps steps from step 0 (a multiple of the graph's 30 steps, >= 60; stop rule off) in which workgroup 0 of
+ * every step kernel stores its start time (one 8-byte store per launch: the only difference to ttsdec_decode); ms_out[k] is
+ * the mean time from launch k's start to the next launch's start - the launch's duration in the loop including the gap
+ * behind it - over the last graph replay; the entries add up to *step_ms, the loop's time per step.  Synchronises the
+ * stream.  Names and counts as for ttsdec_profile_step; y [B, n_steps*r, d_mel], s [B, n_steps*r], w [B, n_steps, L]. */
+int ttsdec_profile_loop(ttsdec_handle* h, const float* memory, int B, int L, int n_steps, int dropout_mode, const uint8_t* masks,
+                        uint64_t seed, float* y, float* s, float* w, int32_t* T_out, void* workspace, size_t workspace_bytes, void* stream,
+                        float* ms_out, const char** names_out, int n_out, int* n_kernels, float* step_ms);
 
 /* ---------------------------------------------------------------------------------------
  * Text encoder: Encoder2.forward in eval mode, tacotron/encoder.py:27-82

@@ -26,13 +26,17 @@ STEP_KERNELS = [
 ]
 
 
-STEP_LABELS = {label for _, label in STEP_KERNELS} | {"lstm_att", "lstm_dec", "query", "proj+prenet+lstm_att"}
+STEP_LABELS = {label for _, label in STEP_KERNELS} | {"lstm_att", "lstm_dec", "query", "proj+prenet+lstm_att", "query+attention+lstm_dec"}
+# the step order the capture ran (tools/prof_kernels.py prints it): the two-role kernels carry their roles' names from it
+ORDER_NAMES = []
 
 
 def short(name):
     name = name.replace("(anonymous namespace)::", "").replace("void ", "")
     if "frame_lstm_kernel" in name and name.rstrip().endswith(", true>(ttsdec::FrameArgs, ttsdec::LstmArgs, ttsdec::ProjArgs, int, int, int, int)"):
         return "proj+prenet+lstm_att"  # (the three-role form of the frame launch)
+    if "attn_lstm_kernel" in name and "query+attention+lstm_dec" in ORDER_NAMES:
+        return "query+attention+lstm_dec"  # (the attention role's workgroups also run the query GEMM: same symbol)
     for key, label in STEP_KERNELS:
         if key in name:
             return label
@@ -64,7 +68,9 @@ def main():
     ap.add_argument("--precision", default="split_f16")
     ap.add_argument("--batch", type=int, default=256)
     ap.add_argument("--note", default="")
+    ap.add_argument("--order", default="", help="comma-separated launch names of the captured step order (prof_kernels.py's output keys)")
     a = ap.parse_args()
+    ORDER_NAMES.extend(n for n in a.order.split(",") if n)
     if a.mode == "traffic":
         import bench
 

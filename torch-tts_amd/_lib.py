@@ -55,6 +55,7 @@ SYMBOLS = (
     "ttsdec_postnet",
     "ttsdec_cell_step",
     "ttsdec_profile_step",
+    "ttsdec_profile_loop",
     "ttsenc_create",
     "ttsenc_destroy",
     "ttsenc_last_hip_error",
@@ -205,6 +206,12 @@ def load() -> C.CDLL:
             vp, vp, i32, i32, i32, i32, vp, u64,  # h, memory, B, L, iters, dropout_mode, masks, seed
             vp, vp, vp, vp, sz, vp,               # y, s, w, workspace, workspace_bytes, stream
             C.POINTER(f32), C.POINTER(C.c_char_p), i32, C.POINTER(i32),
+        ]
+        lib.ttsdec_profile_loop.restype = i32
+        lib.ttsdec_profile_loop.argtypes = [
+            vp, vp, i32, i32, i32, i32, vp, u64,       # h, memory, B, L, n_steps, dropout_mode, masks, seed
+            vp, vp, vp, vp, vp, sz, vp,                 # y, s, w, T_out, workspace, workspace_bytes, stream
+            C.POINTER(f32), C.POINTER(C.c_char_p), i32, C.POINTER(i32), C.POINTER(f32),
         ]
         lib.ttsenc_create.restype = i32
         lib.ttsenc_create.argtypes = [C.POINTER(EncDims), C.POINTER(vp)]

@@ -57,6 +57,7 @@ struct WsLayout {  // offsets in bytes
   size_t xpre_h, xpre_l, ctx_h, ctx_l, h_att_h[2], h_att_l[2], h_dec_h[2], h_dec_l[2];  // split-fp16 planes
   size_t jparts;  // split-K partial sums of the mel/stop projection [kProjSplit][B, proj_ldp]
   size_t pa, pd;  // fp32 partial gate sums [B, 4H] of the two LSTMs' early parts (two-role step)
+  size_t loop_stamps;     // measurement only: launch start times of one graph replay [kLoopStampSlots][kLoopStampNodes] (common.h)
   size_t dep, dep_bytes;  // arrival counters of the two-role launches: [DEP_KINDS][32-row blocks][kDepLine] (common.h)
   size_t total;
 };
@@ -90,6 +91,7 @@ struct ttsdec_handle {
   bool proj_regw;         // mel/stop projection on the register-weight kernel where it applies (option "proj_regw")
   int opt_graph, opt_chunk_a, opt_chunk_b, opt_proj_regw;  // the options behind those four: -1 = default (on), 0, 1
   int head_proj;          // that projection as a role at the head of the NEXT step's frame launch: 1 / 0, -1 = by batch size; TTSDEC_HEAD_PROJ
+  int query_role;         // attention query as a job of the attention role's workgroups (step_order): 1 / 0, -1 = default
   int profile_ablation;   // ttsdec_profile_step only: the kernels' dbg switches (measurement ablations)
   int debug_flags;        // test hooks, copied into Ctrl::debug_flags: bit 0 = the frame role does not signal, bit 1 = the attention
                           // role does not, bit 2 = the projection head role does not (drives the bounded-spin time-out path)
@@ -105,6 +107,7 @@ struct ttsdec_handle {
   // max |w| read back from the blob header (pack / bind): a weight at or beyond the fp16 range has no
   // split-fp16 form, so the affected GEMMs stay on exact fp32 (ttsdec_get_precision reports it)
   float wmax_dec, wmax_post;
+  unsigned long long* stamps_buf;  // measurement only (TTSDEC_STAMPS): device buffer of this handle's device
 };
 
 namespace {
@@ -257,6 +260,7 @@ WsLayout make_ws_layout(const ttsdec_dims& d, int B, int Lm) {
   W.jparts = take((size_t)kProjSplit * b * proj_ldp(d));
   W.pa = take(b * 4 * d.h_att);
   W.pd = take(b * 4 * d.h_dec);
+  W.loop_stamps = take(kLoopStampSlots * kLoopStampNodes * 2);
   W.dep_bytes = (size_t)DEP_KINDS * ((B + 31) / 32) * kDepLine * sizeof(unsigned int);
   W.dep = take(W.dep_bytes / sizeof(float));
   W.total = off;
@@ -306,6 +310,7 @@ struct StepBufs {
   f16 *xpre_h, *xpre_l, *ctx_h, *ctx_l, *h_att_h[2], *h_att_l[2], *h_dec_h[2], *h_dec_l[2];
   float* jparts;
   float *pa, *pd;
+  unsigned long long* loop_stamps;
   unsigned int* dep;
   int dep_blocks;  // 32-row blocks of the batch: dep + kind * dep_blocks * kDepLine is a hand-off kind's counter array
 };
@@ -327,6 +332,7 @@ StepBufs carve(const WsLayout& W, void* ws) {
   }
   s.jparts = f(W.jparts);
   s.pa = f(W.pa); s.pd = f(W.pd);
+  s.loop_stamps = reinterpret_cast<unsigned long long*>(p + W.loop_stamps);
   s.dep = reinterpret_cast<unsigned int*>(p + W.dep);
   s.dep_blocks = (int)(W.dep_bytes / (DEP_KINDS * kDepLine * sizeof(unsigned int)));
   return s;
@@ -347,6 +353,7 @@ struct StepIo {
   bool use_ctrl;
   int finalize;  // !use_ctrl, frame kernel: the projection partial sums are the previous step's frame
   int dbg;
+  int node_pos;  // position of the launch in the step order (measurement: common.h loop_stamp)
 };
 
 // The kernels of one decode step.  N_F is the fused frame kernel (finish the previous step's
@@ -355,7 +362,8 @@ struct StepIo {
 // Two-role step (fused_kernels.hip): N_FA = frame || attention LSTM, N_TD = attention || decoder LSTM;
 // N_AG / N_DG are those LSTMs alone on the lean tile (profiling).  N_JFA = N_FA with the PREVIOUS step's mel/stop projection as a
 // role at its head (then no N_J in the step), N_JFIN = the projection of a call's last step.
-enum Node { N_F, N_FIN, N_P0, N_P1, N_A, N_Q, N_T, N_D, N_J, N_FA, N_TD, N_AG, N_DG, N_JFA, N_JFIN };
+// N_QTD = N_TD whose attention-role workgroups first compute the query GEMM between them (then no N_Q in the step).
+enum Node { N_F, N_FIN, N_P0, N_P1, N_A, N_Q, N_T, N_D, N_J, N_FA, N_TD, N_AG, N_DG, N_JFA, N_JFIN, N_QTD };
 // PART_GATED: the whole cell with the segment that waits for the other role of the launch LAST
 enum LstmPart { PART_WHOLE = 0, PART_EARLY = 1, PART_LATE = 2, PART_GATED = 3 };
 
@@ -371,6 +379,7 @@ bool split_ok(const ttsdec_dims& d) { return !((d.d_pre | d.d_ctx | d.h_att | d.
 // launch order of one step: the Prod cell attends between its two LSTMs, the Taco2 cell after both
 const StepOrder& step_order(const ttsdec_handle* h, int B);
 bool head_proj(const ttsdec_handle* h, int B);
+bool query_role(const ttsdec_handle* h, int B);
 int& option_ref(ttsdec_handle* h, int o);
 void apply_env_options(ttsdec_handle* h);
 void drop_graph(ttsdec_handle* h);
@@ -426,7 +435,7 @@ void launch_node(const ttsdec_handle* h, const StepBufs& sb, const StepIo& io, N
     f.seed = io.seed; f.keep_scale = keep_scale;
     f.xpre = sb.xpre;
     if (prec) { f.xpre_h = sb.xpre_h; f.xpre_l = sb.xpre_l; f.out_mpad = mpad; }
-    f.M = B; f.ctrl = ctrl; f.slot = io.slot; f.t = io.t;
+    f.M = B; f.ctrl = ctrl; f.slot = io.slot; f.node = io.node_pos; f.t = io.t;
     return f;
   };
   // One LSTM cell as a whole, or cut along its K axis (fused_kernels.hip): EARLY = the segments that do not wait
@@ -506,7 +515,7 @@ void launch_node(const ttsdec_handle* h, const StepBufs& sb, const StepIo& io, N
     a.h_prev = which ? sb.h_dec[p] : sb.h_att[p];
     a.c = which ? sb.c_dec : sb.c_att;
     a.h_out = which ? sb.h_dec[1 - p] : sb.h_att[1 - p];
-    a.M = B; a.H = H; a.pz = d.p_zoneout; a.ctrl = ctrl; a.slot = io.slot; a.dbg = io.dbg;
+    a.M = B; a.H = H; a.pz = d.p_zoneout; a.ctrl = ctrl; a.slot = io.slot; a.node = io.node_pos; a.dbg = io.dbg;
     a.tag = which;
     return a;
   };
@@ -516,7 +525,7 @@ void launch_node(const ttsdec_handle* h, const StepBufs& sb, const StepIo& io, N
     if (prec) { a.ctx_h = sb.ctx_h; a.ctx_l = sb.ctx_l; a.out_mpad = mpad; }
     a.memory = io.memory; a.q = sb.q; a.q_parts = query_split(d); a.q_stride = (size_t)B * D;
     a.w_prev = sb.w[p]; a.w_new = sb.w[1 - p]; a.w_out = io.w; a.ctx = sb.ctx;
-    a.B = B; a.L = io.L; a.D = D; a.t_rel = io.t_rel; a.t_stride = io.t_stride; a.ctrl = ctrl; a.slot = io.slot;
+    a.B = B; a.L = io.L; a.D = D; a.t_rel = io.t_rel; a.t_stride = io.t_stride; a.ctrl = ctrl; a.slot = io.slot; a.node = io.node_pos;
     return a;
   };
 
@@ -534,7 +543,29 @@ void launch_node(const ttsdec_handle* h, const StepBufs& sb, const StepIo& io, N
     case N_TD: {
       AttnArgs a = attn_args();
       a.dep_signal = 1; a.dep_cnt = dep(DEP_ATTN);
-      launch_attn_lstm(a, lstm_args(1, PART_GATED), st);
+      launch_attn_lstm(a, lstm_args(1, PART_GATED), nullptr, st);
+      break;
+    }
+    case N_QTD: {
+      // the query GEMM (decoder_cell.py:188 -> attention.py:105) as a job of the attention role's workgroups
+      ProjArgs pq;
+      memset(&pq, 0, sizeof(pq));
+      pq.prec = prec ? PREC_F16S : PREC_F32;
+      if (prec) {
+        pq.a = act(make_seg1(sb.h_att_h[1 - p], Ha, Ha)); pq.a_lo = act(make_seg1(sb.h_att_l[1 - p], Ha, Ha));
+        pq.W = plane(bl.wq_h); pq.W_lo = plane(bl.wq_l);
+      } else {
+        pq.a = make_seg1(sb.h_att[1 - p], Ha, Ha);
+        pq.W = blob + bl.wq;
+      }
+      pq.ldw = query_ld(d); pq.M = B; pq.N = D; pq.K = query_k(d); pq.ksplit = proj_split(pq.K);
+      pq.split_stride = (size_t)B * D; pq.out = sb.q; pq.ldo = D; pq.ctrl = ctrl; pq.slot = io.slot; pq.mode = PROJ_QUERY;
+      pq.dep_cnt = dep(DEP_QUERY);
+      AttnArgs a = attn_args();
+      a.dep_signal = 1; a.dep_cnt = dep(DEP_ATTN);
+      a.q_parts = pq.ksplit;
+      a.q_tiles = proj_grid_size(B, D, pq.ksplit); a.q_wait_n = proj_grid_size(32, D, pq.ksplit); a.q_cnt = pq.dep_cnt;
+      launch_attn_lstm(a, lstm_args(1, PART_GATED), &pq, st);
       break;
     }
     case N_AG:
@@ -571,7 +602,7 @@ void launch_node(const ttsdec_handle* h, const StepBufs& sb, const StepIo& io, N
       g.masks = io.masks ? io.masks + g.mask_layer_off : nullptr;
       g.seed = io.seed; g.layer = layer; g.keep_scale = keep_scale;
       g.r = d.r; g.d_mel = d.d_mel;
-      g.ctrl = ctrl; g.slot = io.slot; g.t = io.t;
+      g.ctrl = ctrl; g.slot = io.slot; g.node = io.node_pos; g.t = io.t;
       launch_gemm(g, A_PLAIN, EPI_RELU_DROPOUT, st);
       break;
     }
@@ -594,7 +625,7 @@ void launch_node(const ttsdec_handle* h, const StepBufs& sb, const StepIo& io, N
         }
       }
       g.ksplit = query_split(d); g.kchunk = g.K / g.ksplit; g.split_stride = (size_t)B * D;
-      g.ctrl = ctrl; g.slot = io.slot; g.t = io.t;
+      g.ctrl = ctrl; g.slot = io.slot; g.node = io.node_pos; g.t = io.t;
       launch_gemm(g, A_PLAIN, EPI_PLAIN, st);
       break;
     }
@@ -610,7 +641,7 @@ void launch_node(const ttsdec_handle* h, const StepBufs& sb, const StepIo& io, N
       if (is_taco2(d)) g.a = make_seg2(sb.h_att[1 - p], Ha, Ha, sb.h_dec[1 - p], Hd, Hd);
       else g.a = make_seg2(sb.h_dec[1 - p], Hd, Hd, sb.ctx, D, D);
       g.W = blob + bl.proj_w; g.ldw = proj_ld(d); g.K = proj_k(d); g.M = B; g.N = proj_n(d);
-      g.ctrl = ctrl; g.slot = io.slot; g.t = io.t;
+      g.ctrl = ctrl; g.slot = io.slot; g.node = io.node_pos; g.t = io.t;
       if (prec && use_frame(d)) {
         g.prec = PREC_F16S;
         g.W = plane(bl.proj_h); g.W_lo = plane(bl.proj_l);
@@ -627,7 +658,7 @@ void launch_node(const ttsdec_handle* h, const StepBufs& sb, const StepIo& io, N
         memset(&pa, 0, sizeof(pa));
         pa.a = g.a; pa.a_lo = g.a_lo; pa.W = g.W; pa.W_lo = g.W_lo; pa.ldw = g.ldw; pa.prec = g.prec;
         pa.M = B; pa.N = g.N; pa.K = g.K; pa.ksplit = proj_parts(h, prec); pa.split_stride = (size_t)B * proj_ldp(d);
-        pa.out = sb.jparts; pa.ldo = proj_ldp(d); pa.ctrl = ctrl; pa.slot = io.slot;
+        pa.out = sb.jparts; pa.ldo = proj_ldp(d); pa.ctrl = ctrl; pa.slot = io.slot; pa.node = io.node_pos;
         pa.mode = node == N_JFA ? PROJ_HEAD : (node == N_JFIN ? PROJ_FINAL : PROJ_STEP);
         if (node == N_JFA) {
           FrameArgs f = frame_args(false);
@@ -667,6 +698,9 @@ const StepOrder kOrderProdO2 = {4, {N_FA, N_Q, N_TD, N_J}, {"prenet+lstm_att", "
 // ... with step t-1's projection at the head of step t's first launch
 const StepOrder kOrderProdH = {4, {N_JFA, N_Q, N_T, N_D}, {"proj+prenet+lstm_att", "query", "attention", "lstm_dec"}};
 const StepOrder kOrderProdH2 = {3, {N_JFA, N_Q, N_TD}, {"proj+prenet+lstm_att", "query", "attention+lstm_dec"}};
+// ... and with the query as a job of the attention role's workgroups: two launches per step
+const StepOrder kOrderProdO2Q = {3, {N_FA, N_QTD, N_J}, {"prenet+lstm_att", "query+attention+lstm_dec", "proj"}};
+const StepOrder kOrderProdH2Q = {2, {N_JFA, N_QTD}, {"proj+prenet+lstm_att", "query+attention+lstm_dec"}};
 // the two-role step: LJSpeech-type cell, either arithmetic mode
 int overlap_level(const ttsdec_handle* h, int B) {
   const ttsdec_dims& d = h->d;
@@ -677,7 +711,8 @@ int overlap_level(const ttsdec_handle* h, int B) {
   // two of a CU's four matrix pipes busy - so small batches (stand-alone tile) and chip-filling ones only.  us per step for
   // levels 0 / 1 / 2: B = 32 75.3 / 67.4 / 56.4, B = 64 76.2 / 87.1 / 109.8, B = 96 100.8 / 103.9 / 114.3, B = 128 102.2 /
   // 105.2 / 115.1, B = 192 141.9 / 129.7 / 119.2, B = 256 143.2 / 138.1 / 127.3 (profiles/r02_h_levels.txt)
-  return B <= 32 ? 2 : (B >= 192 ? 2 : 0);
+  // (above 320 utterances nothing was measured for level 2: level 1 there, as in split-fp16 mode)
+  return B <= 32 ? 2 : (B < 192 ? 0 : (B <= 320 ? 2 : 1));
 }
 // The projection as the head role of the next step's frame launch, wherever the register-weight kernel applies (split-fp16).
 // us per step without / with it, same box: B = 1 43.0 / 39.8, B = 64 51.8 / 50.1, B = 128 54.2 / 53.5, B = 256 73.4 / 73.3 (there
@@ -686,9 +721,25 @@ bool head_proj(const ttsdec_handle* h, int B) {
   if (!overlap_level(h, B) || !proj_regw(h, lstm_prec(h))) return false;
   return h->head_proj != 0;  // (-1 = default = on)
 }
+// The query as a job of the attention role (fused_kernels.hip attn_lstm_kernel): needs every attention-role workgroup resident
+// at once - one per utterance, at most the chip's 256 CUs x 2 workgroups minus the LSTM role's - and whole K slices for the
+// register-weight GEMM body.
+// Measured, us per step with / without it (same box, profiles/r03_f_*): split-fp16 B = 256 60.4 / 61.6, 128 49.4 / 50.0, 64 46.6 /
+// 47.0; B = 32 44.1 / 42.5 (the roles do not share CUs there: the hop costs more than the launch), B = 1 175 / 38 (one
+// workgroup would run all 32 tiles); exact fp32 B = 256 125.0 / 125.0, B = 32 58.6 / 55.3.  So: split-fp16, 64 utterances or
+// more, at most one tile per workgroup (option query_role = 1 forces it wherever it is possible at all).
+bool query_role(const ttsdec_handle* h, int B) {
+  const ttsdec_dims& d = h->d;
+  if (overlap_level(h, B) < 2 || h->query_role == 0 || B > 256) return false;
+  const int ps = proj_split(query_k(d));
+  if (!(ps > 0 && ps <= kQuerySplit && !(d.h_att & 7))) return false;
+  if (h->query_role > 0) return true;
+  return lstm_prec(h) && B >= 64 && proj_grid_size(B, d.d_ctx, ps) <= B;
+}
 const StepOrder& step_order(const ttsdec_handle* h, int B) {
   const ttsdec_dims& d = h->d;
   if (const int lv = overlap_level(h, B)) {
+    if (lv >= 2 && query_role(h, B)) return head_proj(h, B) ? kOrderProdH2Q : kOrderProdO2Q;
     if (head_proj(h, B)) return lv >= 2 ? kOrderProdH2 : kOrderProdH;
     return lv >= 2 ? kOrderProdO2 : kOrderProdO;
   }
@@ -699,9 +750,13 @@ const StepOrder& step_order(const ttsdec_handle* h, int B) {
 // One step on a single stream, in the reference's order.  (For the Taco2 cell the attention
 // kernel at the end of step t also produces the context bmm(w_t, memory) that step t+1 starts
 // from, decoder_cell.py:118.)
-void launch_step_serial(const ttsdec_handle* h, const StepBufs& sb, const StepIo& io, hipStream_t st) {
-  const StepOrder& order = step_order(h, io.B);
-  for (int i = 0; i < order.n; ++i) launch_node(h, sb, io, order.nodes[i], st);
+void launch_step_serial(const ttsdec_handle* h, const StepBufs& sb, const StepIo& io0, hipStream_t st) {
+  const StepOrder& order = step_order(h, io0.B);
+  StepIo io = io0;
+  for (int i = 0; i < order.n; ++i) {
+    io.node_pos = i;
+    launch_node(h, sb, io, order.nodes[i], st);
+  }
 }
 
 int ensure_streams(ttsdec_handle* h) {
@@ -753,8 +808,8 @@ int ensure_graph(ttsdec_handle* h, const StepBufs& sb, const void* ws, int B, in
 
 
 // ---- options (include/ttsdec.h TTSDEC_OPT_*) ----
-const char* const kOptionNames[TTSDEC_OPT_COUNT] = {"graph",     "overlap",          "chunk_a",     "chunk_b",   "proj_regw",
-                                                    "head_proj", "profile_ablation", "debug_flags", "spin_limit"};
+const char* const kOptionNames[TTSDEC_OPT_COUNT] = {"graph",     "overlap",    "chunk_a",          "chunk_b",     "proj_regw",
+                                                    "head_proj", "query_role", "profile_ablation", "debug_flags", "spin_limit"};
 int& option_ref(ttsdec_handle* h, int o) {
   switch (o) {
     case TTSDEC_OPT_OVERLAP: return h->overlap;
@@ -762,6 +817,7 @@ int& option_ref(ttsdec_handle* h, int o) {
     case TTSDEC_OPT_CHUNK_B: return h->opt_chunk_b;
     case TTSDEC_OPT_PROJ_REGW: return h->opt_proj_regw;
     case TTSDEC_OPT_HEAD_PROJ: return h->head_proj;
+    case TTSDEC_OPT_QUERY_ROLE: return h->query_role;
     case TTSDEC_OPT_PROFILE_ABLATION: return h->profile_ablation;
     case TTSDEC_OPT_DEBUG_FLAGS: return h->debug_flags;
     case TTSDEC_OPT_SPIN_LIMIT: return h->spin_limit;
@@ -832,6 +888,7 @@ int ttsdec_create(const ttsdec_dims* dims, ttsdec_handle** out) {
   h->graph = nullptr;
   h->g_ws = h->g_blob = nullptr;
   h->wmax_dec = h->wmax_post = 0.f;
+  h->stamps_buf = nullptr;
   // Tuning / measurement options (include/ttsdec.h TTSDEC_OPT_*): library defaults, then the process-wide
   // TTSDEC_OPTIONS="name=value,..." (read here, once per handle), then ttsdec_set_option.
   // (A two-stream schedule that ran the LSTMs' early K segments beside the small critical-path kernels was built and
@@ -849,6 +906,7 @@ int ttsdec_destroy(ttsdec_handle* h) {
   if (!h) return TTSDEC_OK;
   drop_graph(h);
   if (h->streams_ready) (void)hipStreamDestroy(h->cap_stream);
+  if (h->stamps_buf) (void)hipFree(h->stamps_buf);
   delete h;
   return TTSDEC_OK;
 }
@@ -1027,10 +1085,11 @@ size_t ttsdec_workspace_bytes(const ttsdec_handle* h, int B, int L) {
   return make_ws_layout(h->d, B, L).total;
 }
 
-int ttsdec_decode(ttsdec_handle* h, const float* memory, int B, int L, int t_begin, int n_steps, int t_stride,
-                  float stop_threshold, int check_stop, int dropout_mode, const uint8_t* masks, uint64_t seed,
-                  const float* teacher, int teacher_T, const uint8_t* teacher_flags, float* y, float* s, float* w,
-                  int32_t* T_out, void* workspace, size_t workspace_bytes, void* stream) {
+// stamp_loop (ttsdec_profile_loop): every step kernel records its start time (common.h loop_stamp) in the workspace
+static int decode_impl(ttsdec_handle* h, const float* memory, int B, int L, int t_begin, int n_steps, int t_stride,
+                       float stop_threshold, int check_stop, int dropout_mode, const uint8_t* masks, uint64_t seed,
+                       const float* teacher, int teacher_T, const uint8_t* teacher_flags, float* y, float* s, float* w,
+                       int32_t* T_out, void* workspace, size_t workspace_bytes, void* stream, bool stamp_loop) {
   if (!h || !memory || !y || !s || !w || !workspace) return TTSDEC_ERR_INVALID_ARG;
   if (B <= 0 || L <= 0 || t_begin < 0 || n_steps < 0 || t_stride < n_steps) return TTSDEC_ERR_INVALID_ARG;
   if (dropout_mode < TTSDEC_DROPOUT_OFF || dropout_mode > TTSDEC_DROPOUT_PHILOX) return TTSDEC_ERR_INVALID_ARG;
@@ -1071,15 +1130,15 @@ int ttsdec_decode(ttsdec_handle* h, const float* memory, int B, int L, int t_beg
   ca.y = y; ca.s = s; ca.w = w;
   ca.debug_flags = h->debug_flags > 0 ? h->debug_flags : 0;
   ca.spin_limit = h->spin_limit > 0 ? h->spin_limit : kRoleSpinLimit;
+  ca.loop_stamps = stamp_loop ? sb.loop_stamps : nullptr;
   // measurement only: TTSDEC_STAMPS=<file> collects per-workgroup time stamps of the two-role launches of the
   // call's last step and writes them to <file> (synchronises; never set in production)
-  static unsigned long long* g_stamps = nullptr;
   const char* stamp_file = getenv("TTSDEC_STAMPS");
   ca.stamps = nullptr;
-  if (stamp_file && *stamp_file) {
-    if (!g_stamps) { HIP_TRY(h, hipMalloc(&g_stamps, kStampKinds * 1024 * 8 * sizeof(unsigned long long))); }
-    HIP_TRY(h, hipMemsetAsync(g_stamps, 0, kStampKinds * 1024 * 8 * sizeof(unsigned long long), st));
-    ca.stamps = g_stamps;
+  if (stamp_file && *stamp_file) {  // (the buffer belongs to the handle, hence to its device; freed by ttsdec_destroy)
+    if (!h->stamps_buf) { HIP_TRY(h, hipMalloc(&h->stamps_buf, kStampKinds * 1024 * 8 * sizeof(unsigned long long))); }
+    HIP_TRY(h, hipMemsetAsync(h->stamps_buf, 0, kStampKinds * 1024 * 8 * sizeof(unsigned long long), st));
+    ca.stamps = h->stamps_buf;
   }
   launch_set_call(sb.ctrl, ca, st);
   HIP_TRY(h, hipMemsetAsync(sb.dep, 0, W.dep_bytes, st));  // arrival counters count from the call's first step
@@ -1097,6 +1156,7 @@ int ttsdec_decode(ttsdec_handle* h, const float* memory, int B, int L, int t_beg
       launch_step_serial(h, sb, io, st);
     }
   }
+  io.node_pos = kLoopStampNodes - 1;     // (the end-of-call launches below stamp a node index no step launch uses)
   if (head_proj(h, B) && n_steps > 0) {  // (that step order leaves each step's projection to the NEXT step's launch)
     io.slot = (n_steps - 1) & 1;        // buffer parity of the call's last step (t_begin is even)
     launch_node(h, sb, io, N_JFIN, st);
@@ -1110,6 +1170,53 @@ int ttsdec_decode(ttsdec_handle* h, const float* memory, int B, int L, int t_beg
     if (FILE* f = fopen(stamp_file, "wb")) { fwrite(buf.data(), 1, buf.size(), f); fclose(f); }
   }
   return check_launch(h, "decode");
+}
+
+int ttsdec_decode(ttsdec_handle* h, const float* memory, int B, int L, int t_begin, int n_steps, int t_stride,
+                  float stop_threshold, int check_stop, int dropout_mode, const uint8_t* masks, uint64_t seed,
+                  const float* teacher, int teacher_T, const uint8_t* teacher_flags, float* y, float* s, float* w,
+                  int32_t* T_out, void* workspace, size_t workspace_bytes, void* stream) {
+  return decode_impl(h, memory, B, L, t_begin, n_steps, t_stride, stop_threshold, check_stop, dropout_mode, masks, seed, teacher, teacher_T,
+                     teacher_flags, y, s, w, T_out, workspace, workspace_bytes, stream, false);
+}
+
+int ttsdec_profile_loop(ttsdec_handle* h, const float* memory, int B, int L, int n_steps, int dropout_mode, const uint8_t* masks,
+                        uint64_t seed, float* y, float* s, float* w, int32_t* T_out, void* workspace, size_t workspace_bytes, void* stream,
+                        float* ms_out, const char** names_out, int n_out, int* n_kernels, float* step_ms) {
+  if (!h || !ms_out || !workspace || n_steps < 2 * kGraphSlots || n_steps % kGraphSlots) return TTSDEC_ERR_INVALID_ARG;
+  if (!h->use_graph) return TTSDEC_ERR_INVALID_ARG;  // (it is the replayed graph this function looks into)
+  const StepOrder& order = step_order(h, B);
+  if (n_kernels) *n_kernels = order.n;
+  if (n_out < order.n || order.n >= kLoopStampNodes) return TTSDEC_ERR_INVALID_ARG;
+  const WsLayout W = make_ws_layout(h->d, B, L);
+  if (workspace_bytes < W.total) return TTSDEC_ERR_WORKSPACE;
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  int rc = decode_impl(h, memory, B, L, 0, n_steps, n_steps, -1e30f, 0, dropout_mode, masks, seed, nullptr, 0, nullptr, y, s, w, T_out, workspace,
+                       workspace_bytes, stream, true);
+  if (rc != TTSDEC_OK) return rc;
+  unsigned long long t[kLoopStampSlots * kLoopStampNodes];
+  HIP_TRY(h, hipStreamSynchronize(st));
+  HIP_TRY(h, hipMemcpy(t, static_cast<char*>(workspace) + W.loop_stamps, sizeof(t), hipMemcpyDeviceToHost));
+  // the LAST replay's start times: slots 0 .. kGraphSlots-1; a launch's span = the next launch's start - its own
+  // (s_memrealtime ticks of 10 ns); the last launch of the last slot has no successor inside the replay and is left out
+  double total = 0.0;
+  for (int k = 0; k < order.n; ++k) {
+    double sum = 0.0;
+    int cnt = 0;
+    for (int i = 0; i < kGraphSlots; ++i) {
+      const bool last = k + 1 == order.n;
+      if (last && i + 1 == kGraphSlots) continue;
+      const unsigned long long a = t[i * kLoopStampNodes + k], b = last ? t[(i + 1) * kLoopStampNodes] : t[i * kLoopStampNodes + k + 1];
+      if (a == 0 || b <= a) return TTSDEC_ERR_INVALID_ARG;  // (a launch that did not stamp: not a step kernel this function knows)
+      sum += (double)(b - a) * 1e-5;  // ms
+      ++cnt;
+    }
+    ms_out[k] = (float)(sum / cnt);
+    if (names_out) names_out[k] = order.names[k];
+    total += ms_out[k];
+  }
+  if (step_ms) *step_ms = (float)total;
+  return TTSDEC_OK;
 }
 
 size_t ttsdec_postnet_workspace_bytes(const ttsdec_handle* h, int B, int T) {
@@ -1394,7 +1501,8 @@ int ttsdec_profile_step(ttsdec_handle* h, const float* memory, int B, int L, int
   const char* names[kMaxKernelsPerStep + 4];
   int nn = 0;
   for (int k = 0; k < order.n; ++k) { nodes[nn] = order.nodes[k]; names[nn++] = order.names[k]; }
-  if ((&order == &kOrderProdO || &order == &kOrderProdO2 || &order == &kOrderProdH || &order == &kOrderProdH2) && n_out >= order.n + 4) {
+  if ((&order == &kOrderProdO || &order == &kOrderProdO2 || &order == &kOrderProdH || &order == &kOrderProdH2 || &order == &kOrderProdO2Q ||
+       &order == &kOrderProdH2Q) && n_out >= order.n + 4) {
     const Node extra[4] = {N_F, N_AG, N_T, N_DG};
     const char* extra_names[4] = {"prenet(alone)", "lstm_att_lean(alone)", "attention(alone)", "lstm_dec_lean(alone)"};
     for (int k = 0; k < 4; ++k) { nodes[nn] = extra[k]; names[nn++] = extra_names[k]; }

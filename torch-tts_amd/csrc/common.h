@@ -47,8 +47,20 @@ struct Ctrl {
   // test hooks (include/ttsdec.h TTSDEC_OPT_DEBUG_FLAGS / _SPIN_LIMIT): bit 0 = the frame role does not signal, bit 1 = the
   // attention role does not, bit 2 = the projection head role does not; polls before role_wait gives up
   int debug_flags, spin_limit;
-  int pad[24];
+  // measurement only (ttsdec_profile_loop): when set, workgroup 0 of every step kernel stores its entry time at
+  // loop_stamps[slot * kLoopStampNodes + position of the launch in the step order] - the launches' start times inside the
+  // replayed graph, at the price of one 8-byte store per launch
+  unsigned long long* loop_stamps;
+  int pad[22];
 };
+constexpr int kLoopStampNodes = 8;   // >= launches per step
+constexpr int kLoopStampSlots = 32;  // >= steps per captured graph
+__device__ __forceinline__ void loop_stamp(const Ctrl* c, int slot, int node) {
+  if (c != nullptr && blockIdx.x == 0 && blockIdx.y == 0 && blockIdx.z == 0 && threadIdx.x == 0) {
+    unsigned long long* p = c->loop_stamps;
+    if (p != nullptr && slot < kLoopStampSlots) p[slot * kLoopStampNodes + node] = __builtin_amdgcn_s_memrealtime();
+  }
+}
 constexpr int kStampKinds = 3;
 // stamps[(kind * 1024 + block) * 8 + k]; kind 0 = frame || lstm_att, 1 = attention || lstm_dec, 2 = the projection role at the head of
 // kind 0's launch (k: 2 = entry, 3 = control block and operands arrived, 4 = partial tile reduced, 5 = signalled);
@@ -318,7 +330,7 @@ constexpr int kRoleSpinLimit = 1 << 17;  // x ~0.25 us of s_sleep + the poll's r
 // workgroup waits for the slowest producer of the whole chip, and no counter takes more than 64 adds per step (96 adds to
 // ONE word took the projection role's signal ~1.5 us; MI355X_MICROARCH.md "fanin").
 constexpr int kDepLine = 32;  // unsigned ints per counter line
-enum DepKind { DEP_FRAME = 0, DEP_ATTN = 1, DEP_PROJ = 2, DEP_KINDS = 3 };
+enum DepKind { DEP_FRAME = 0, DEP_ATTN = 1, DEP_PROJ = 2, DEP_QUERY = 3, DEP_KINDS = 4 };
 // the poll alone: for a consumer that takes every handed-off byte with sc1 loads (load_wt), or that only wants to know.
 // Two counters (c1 may be nullptr): a consumer whose rows span two of the producers' 32-row blocks.
 __device__ __forceinline__ void role_poll(const unsigned int* c0, unsigned int target0, Ctrl* ctrl, const unsigned int* c1 = nullptr,

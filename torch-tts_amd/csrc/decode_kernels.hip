@@ -59,6 +59,7 @@ struct LoaderW {
 
 template <class Cfg, int AK, int EK>
 __global__ __launch_bounds__(kGemmThreads, Cfg::kWavesPerSimd) void gemm_rows_kernel(GemmArgs g) {
+  loop_stamp(g.ctrl, g.slot, g.node);
   bool live = true;
   if (g.ctrl != nullptr) {  // step kernel inside a decode call: "now" and the call's buffers come from *ctrl
     const Ctrl* c = g.ctrl;
@@ -393,6 +394,7 @@ void launch_gemm(const GemmArgs& a, AKind ak, EpiKind ek, hipStream_t st) {
 // list the two cells of a decode step as separate kernels.
 template <class Cfg, int TAG = 0>
 __global__ __launch_bounds__(kGemmThreads) void lstm_kernel(LstmArgs g) {
+  loop_stamp(g.ctrl, g.slot, g.node);
   __shared__ __attribute__((aligned(16))) float smem[Cfg::kLdsFloats];
   lstm_body<Cfg>(g, smem, blockIdx.x, blockIdx.y);
 }
@@ -476,6 +478,7 @@ void launch_lstm(const LstmArgs& a, hipStream_t st) {
 // ===========================================================================
 template <int NJ>
 __global__ __launch_bounds__(kAttnThreads) void attn_kernel(AttnArgs g) {
+  loop_stamp(g.ctrl, g.slot, g.node);
   __shared__ __attribute__((aligned(16))) float part[attn_lds_floats<NJ>()];
   attn_body<NJ>(g, part, blockIdx.x);
 }
@@ -572,6 +575,7 @@ __global__ void set_call_kernel(Ctrl* c, CallArgs a) {
   c->stamps = a.stamps;
   c->debug_flags = a.debug_flags;
   c->spin_limit = a.spin_limit;
+  c->loop_stamps = a.loop_stamps;
 }
 void launch_set_call(Ctrl* ctrl, const CallArgs& a, hipStream_t st) {
   hipLaunchKernelGGL(set_call_kernel, dim3(1), dim3(1), 0, st, ctrl, a);

@@ -580,9 +580,9 @@ __device__ __forceinline__ void proj_body(ProjArgs g, float* red, int id) {
     else if (g.mode == PROJ_FINAL) live = c->t_end > c->t_call && c->t_end - 1 <= c->stop_t;
     else live = t < c->t_end && t <= c->stop_t;
     if (!live) return;
-    signal = g.mode == PROJ_HEAD;
+    signal = g.mode == PROJ_HEAD || g.mode == PROJ_QUERY;
   }
-  const stamp_ptr st = signal ? stamps_of(g.ctrl) : (stamp_ptr) nullptr;
+  const stamp_ptr st = g.mode == PROJ_HEAD && signal ? stamps_of(g.ctrl) : (stamp_ptr) nullptr;
   const unsigned long long t_ctrl = now_rt();
 
   f32x16 acc = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};

@@ -20,12 +20,14 @@ namespace ttsdec {
 // NI: projection columns per thread (16 * NI >= r*d_mel + r); 6 covers one frame per step with half the partial-sum loads
 template <int K0H, int PH, int PREC, int NI>
 __global__ __launch_bounds__(kFrameThreads) void frame_kernel(FrameArgs g) {
+  loop_stamp(g.ctrl, g.slot, g.node);
   __shared__ __attribute__((aligned(16))) float lds[FrameLds<K0H, PH, PREC>::kFloats];
   frame_body<K0H, PH, PREC, NI>(g, lds, blockIdx.x, blockIdx.y);
 }
 
 template <int PREC>
 __global__ __launch_bounds__(kFrameThreads) void proj_kernel(ProjArgs g) {
+  loop_stamp(g.ctrl, g.slot, g.node);
   __shared__ __attribute__((aligned(16))) float red[kProjLdsFloats];
   proj_body<PREC>(g, red, blockIdx.x);
 }

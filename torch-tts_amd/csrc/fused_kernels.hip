@@ -70,6 +70,7 @@ __global__ __launch_bounds__(kGemmThreads, WPE) void frame_lstm_kernel(FrameArgs
                                                                        int lstm_cols) {
   constexpr int PREC = Cfg::kPrec;
   __shared__ __attribute__((aligned(16))) float smem[cmax<cmax<Cfg::kLdsFloats, FrameLds<K0H, PH, PREC>::kFloats>(), kHead ? kProjLdsFloats : 1>()];
+  loop_stamp(f.ctrl, f.slot, f.node);
   int id = blockIdx.x;
   if constexpr (kHead) {
     if (id < n_proj) {
@@ -89,12 +90,25 @@ __global__ __launch_bounds__(kGemmThreads, WPE) void frame_lstm_kernel(FrameArgs
 }
 
 // ---- role A = attention + context, role B = early part of the decoder LSTM ----
+// Query role: the attention role's workgroups first compute the attention query GEMM between them (AttnArgs::q_tiles tiles
+// of proj_body, workgroup b the tiles b, b + B, ...), each signalling its tile's 32-row block; an attention pass starts once
+// the tiles of its utterance's row block are in.  The step loses the query launch (~6.5 us) and gains a hop inside this one,
+// on a role that has slack: the decoder LSTM reaches its gate at ~22 us, the attention pass used to end at ~15.
+// All attention-role workgroups must be resident together for this (they have the lowest block ids; B <= the chip's two
+// workgroups per CU): the host only asks for it then.
 template <int NJ, class Cfg, int WPE>
-__global__ __launch_bounds__(kGemmThreads, WPE) void attn_lstm_kernel(AttnArgs a, LstmArgs l, int n_attn, int lstm_cols) {
-  __shared__ __attribute__((aligned(16))) float smem[cmax<Cfg::kLdsFloats, attn_lds_floats<NJ>()>()];
+__global__ __launch_bounds__(kGemmThreads, WPE) void attn_lstm_kernel(AttnArgs a, LstmArgs l, ProjArgs pq, int n_attn, int lstm_cols) {
+  __shared__ __attribute__((aligned(16))) float smem[cmax<cmax<Cfg::kLdsFloats, attn_lds_floats<NJ>()>(), kProjLdsFloats>()];
+  loop_stamp(a.ctrl, a.slot, a.node);
   const int id = blockIdx.x;
   if (id < n_attn) {
     __builtin_amdgcn_s_setprio(3);  // (as above: the decoder LSTM's last segment waits for every one of these)
+    if (a.q_tiles > 0) {
+      for (int tile = id; tile < a.q_tiles; tile += n_attn) {
+        proj_body<Cfg::kPrec>(pq, smem, tile);
+        __syncthreads();  // (the reduction tile in LDS is reused by the next tile / the attention pass)
+      }
+    }
     attn_body<NJ>(a, smem, id);
   } else {
     const int j = id - n_attn;
@@ -156,21 +170,24 @@ void launch_frame_lstm(const FrameArgs& f, const LstmArgs& l, hipStream_t st) {
 void launch_proj_frame_lstm(const ProjArgs& pj, const FrameArgs& f, const LstmArgs& l, hipStream_t st) { launch_frame_lstm_any<true>(f, l, pj, st); }
 
 template <int NJ, int PREC>
-static void launch_attn_lstm_nj(const AttnArgs& a, const LstmArgs& l, hipStream_t st) {
+static void launch_attn_lstm_nj(const AttnArgs& a, const LstmArgs& l, const ProjArgs& pq, hipStream_t st) {
   using TL = LeanTiles<PREC>;
   const LeanKind kind = lean_kind(l.M, a.B, l.H);
   const int lcols = kind == LEAN_64x16 ? (l.H + 15) / 16 : (l.H + 7) / 8;
   const int lrows = kind == SMALL_FAT ? (l.M + 31) / 32 : (l.M + 63) / 64;
   dim3 grid(a.B + lcols * lrows), block(kGemmThreads);
-  if (kind == SMALL_FAT) hipLaunchKernelGGL((attn_lstm_kernel<NJ, typename TL::SmallFat, 2>), grid, block, 0, st, a, l, a.B, lcols);
-  else if (kind == LEAN_64x8) hipLaunchKernelGGL((attn_lstm_kernel<NJ, typename TL::Lean64x8, 4>), grid, block, 0, st, a, l, a.B, lcols);
-  else hipLaunchKernelGGL((attn_lstm_kernel<NJ, typename TL::Lean64x16, 4>), grid, block, 0, st, a, l, a.B, lcols);
+  if (kind == SMALL_FAT) hipLaunchKernelGGL((attn_lstm_kernel<NJ, typename TL::SmallFat, 2>), grid, block, 0, st, a, l, pq, a.B, lcols);
+  else if (kind == LEAN_64x8) hipLaunchKernelGGL((attn_lstm_kernel<NJ, typename TL::Lean64x8, 4>), grid, block, 0, st, a, l, pq, a.B, lcols);
+  else hipLaunchKernelGGL((attn_lstm_kernel<NJ, typename TL::Lean64x16, 4>), grid, block, 0, st, a, l, pq, a.B, lcols);
 }
-void launch_attn_lstm(const AttnArgs& a, const LstmArgs& l, hipStream_t st) {
+void launch_attn_lstm(const AttnArgs& a, const LstmArgs& l, const ProjArgs* q, hipStream_t st) {
   if (a.B <= 0) return;
   const bool f16 = l.prec == 1;
-  if (a.D / 4 <= 64) { if (f16) launch_attn_lstm_nj<1, PREC_F16S>(a, l, st); else launch_attn_lstm_nj<1, PREC_F32>(a, l, st); }
-  else { if (f16) launch_attn_lstm_nj<2, PREC_F16S>(a, l, st); else launch_attn_lstm_nj<2, PREC_F32>(a, l, st); }
+  ProjArgs pq;
+  if (q != nullptr) pq = *q;
+  else memset(&pq, 0, sizeof(pq));
+  if (a.D / 4 <= 64) { if (f16) launch_attn_lstm_nj<1, PREC_F16S>(a, l, pq, st); else launch_attn_lstm_nj<1, PREC_F32>(a, l, pq, st); }
+  else { if (f16) launch_attn_lstm_nj<2, PREC_F16S>(a, l, pq, st); else launch_attn_lstm_nj<2, PREC_F32>(a, l, pq, st); }
 }
 
 void launch_lstm_lean(const LstmArgs& l, hipStream_t st) {

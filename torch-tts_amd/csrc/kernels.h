@@ -66,6 +66,7 @@ struct GemmArgs {
   // ctrl == nullptr (postnet, cell_step, profiling): everything comes from this struct.
   Ctrl* ctrl;
   int slot;
+  int node;  // position of the launch in the step order (measurement: common.h loop_stamp)
   int t;  // absolute step index when ctrl == nullptr
 };
 
@@ -103,6 +104,7 @@ struct LstmArgs {
   int seq_out_ld, seq_out_off;
   Ctrl* ctrl;
   int slot;
+  int node;  // position of the launch in the step order (measurement: common.h loop_stamp)
   int dbg;  // measurement ablations (ttsdec_profile_step only): 1 = every load reads the zero block
   int tag;  // 1 = the decoder LSTM of a decode step (separate kernel symbol for profilers), else 0
   int live_lag;  // 1: this cell runs in the same launch as the frame kernel of its step (see lstm_body)
@@ -130,9 +132,16 @@ struct AttnArgs {
   int ctx_only;         // 1: no weight update, just ctx = sum_l w_prev[l] * memory[l] (decoder_cell.py:118)
   int dep_signal;       // 1: two-role launch - every workgroup signals dep_cnt[(b / 32) * kDepLine] after its last store
   unsigned int* dep_cnt;
+  // Query role (fused_kernels.hip): BEFORE its attention pass workgroup b computes tiles b, b + B, ... of the q_tiles 32 x 32 x
+  // K-slice tiles of the query GEMM (the launch's ProjArgs, frame_body.h proj_body) and signals q_cnt[32-row block of the
+  // tile]; the attention pass then waits until the q_wait_n tiles of ITS row block have arrived (per step) and takes q with
+  // sc1 loads.  q_tiles = 0: q comes from an earlier launch.
+  int q_tiles, q_wait_n;
+  unsigned int* q_cnt;
   int B, L, D, t_rel, t_stride;
   Ctrl* ctrl;  // != nullptr: memory, w_out, t_rel, t_stride come from *ctrl
   int slot;
+  int node;  // position of the launch in the step order (measurement: common.h loop_stamp)
 };
 void launch_attn(const AttnArgs& a, hipStream_t st);
 
@@ -174,6 +183,7 @@ struct FrameArgs {
   int M;
   Ctrl* ctrl;
   int slot;
+  int node;  // position of the launch in the step order (measurement: common.h loop_stamp)
   int t;    // ctrl == nullptr
   int dbg;  // measurement ablations (ttsdec_profile_step only): bit 1 = no layer-0 MFMAs, bit 2 = no layer-1 MFMAs
   int dep_signal;  // 1: two-role launch - every workgroup signals dep_cnt[row block * kDepLine] after its last store
@@ -201,6 +211,7 @@ struct ProjArgs {
   int ldo;
   Ctrl* ctrl;            // != nullptr: the launch does nothing unless its step is live (see mode)
   int slot;
+  int node;              // position of the launch in the step order (measurement: common.h loop_stamp)
   // mode 0: a launch of its own at the end of step t = ctrl->t_cur + slot.  mode 1 (PROJ_HEAD): a ROLE at the head of step t's
   // frame launch, computing step t-1's projection - live like that launch's finalize phase (t-1 <= stop_t, t > t_call) - whose
   // slabs are stored write-through and signalled through dep_cnt[32-row block * kDepLine].  mode 2 (PROJ_FINAL): the projection of the call's
@@ -208,7 +219,8 @@ struct ProjArgs {
   int mode;
   unsigned int* dep_cnt;
 };
-enum ProjMode { PROJ_STEP = 0, PROJ_HEAD = 1, PROJ_FINAL = 2 };
+// PROJ_QUERY: live like PROJ_STEP, signals like PROJ_HEAD - the attention query as a job of the attention role's workgroups
+enum ProjMode { PROJ_STEP = 0, PROJ_HEAD = 1, PROJ_FINAL = 2, PROJ_QUERY = 3 };
 int proj_split(int K);  // the ksplit of this kernel for K, or 0 when it does not cover K
 void launch_proj(const ProjArgs& a, hipStream_t st);
 
@@ -221,7 +233,7 @@ void launch_frame_lstm(const FrameArgs& f, const LstmArgs& l, hipStream_t st);  
 // ... with the previous step's mel/stop projection as a role at its head: proj(t-1) -> frame(t) || lstm_att(t)
 void launch_proj_frame_lstm(const ProjArgs& pj, const FrameArgs& f, const LstmArgs& l, hipStream_t st);
 int proj_grid_size(int M, int N, int ksplit);  // workgroups of the projection kernel / role
-void launch_attn_lstm(const AttnArgs& a, const LstmArgs& l, hipStream_t st);    // attention || decoder LSTM
+void launch_attn_lstm(const AttnArgs& a, const LstmArgs& l, const ProjArgs* q, hipStream_t st);  // [query ->] attention || decoder LSTM
 void launch_lstm_lean(const LstmArgs& l, hipStream_t st);                       // an LSTM on the lean tile alone (profiling)
 
 // ---- state init / bookkeeping ----
@@ -250,6 +262,7 @@ struct CallArgs {  // copied into *ctrl by launch_set_call at the start of every
   float *y, *s, *w;
   unsigned long long* stamps;  // measurement only
   int debug_flags, spin_limit;  // test hooks (Ctrl)
+  unsigned long long* loop_stamps;  // measurement only (Ctrl)
 };
 void launch_set_call(Ctrl* ctrl, const CallArgs& a, hipStream_t st);
 void launch_advance(Ctrl* ctrl, int n_slots, hipStream_t st);

@@ -254,11 +254,23 @@ __device__ __forceinline__ void attn_body(AttnArgs g, float* part, int b) {
   float* wnew = g.w_new + (size_t)b * L;
   const auto wout = as_g(g.w_out ? g.w_out + ((size_t)b * g.t_stride + g.t_rel) * L : nullptr);
 
+  // q of this utterance: from an earlier launch, or (query role) from workgroups of this very launch - then behind the
+  // arrival counter of the utterance's 32-row block and with sc1 loads (common.h load_wt; the slabs were stored write-through
+  // and drained before each signal)
+  const bool q_here = g.q_tiles > 0 && g.ctrl != nullptr;
+  if (q_here) {
+    if (wv == 0) role_poll(g.q_cnt + (b / 32) * kDepLine, (unsigned int)(g.t_rel + 1) * (unsigned int)g.q_wait_n, g.ctrl);
+    lds_barrier();
+  }
+  auto load_q4 = [&](const float* p) {
+    if (q_here) return make_float4(load_wt(p), load_wt(p + 1), load_wt(p + 2), load_wt(p + 3));
+    return *reinterpret_cast<const float4*>(p);
+  };
   float4 qv[NJ];
 #pragma unroll
   for (int j = 0; j < NJ; ++j) {
     const int c4 = lane + 64 * j;
-    qv[j] = (c4 < D4 && !g.ctx_only) ? *reinterpret_cast<const float4*>(g.q + (size_t)b * D + c4 * 4)
+    qv[j] = (c4 < D4 && !g.ctx_only) ? load_q4(g.q + (size_t)b * D + c4 * 4)
                                      : make_float4(0.f, 0.f, 0.f, 0.f);  // ctx_only: no query, energies unused
   }
   if (!g.ctx_only) {  // split-K query: add the partial slabs in index order
@@ -267,7 +279,7 @@ __device__ __forceinline__ void attn_body(AttnArgs g, float* part, int b) {
       for (int j = 0; j < NJ; ++j) {
         const int c4 = lane + 64 * j;
         if (c4 < D4) {
-          const float4 v = *reinterpret_cast<const float4*>(g.q + z * g.q_stride + (size_t)b * D + c4 * 4);
+          const float4 v = load_q4(g.q + z * g.q_stride + (size_t)b * D + c4 * 4);
           qv[j].x = add_rn(qv[j].x, v.x); qv[j].y = add_rn(qv[j].y, v.y);
           qv[j].z = add_rn(qv[j].z, v.z); qv[j].w = add_rn(qv[j].w, v.w);
         }

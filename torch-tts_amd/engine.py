@@ -303,6 +303,30 @@ class Engine:
         return {names[i].decode(): float(ms[i]) for i in range(nk.value)}
 
 
+    def profile_loop(self, memory: Tensor, n_steps: int, dropout_mode: int, masks: Optional[Tensor], seed: int):
+        """Per-launch time (ms) INSIDE the replayed graph of the step loop and the loop's time per step; see
+        ttsdec_profile_loop (n_steps: a multiple of 30, at least 60)."""
+        B, L, _ = memory.shape
+        d = self.dims
+        y = torch.empty(B, n_steps * d.r, d.d_mel, device=self.device)
+        s = torch.empty(B, n_steps * d.r, device=self.device)
+        w = torch.empty(B, n_steps, L, device=self.device)
+        t_out = torch.zeros(2, dtype=torch.int32, device=self.device)
+        ws = self.workspace(B, L)
+        ms = (C.c_float * 16)()
+        names = (C.c_char_p * 16)()
+        nk = C.c_int(0)
+        step = C.c_float(0.0)
+        with torch.cuda.device(self.device):
+            rc = self._lib.ttsdec_profile_loop(
+                self._h, memory.data_ptr(), B, L, n_steps, dropout_mode, _ptr(masks), seed & 0xFFFFFFFFFFFFFFFF,
+                y.data_ptr(), s.data_ptr(), w.data_ptr(), t_out.data_ptr(), ws.data_ptr(), ws.numel(), _stream(self.device),
+                ms, names, 16, C.byref(nk), C.byref(step),
+            )
+        _lib.check(rc, "ttsdec_profile_loop", self._h)
+        return {names[i].decode(): float(ms[i]) for i in range(nk.value)}, float(step.value)
+
+
 class EngineCache:
     """Per-device engines of one module.  Lives in the module's __dict__ but is
     dropped on pickling / deepcopy, and shared (keyed by device) by the replicas
