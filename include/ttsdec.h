@@ -389,6 +389,11 @@ typedef struct ttsvits_handle ttsvits_handle;
  * A NULL entry leaves that tensor zero (a module that owns only the text encoder or only the flow). */
 int ttsvits_create(const ttsvits_dims* dims, ttsvits_handle** out);
 int ttsvits_destroy(ttsvits_handle* h);
+/* Arithmetic of every GEMM of the two entry points below: TTSDEC_PREC_SPLIT_F16 (default: hi + lo fp16 planes, fp32 accumulate)
+ * or TTSDEC_PREC_F32 (exact fp32 matrix instruction); both forms of the weights live in the packed blob, so this can be
+ * switched at any time.  Attention and the elementwise math are fp32 in both modes. */
+int ttsvits_set_precision(ttsvits_handle* h, int precision);
+int ttsvits_get_precision(const ttsvits_handle* h);
 const char* ttsvits_last_hip_error(const ttsvits_handle* h);
 int ttsvits_num_weight_tensors(const ttsvits_handle* h);
 size_t ttsvits_packed_bytes(const ttsvits_handle* h);

@@ -346,3 +346,48 @@ def test_blob_key_sees_invalidate_but_not_data_edits():
     for m in (pickle.loads(pickle.dumps(dec)), copy.deepcopy(dec)):
         assert set(m.state_dict()) == set(dec.state_dict())
         m.load_state_dict(dec.state_dict())
+
+
+def test_options_api_and_env_presets_host_only(monkeypatch):
+    """ttsdec_set_option / get_option / option_name and the TTSDEC_OPTIONS preset (include/ttsdec.h): host-only, no GPU."""
+    ids = _lib.option_ids()
+    assert {"graph", "overlap", "chunk_a", "chunk_b", "proj_regw", "head_proj", "query_role", "profile_ablation", "debug_flags", "spin_limit"} <= set(ids)
+    assert _lib.load().ttsdec_option_name(len(ids)) is None and _lib.load().ttsdec_option_name(-1) is None
+    e = T.Engine(T.EngineDims(postnet_layers=3), None)
+    assert all(e.get_option(n) in (-1, 0) for n in ids)  # library defaults
+    e.set_option("overlap", 1)
+    e.set_option("spin_limit", 77)
+    assert e.get_option("overlap") == 1 and e.get_option("spin_limit") == 77 and e.get_option("graph") == -1
+    lib = _lib.load()
+    import ctypes as C
+    assert lib.ttsdec_set_option(e._h, 999, 1) == _lib.ERR_INVALID_ARG and lib.ttsdec_set_option(None, 0, 1) == _lib.ERR_INVALID_ARG
+    assert lib.ttsdec_get_option(e._h, 0, None) == _lib.ERR_INVALID_ARG
+    v = C.c_int(5)
+    assert lib.ttsdec_get_option(e._h, -3, C.byref(v)) == _lib.ERR_INVALID_ARG
+    # presets: well-formed items apply, junk is ignored (never a crash: the string comes from the environment)
+    monkeypatch.setenv("TTSDEC_OPTIONS", "overlap=2,,graph=0,=5,nonsense,head_proj=,query_role=0=1,spin_limit=123456789012345,chunk_b=0,")
+    e2 = T.Engine(T.EngineDims(postnet_layers=0), None)
+    assert (e2.get_option("overlap"), e2.get_option("graph"), e2.get_option("chunk_b"), e2.get_option("chunk_a")) == (2, 0, 0, -1)
+    assert e2.get_option("head_proj") == 0 and e2.get_option("query_role") == 0 and e2.get_option("spin_limit") == 0x7FFFFFFF
+    monkeypatch.setenv("TTSDEC_OPTIONS", "x" * 5000 + ",overlap=1")
+    assert T.Engine(T.EngineDims(), None).get_option("overlap") == 1
+
+
+def test_workspace_and_blob_layouts_over_many_shapes_host_only():
+    """The carving arithmetic of api.hip (run under ASan / UBSan by tools/build_asan.sh): sizes are positive, 256-byte granular,
+    monotone in B and L, and zero / error for nonsense - for every cell and postnet type."""
+    for cell, ph in ((_lib.CELL_TACO2PROD, 0), (_lib.CELL_TACO2, 128)):
+        for pt, layers in ((_lib.POSTNET_TYPE_MEL, 5), (_lib.POSTNET_TYPE_MEL2, 2), (_lib.POSTNET_TYPE_MEL, 0)):
+            d = T.EngineDims(r=2 if cell == _lib.CELL_TACO2 else 1, cell_type=cell, d_pre_hidden=ph, postnet_type=pt, postnet_layers=layers)
+            e = T.Engine(d, None)
+            assert e.packed_bytes() > 0 and e.packed_bytes() % 256 == 0 and e.num_weight_tensors() >= 21
+            prev = 0
+            for B in (1, 3, 31, 32, 33, 64, 65, 255, 256, 257, 2048, 8192):
+                sizes = [e.workspace_bytes(B, L) for L in (1, 2, 120, 521)]
+                assert all(s > 0 and s % 256 == 0 for s in sizes) and sizes == sorted(sizes), (B, sizes)
+                assert sizes[2] >= prev
+                prev = sizes[2]
+                if layers:
+                    assert e.postnet_workspace_bytes(B, 600) > e.postnet_workspace_bytes(B, 1) > 0
+            assert e.workspace_bytes(0, 5) == 0 and e.workspace_bytes(5, 0) == 0 and e.workspace_bytes(-1, -1) == 0
+            assert e.postnet_workspace_bytes(0, 1) == 0

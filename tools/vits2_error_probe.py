@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Where does the reverse flow's error against the CPU oracle come from?  Prints, per number of coupling layers,
 max abs error, the scale of the reference and the error in units of the 1e-4 / 1e-5 bar - with the library's GEMMs in
-split-fp16 (default) and in exact fp32 (TTSVITS_F32=1, measurement switch)."""
+split-fp16 (default) and in exact fp32 (module attribute precision = "f32": ttsvits_set_precision)."""
 import os
 import sys
 
@@ -29,6 +29,7 @@ for n_flows in (1, 2, 4):
     sd = {k[len("flow."):]: v for k, v in wts.items() if k.startswith("flow.")}
     missing, unexpected = fl.load_state_dict(sd, strict=False)
     fl = fl.cuda().eval()
+    fl.precision = os.environ.get("VITS_PRECISION", "split_f16")
     with torch.no_grad():
         out = fl(z.cuda(), ymask.cuda(), reverse=True).cpu()
     def rep(name, a, b):

@@ -67,6 +67,8 @@ SYMBOLS = (
     "ttsenc_forward",
     "ttsvits_create",
     "ttsvits_destroy",
+    "ttsvits_set_precision",
+    "ttsvits_get_precision",
     "ttsvits_last_hip_error",
     "ttsvits_num_weight_tensors",
     "ttsvits_packed_bytes",
@@ -235,6 +237,10 @@ def load() -> C.CDLL:
         lib.ttsvits_create.argtypes = [C.POINTER(VitsDims), C.POINTER(vp)]
         lib.ttsvits_destroy.restype = i32
         lib.ttsvits_destroy.argtypes = [vp]
+        lib.ttsvits_set_precision.restype = i32
+        lib.ttsvits_set_precision.argtypes = [vp, i32]
+        lib.ttsvits_get_precision.restype = i32
+        lib.ttsvits_get_precision.argtypes = [vp]
         lib.ttsvits_last_hip_error.restype = C.c_char_p
         lib.ttsvits_last_hip_error.argtypes = [vp]
         lib.ttsvits_num_weight_tensors.restype = i32

@@ -844,7 +844,10 @@ void apply_env_options(ttsdec_handle* h) {
       if (eq != std::string::npos) {
         const std::string name = item.substr(0, eq);
         for (int o = 0; o < TTSDEC_OPT_COUNT; ++o)
-          if (name == kOptionNames[o]) option_ref(h, o) = atoi(item.c_str() + eq + 1);
+          if (name == kOptionNames[o]) {
+            const long v = strtol(item.c_str() + eq + 1, nullptr, 10);  // (saturates; the string comes from the environment)
+            option_ref(h, o) = v > 0x7fffffffL ? 0x7fffffff : (v < -0x7fffffffL ? -0x7fffffff : (int)v);
+          }
       }
       pos = end + 1;
     }

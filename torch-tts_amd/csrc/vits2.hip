@@ -50,6 +50,7 @@ struct ttsvits_handle {
   VitsBlob bl;
   const float* blob;
   int device;  // HIP device current at create (-1: none); must be current for every later call
+  int precision;  // TTSDEC_PREC_SPLIT_F16 (default) or TTSDEC_PREC_F32: arithmetic of every GEMM (ttsvits_set_precision)
   std::string hip_err;
 };
 
@@ -878,7 +879,7 @@ int run_stack(ttsvits_handle* h, const StackBlob& sb, const StackDims& sd, const
 size_t stack_ws_floats(const StackDims& sd, size_t M) {
   return M * (size_t)(4 * sd.C + 3 * sd.C + sd.F + (sd.C > sd.F ? sd.C : sd.F) + 3 * sd.C + sd.F) + 13 * kAlign;
 }
-StackWs carve_stack(float*& p, const StackDims& sd, size_t M) {
+StackWs carve_stack(float*& p, const StackDims& sd, size_t M, bool split) {
   auto take = [&](size_t n) { float* r = p; p += up(n, kAlign); return r; };
   StackWs w;
   w.x = take(M * sd.C); w.xm = take(M * sd.C); w.qkv = take(M * 3 * sd.C); w.att = take(M * sd.C); w.t = take(M * sd.C);
@@ -886,7 +887,7 @@ StackWs carve_stack(float*& p, const StackDims& sd, size_t M) {
   w.cx.planes = reinterpret_cast<f16*>(take(M * (sd.C > sd.F ? sd.C : sd.F)));  // hi + lo planes of one A operand (fallback)
   w.x_p = reinterpret_cast<f16*>(take(M * sd.C)); w.xm_p = reinterpret_cast<f16*>(take(M * sd.C));
   w.att_p = reinterpret_cast<f16*>(take(M * sd.C)); w.f_p = reinterpret_cast<f16*>(take(M * sd.F));
-  w.cx.split = !getenv("TTSVITS_F32");  // (measurement switch: exact fp32 MFMAs for every GEMM)
+  w.cx.split = split;  // (ttsvits_set_precision: split-fp16 planes, or exact fp32 MFMAs for every GEMM)
   return w;
 }
 
@@ -957,9 +958,16 @@ int ttsvits_create(const ttsvits_dims* dims, ttsvits_handle** out) {
   h->bl = make_layout(*dims);
   h->blob = nullptr;
   h->device = current_device_or_minus1();
+  h->precision = TTSDEC_PREC_SPLIT_F16;
   *out = h;
   return TTSDEC_OK;
 }
+int ttsvits_set_precision(ttsvits_handle* h, int precision) {
+  if (!h || (precision != TTSDEC_PREC_F32 && precision != TTSDEC_PREC_SPLIT_F16)) return TTSDEC_ERR_INVALID_ARG;
+  h->precision = precision;
+  return TTSDEC_OK;
+}
+int ttsvits_get_precision(const ttsvits_handle* h) { return h ? h->precision : TTSDEC_ERR_INVALID_ARG; }
 int ttsvits_destroy(ttsvits_handle* h) {
   delete h;
   return TTSDEC_OK;
@@ -1036,7 +1044,7 @@ int ttsvits_text_encoder(ttsvits_handle* h, const int64_t* ids, const int32_t* l
   const int M = B * T, H = d.hidden_channels, I = d.inter_channels;
   float* p = static_cast<float*>(workspace);
   const StackDims sd = enc_dims(d);
-  StackWs sw = carve_stack(p, sd, (size_t)M);
+  StackWs sw = carve_stack(p, sd, (size_t)M, h->precision == TTSDEC_PREC_SPLIT_F16);
   float* mask = p; p += up((size_t)M, kAlign);
   float* stats = p;
   // models.py:370-376
@@ -1078,7 +1086,7 @@ int ttsvits_flow_reverse(ttsvits_handle* h, const float* z, const int32_t* lengt
   const int M = B * T, I = d.inter_channels, half = I / 2, Fh = d.flow_hidden;
   float* p = static_cast<float*>(workspace);
   const StackDims sd = tf_dims(d);
-  StackWs sw = carve_stack(p, sd, (size_t)M);
+  StackWs sw = carve_stack(p, sd, (size_t)M, h->precision == TTSDEC_PREC_SPLIT_F16);
   auto take = [&](size_t n) { float* r = p; p += up(n, kAlign); return r; };
   float* mask = take(M);
   float* xa = take((size_t)M * I);   // current x (ping)
@@ -1091,7 +1099,7 @@ int ttsvits_flow_reverse(ttsvits_handle* h, const float* z, const int32_t* lengt
   float* rs = take((size_t)M * 2 * Fh);
   GemmCtx fcx;
   fcx.planes = reinterpret_cast<f16*>(take((size_t)M * (Fh > half ? Fh : half)));
-  fcx.split = !getenv("TTSVITS_F32");
+  fcx.split = h->precision == TTSDEC_PREC_SPLIT_F16;
   f16* hx_p = reinterpret_cast<f16*>(take((size_t)M * Fh));  // planes of hx / acts / ho, written by their producers
   f16* acts_p = reinterpret_cast<f16*>(take((size_t)M * Fh));
   f16* ho_p = reinterpret_cast<f16*>(take((size_t)M * Fh));

@@ -115,6 +115,13 @@ class VitsEngine:
     def num_weight_tensors(self) -> int:
         return int(self._lib.ttsvits_num_weight_tensors(self._h))
 
+    def set_precision(self, mode: str) -> None:
+        """"split_f16" (default) or "f32": arithmetic of every GEMM (include/ttsdec.h ttsvits_set_precision)."""
+        self._err(self._lib.ttsvits_set_precision(self._h, {"f32": _lib.PREC_F32, "split_f16": _lib.PREC_SPLIT_F16}[mode]), "ttsvits_set_precision")
+
+    def precision(self) -> str:
+        return {_lib.PREC_F32: "f32", _lib.PREC_SPLIT_F16: "split_f16"}[int(self._lib.ttsvits_get_precision(self._h))]
+
     def ensure_packed(self, tensors, key_tensors=None) -> None:
         """tensors: the list the C ABI expects, or a callable producing it (called only when a repack is
         needed); key_tensors: the parameters whose identity / version decide that (default: the list itself -
@@ -222,6 +229,7 @@ class TextEncoder(PackedWeightsMixin, nn.Module):
         nn.init.normal_(self.emb.weight, 0.0, hidden_channels**-0.5)
         self.encoder = Encoder(hidden_channels, filter_channels, n_heads, n_layers, kernel_size, p_dropout)
         self.proj = nn.Conv1d(hidden_channels, out_channels * 2, 1)
+        self.precision = "split_f16"  # arithmetic of the GEMMs: "split_f16" (fp32-class, default) or "f32" (exact)
         self._engines = _EngCache()
 
     def _dims(self):
@@ -236,6 +244,7 @@ class TextEncoder(PackedWeightsMixin, nn.Module):
         if torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters()):
             raise NotImplementedError("the HIP text encoder is inference-only: call under torch.no_grad()")
         eng = self._engines.get(self._dims(), x.device)
+        eng.set_precision(self.precision)
         eng.ensure_packed([self.emb.weight] + self.encoder.weight_tensors() + [self.proj.weight, self.proj.bias])
         xo, m, logs = eng.text_encoder(x, x_lengths)
         T = x.shape[1]
@@ -304,6 +313,7 @@ class ResidualCouplingTransformersBlock(PackedWeightsMixin, nn.Module):
             self.flows.append(ResidualCouplingTransformersLayer(channels, hidden_channels, kernel_size, dilation_rate, n_layers,
                                                                 gin_channels=gin_channels, mean_only=True))
             self.flows.append(_Flip())
+        self.precision = "split_f16"  # arithmetic of the GEMMs: "split_f16" (fp32-class, default) or "f32" (exact)
         self._engines = _EngCache()
 
     def _dims(self):
@@ -317,6 +327,7 @@ class ResidualCouplingTransformersBlock(PackedWeightsMixin, nn.Module):
         if torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters()):
             raise NotImplementedError("the HIP flow is inference-only: call under torch.no_grad()")
         eng = self._engines.get(self._dims(), x.device)
+        eng.set_precision(self.precision)
 
         def tensors() -> List[Optional[torch.Tensor]]:
             ts: List[Optional[torch.Tensor]] = [None] * 3  # emb, proj.weight, proj.bias of the (absent) text encoder
