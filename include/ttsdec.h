@@ -254,6 +254,10 @@ size_t ttsdec_workspace_bytes(const ttsdec_handle* h, int B, int L);
  *                 finite but those rows are not fp32-accurate: rerun with TTSDEC_PREC_F32.
  *                 (Activation bound of the split mode: |x| <= 65504; h is bounded by 1, the context
  *                 by max |memory|.)
+ *   State after a fired stop: the outputs up to and including the stop step are final, but the recurrent state left in the
+ *   workspace is NOT the state at the stop step (launches that overlap the next step's early work have already advanced
+ *   parts of it: the attention LSTM's cell state is one step past the stop frame).  A decode that stopped cannot be
+ *   continued; start the next utterance batch with t_begin = 0.
  */
 int ttsdec_decode(ttsdec_handle* h, const float* memory, int B, int L, int t_begin, int n_steps, int t_stride,
                   float stop_threshold, int check_stop, int dropout_mode, const uint8_t* masks, uint64_t seed,
@@ -342,9 +346,12 @@ int ttsenc_pack_weights(ttsenc_handle* h, const float* const* src, int n_src, vo
 int ttsenc_bind_weights(ttsenc_handle* h, const void* blob);
 size_t ttsenc_workspace_bytes(const ttsenc_handle* h, int B, int L);
 /* ids [B, L] int64 (0 = padding), lengths [B] int32 on the device; L_out = max(lengths) (host-known:
- * the reference pads its output to the longest utterance, rnn.py:126); memory [B, L_out, d_out]. */
+ * the reference pads its output to the longest utterance, rnn.py:126); memory [B, L_out, d_out].
+ * status: optional device int32 (caller zeroes it): bit 0 is set when an id lay outside [0, alphabet_size) - nn.Embedding raises
+ * IndexError there (encoder.py:69); the kernel reads the nearest table row instead of memory outside the table and the caller
+ * reads the word with the results (no scan of the ids on the host, no synchronisation before the launch). */
 int ttsenc_forward(ttsenc_handle* h, const int64_t* ids, const int32_t* lengths, int B, int L, int L_out, float* memory,
-                   void* workspace, size_t workspace_bytes, void* stream);
+                   void* workspace, size_t workspace_bytes, void* stream, int32_t* status);
 
 /* ---------------------------------------------------------------------------------------
  * VITS2 second hot path (BASELINE.json configs[4]):
@@ -400,9 +407,10 @@ size_t ttsvits_packed_bytes(const ttsvits_handle* h);
 int ttsvits_pack_weights(ttsvits_handle* h, const float* const* src, int n_src, void* blob, void* stream);
 int ttsvits_bind_weights(ttsvits_handle* h, const void* blob);
 size_t ttsvits_text_encoder_workspace_bytes(const ttsvits_handle* h, int B, int T);
-/* ids [B, T] int64, lengths [B] int32 (device).  x [B, T, hidden], m and logs [B, T, inter]; padded frames are zero. */
+/* ids [B, T] int64, lengths [B] int32 (device).  x [B, T, hidden], m and logs [B, T, inter]; padded frames are zero.
+ * status: as for ttsenc_forward (bit 0: an id outside [0, n_vocab), models.py:370). */
 int ttsvits_text_encoder(ttsvits_handle* h, const int64_t* ids, const int32_t* lengths, int B, int T, float* x, float* m,
-                         float* logs, void* workspace, size_t workspace_bytes, void* stream);
+                         float* logs, void* workspace, size_t workspace_bytes, void* stream, int32_t* status);
 size_t ttsvits_flow_workspace_bytes(const ttsvits_handle* h, int B, int T);
 /* z [B, T, inter] -> out [B, T, inter]; lengths [B] int32 (device) give y_mask. */
 int ttsvits_flow_reverse(ttsvits_handle* h, const float* z, const int32_t* lengths, int B, int T, float* out, void* workspace,

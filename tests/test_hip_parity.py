@@ -978,6 +978,27 @@ def test_data_edits_need_invalidate_and_load_state_dict_repacks(H):
     assert torch.equal(y3, y1)
 
 
+def test_reference_style_checkpoint_loader_repacks(H):
+    """The reference's own partial loader writes through param.data.copy_ (train_util.py:43), which the blob fingerprint cannot
+    see; the drop-in loader (torch_tts_amd.train_util.load_state_dict) loads the same way and invalidates the packed weights."""
+    dims = O.DecoderDims(d_mel=80, d_pre=128, d_ctx=64, h_att=128, h_dec=192)
+    w1 = O.random_decoder_weights(dims, seed=1, nonzero_init_state=True)
+    w2 = O.random_decoder_weights(dims, seed=2, nonzero_init_state=True)
+    mem = O.synthetic_memory(5, 9, dims.d_ctx, seed=3)
+    masks = O.synthetic_masks(6, 5, dims.d_pre, seed=4)
+    dec = H.make_decoder(dims, w1)
+    y1, _, _, _ = H.run_decoder_with_masks(dec, mem, masks, max_steps=5)
+    w2["no.such.parameter"] = torch.zeros(3)  # (skipped with a warning, like the reference)
+    import torch_tts_amd as T
+
+    T.train_util.load_state_dict(dec, w2)
+    y2, s2, wt2, _ = H.run_decoder_with_masks(dec, mem, masks, max_steps=5)
+    oy, os_, ow = O.decode({k: v for k, v in w2.items() if k != "no.such.parameter"}, dims, mem, max_steps=5, masks=masks)
+    assert not torch.equal(y1, y2)
+    H.assert_close(y2, oy, RTOL, ATOL, "y after the reference-style loader")
+    H.assert_argmax(wt2, ow, "argmax after the reference-style loader")
+
+
 def test_stop_rule_with_a_grid_larger_than_one_residency_wave(H):
     """B = 8192 -> 1024 frame-kernel workgroups (4 per CU): workgroups dispatched after the stop flag was lowered
     must still write their rows of the firing step (the frame kernel gates on t-1 <= stop_t)."""

@@ -28,17 +28,21 @@ def main():
     res = {}
     try:
         dims = O.DecoderDims()  # LJSpeech dims
-        B, L, Tn = 140, 40, 16  # shards of 70: whole batch and shards in one regime of the launch schedule (65 .. 256 utterances)
+        L, Tn = 40, 16
+        # whole batch and shards must lie in one regime of the launch schedule (test_shard_equivalence_bitwise): split-fp16
+        # 65 .. 256 utterances, exact fp32 more than 320
+        batch = {"split_f16": 140, "f32": 768}
         # rank 0 owns the real weights; the other rank starts from DIFFERENT ones, so only the broadcast blob can make it agree
         wts = O.random_decoder_weights(dims, seed=42 if rank == 0 else 999, nonzero_init_state=True)
         cell = T.Taco2ProdDecoderCell(dims.d_ctx, dims.d_mel, 1, [dims.h_att, dims.h_dec], dim_pre=dims.d_pre, dim_att=dims.h_att)
         dec = T.Decoder(cell, 1, dims.d_mel)
         dec.load_state_dict(wts, strict=False)
         dec = dec.to(dev).eval()
-        mem = O.synthetic_memory(B, L, dims.d_ctx, seed=5).to(dev)
-        masks = O.synthetic_masks(Tn, B, dims.d_pre, seed=6).to(dev)
         per_prec = {}
         for prec in ("split_f16", "f32"):
+            B = batch[prec]
+            mem = O.synthetic_memory(B, L, dims.d_ctx, seed=5).to(dev)
+            masks = O.synthetic_masks(Tn, B, dims.d_pre, seed=6).to(dev)
             eng = dec._engines.get(dec.decoder_cell.engine_dims(), dev)
             eng.set_precision(prec)
             D.broadcast_engine_weights(eng, dec.weight_tensors(), src=0)  # pack on 0, broadcast, bind elsewhere

@@ -10,6 +10,7 @@ from .postnet import Conv1dFix, MelPostnet, MelPostnet2
 from .tacotron import Encoder2, Tacotron, build_tacotron, lengths_to_mask
 from . import vits2  # noqa: F401  (TextEncoder, ResidualCouplingTransformersBlock)
 from . import audio  # noqa: F401  (AudioFrontend.mel_inv / decode, m_rev, synth_audio)
+from . import train_util  # noqa: F401  (load_state_dict: the reference's partial checkpoint loader + blob invalidation)
 
 __all__ = [
     "Decoder", "Taco2ProdDecoderCell", "Taco2DecoderCell", "PreNet", "LSTMZoneoutCell", "StepwiseMonotonicAttention", "MelPostnet", "MelPostnet2",

@@ -232,7 +232,7 @@ def load() -> C.CDLL:
         lib.ttsenc_workspace_bytes.restype = sz
         lib.ttsenc_workspace_bytes.argtypes = [vp, i32, i32]
         lib.ttsenc_forward.restype = i32
-        lib.ttsenc_forward.argtypes = [vp, vp, vp, i32, i32, i32, vp, vp, sz, vp]
+        lib.ttsenc_forward.argtypes = [vp, vp, vp, i32, i32, i32, vp, vp, sz, vp, vp]
         lib.ttsvits_create.restype = i32
         lib.ttsvits_create.argtypes = [C.POINTER(VitsDims), C.POINTER(vp)]
         lib.ttsvits_destroy.restype = i32
@@ -254,7 +254,7 @@ def load() -> C.CDLL:
         lib.ttsvits_text_encoder_workspace_bytes.restype = sz
         lib.ttsvits_text_encoder_workspace_bytes.argtypes = [vp, i32, i32]
         lib.ttsvits_text_encoder.restype = i32
-        lib.ttsvits_text_encoder.argtypes = [vp, vp, vp, i32, i32, vp, vp, vp, vp, sz, vp]
+        lib.ttsvits_text_encoder.argtypes = [vp, vp, vp, i32, i32, vp, vp, vp, vp, sz, vp, vp]
         lib.ttsvits_flow_workspace_bytes.restype = sz
         lib.ttsvits_flow_workspace_bytes.argtypes = [vp, i32, i32]
         lib.ttsvits_flow_reverse.restype = i32

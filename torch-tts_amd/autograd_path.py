@@ -30,6 +30,22 @@ from .rng import MaskStream
 Tensor = torch.Tensor
 
 
+_WARNED = set()
+
+
+def warn_eval_on_autograd_path(module) -> None:
+    """An eval-mode module that lands here only because grad mode is on (its parameters require grad and the call is not
+    under torch.no_grad()) gets correct results - but from step-by-step torch ops, orders of magnitude slower than the HIP
+    path.  Say so once per class."""
+    if not module.training and type(module).__name__ not in _WARNED:
+        _WARNED.add(type(module).__name__)
+        import warnings
+
+        warnings.warn(f"{type(module).__name__} is in eval mode but grad is enabled, so it runs the differentiable torch-op path, not the "
+                      "HIP kernels: wrap inference in torch.no_grad() (as the reference's run_inference_step does) for the fast path",
+                      RuntimeWarning, stacklevel=3)
+
+
 def _require_device(t: Tensor, what: str) -> None:
     if not t.is_cuda:
         raise RuntimeError(f"{what} must live on a ROCm device (got {t.device}): this package has no CPU path")
@@ -144,16 +160,23 @@ def decoder_forward(dec, memory: Tensor, mmask, x: Optional[Tensor], max_steps: 
     ss: List[Tensor] = []
     ws: List[Tensor] = []
     step = 0
+    # reference_rng: the keep-masks (and teacher-forcing coin flips) of a teacher-forced run are all drawn up front, in the
+    # reference's order, and uploaded in ONE copy (a blocking host-to-device copy per step otherwise); free-running decoding
+    # draws step by step (its length is not known)
+    pre_masks = pre_flags = None
+    if stream is not None and x_split is not None:
+        pre_masks, pre_flags = stream.draw(len(x_split))
+        pre_masks = pre_masks.reshape(len(x_split), -1).to(memory.device)
     while True:
         keep, forced = None, True
         if stream is not None:
-            masks, flags = stream.draw(1)
             w0, w1 = stream.widths
-            flat = masks.reshape(-1).to(memory.device)
+            if pre_masks is not None:
+                flat, forced = pre_masks[step], bool(pre_flags[step])
+            else:
+                masks, flags = stream.draw(1)
+                flat, forced = masks.reshape(-1).to(memory.device), bool(flags[0])
             keep = (flat[: B * w0].view(B, w0), flat[B * w0 :].view(B, w1))
-            forced = bool(flags[0])
-        elif x_split is not None and p_no_forcing:
-            forced = bool(torch.rand(1) > p_no_forcing)
         d_t, _, state = cell_step(cell, y_t[:, -1, :], state, memory, keep)
         s_t = dec.fc_stop(d_t).unsqueeze(2)
         y_t = F.leaky_relu(dec.fc_mel(d_t), 0.01).view(-1, r, dm)
@@ -164,6 +187,10 @@ def decoder_forward(dec, memory: Tensor, mmask, x: Optional[Tensor], max_steps: 
         if x_split is not None:
             if step >= len(x_split):
                 break
+            if stream is None and p_no_forcing:
+                # (decoder.py:65: the coin is flipped here, behind the break - one draw per step but the last, so the host
+                # generator ends where the reference leaves it)
+                forced = bool(torch.rand(1) > p_no_forcing)
             if forced:
                 y_t = x_split[step - 1]
         elif bool(torch.any(s_t < dec.stop_threshold)) or (max_steps and step > max_steps):

@@ -663,21 +663,26 @@ void launch_absmax(const float* src, size_t n, float* out, hipStream_t st) {
 }
 
 __global__ void embed_kernel(const long long* ids, const float* table, int n_table, int n_rows, int E, float* out_a, int lda,
-                             float* out_b, int ldb) {
+                             float* out_b, int ldb, int* status) {
   const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= (size_t)n_rows * E) return;
   const int m = (int)(i / E), c = (int)(i % E);
-  long long id = ids[m];  // the host wrapper range-checks ids (IndexError, like nn.Embedding); never read outside the table
-  id = id < 0 ? 0 : (id >= n_table ? n_table - 1 : id);
+  long long id = ids[m];
+  // an id outside the table (nn.Embedding raises IndexError there): never read outside the table - clamp - and tell the host
+  // through the status word, which it reads with the results (no host-side scan of the ids, no sync before the launch)
+  if (id < 0 || id >= n_table) {
+    if (c == 0 && status != nullptr) atomicOr(status, 1);
+    id = id < 0 ? 0 : n_table - 1;
+  }
   const float v = table[(size_t)id * E + c];
   out_a[(size_t)m * lda + c] = v;
   out_b[(size_t)m * ldb + c] = v;
 }
 void launch_embed(const long long* ids, const float* table, int n_table, int n_rows, int E, float* out_a, int lda, float* out_b,
-                  int ldb, hipStream_t st) {
+                  int ldb, int* status, hipStream_t st) {
   const size_t n = (size_t)n_rows * E;
   hipLaunchKernelGGL(embed_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, ids, table, n_table, n_rows, E, out_a, lda, out_b,
-                     ldb);
+                     ldb, status);
 }
 
 __global__ void fill_rows_kernel(float* dst, const float* row, int n_rows, int n_cols) {

@@ -160,7 +160,7 @@ int ttsenc_bind_weights(ttsenc_handle* h, const void* blob) {
 }
 
 int ttsenc_forward(ttsenc_handle* h, const int64_t* ids, const int32_t* lengths, int B, int L, int L_out, float* memory,
-                   void* workspace, size_t workspace_bytes, void* stream) {
+                   void* workspace, size_t workspace_bytes, void* stream, int32_t* status) {
   if (!h || !ids || !lengths || !memory || !workspace || B <= 0 || L <= 0 || L_out <= 0 || L_out > L) return TTSDEC_ERR_INVALID_ARG;
   if (!h->blob) return TTSDEC_ERR_NOT_BOUND;
   if (!device_is_current(h->device)) return TTSDEC_ERR_DEVICE;
@@ -177,7 +177,7 @@ int ttsenc_forward(ttsenc_handle* h, const int64_t* ids, const int32_t* lengths,
   float *x = F(W.x), *cat = F(W.cat), *gx = F(W.gx);
 
   // encoder.py:69: embedding (row 0 of the table is the zero padding vector); also the right half of the cat
-  launch_embed(reinterpret_cast<const long long*>(ids), blob + bl.emb, d.alphabet_size, M, E, x, E, cat + E, 2 * E, st);
+  launch_embed(reinterpret_cast<const long long*>(ids), blob + bl.emb, d.alphabet_size, M, E, x, E, cat + E, 2 * E, status, st);
   // encoder.py:70: three conv blocks over the padded sequence; the last writes the left half of the cat
   // The convs and the input projection run in the GEMM core's split-fp16 mode (fp32-class accuracy,
   // gemm_tile.h): one elementwise pass makes the hi / lo planes of each A operand.

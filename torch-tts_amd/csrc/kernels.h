@@ -280,9 +280,9 @@ void launch_to_bf16(const float* src, void* dst, size_t n, hipStream_t st);
 // *out = max(*out, max |src[i]|)  (*out must hold a non-negative float, e.g. 0)
 void launch_absmax(const float* src, size_t n, float* out, hipStream_t st);
 // out_a[m, 0:E] (ld lda) and out_b[m, 0:E] (ld ldb) = table[ids[m], :]   (nn.Embedding lookup)
-// (ids outside [0, n_table) are clamped: the host wrappers reject them before the call)
+// (ids outside [0, n_table) are clamped and reported: bit 0 of *status, a device word that may be nullptr)
 void launch_embed(const long long* ids, const float* table, int n_table, int n_rows, int E, float* out_a, int lda, float* out_b,
-                  int ldb, hipStream_t st);
+                  int ldb, int* status, hipStream_t st);
 // device bookkeeping shared by the three handle types
 int current_device_or_minus1();
 bool device_is_current(int device);

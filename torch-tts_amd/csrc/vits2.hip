@@ -116,14 +116,17 @@ int vits_fail(ttsvits_handle* h, const char* where) {
 // (every producer below can also emit the split-fp16 planes of its output - hi at p, lo at p + M*C - so
 // the GEMM that consumes it needs no separate conversion pass)
 __global__ void embed_scale_kernel(const long long* ids, const int* lengths, const float* table, int n_vocab, int T, int H, float scale,
-                                   float* x, f16* xp, float* mask, int M) {
+                                   float* x, f16* xp, float* mask, int M, int* status) {
   const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= (size_t)M * H) return;
   const int m = (int)(i / H), c = (int)(i % H);
   const int b = m / T, t = m - b * T;
   const float mk = t < lengths[b] ? 1.0f : 0.0f;
-  long long id = ids[m];  // the host wrapper range-checks ids (IndexError, like nn.Embedding); never read outside the table
-  id = id < 0 ? 0 : (id >= n_vocab ? n_vocab - 1 : id);
+  long long id = ids[m];
+  if (id < 0 || id >= n_vocab) {  // (nn.Embedding raises there: clamp - never read outside the table - and report, see embed_kernel)
+    if (c == 0 && status != nullptr) atomicOr(status, 1);
+    id = id < 0 ? 0 : n_vocab - 1;
+  }
   const float v = mul_rn(mul_rn(table[(size_t)id * H + c], scale), mk);
   x[i] = v;
   if (xp) split_f16(v, xp[i], xp[(size_t)M * H + i]);
@@ -590,6 +593,242 @@ size_t mha_mfma_lds_bytes(int T, int dk, int window) {
   return (s > red ? s : red) * sizeof(float);
 }
 
+// ===========================================================================
+// The same attention, WITHOUT the relative-position window (the flow's pre_transformer, models.py:508), as ONE pass over the
+// keys with an online softmax, on the f16 matrix instruction with split-fp16 operands (hi + lo fp16 planes, fp32 accumulate:
+// the arithmetic of every GEMM of this file).  One workgroup = 4 waves x 32 query frames of one (utterance, head); the key /
+// value frames go through LDS in tiles of 32, ONCE per workgroup - the kernel above, 32 queries per workgroup and its
+// operands straight from global memory, re-read K and V 19 times per (utterance, head) at 600 frames and ran on exact-fp32
+// MFMAs (1/5.3 of this rate): 205 us per launch on the flow's shape against a matrix-pipe floor of ~15 us here.
+//
+// Orientation (cdna_hip_programming.md, "An accumulator tile as the next MFMA's operand"): the score tile is computed
+// TRANSPOSED, X = K Q^T (rows = keys, columns = queries), so a lane holds ONE query's scores of 16 keys in its 16 accumulator
+// registers (the other 16 keys sit in lane + 32): the softmax statistics are lane-local plus one half-wave exchange, and the
+// probabilities, converted to fp16 planes in registers, ARE the B operand of the second product Y = V^T P^T (rows = head
+// channels, columns = queries) - no LDS round trip, no transpose of P.  Y's columns are queries again, so the online
+// rescaling multiplies a lane's own registers.  The k index of that second product is permuted (element j of lane half h
+// of k-step s is key 16 s + 8 (j >> 2) + 4 h + (j & 3)); V is staged TRANSPOSED in LDS ([channel][key]) so that a lane's A
+// fragment of V^T is two 8-byte reads.
+//   scores: s = (q / sqrt(dk)) . k, -1e4 where mask_q * mask_k == 0 (attentions.py:270-271), keys past T excluded
+//   p = exp(s - running max);  out = sum_k p v / sum_k p      (softmax and P V of attentions.py:283-286, one pass)
+// LDS per buffer: K [32 keys][dk] hi / lo with 16-byte row padding (row stride 2 dk + 16 bytes: the 16 rows of a ds_read_b128
+// group land on 16 distinct 16-byte slots), V^T [32 n_dt rows][32 keys] hi / lo with 72-byte rows (conflict-free 8-byte
+// reads), the 32 key masks.  Two buffers: the next tile's global loads are in flight during a tile's MFMAs and written to LDS
+// behind them (one barrier per tile).
+constexpr int kFaWaves = 4, kFaThreads = 64 * kFaWaves, kFaQ = 32 * kFaWaves;
+template <int DK>
+struct FaLds {
+  static constexpr int NDT = (DK + 31) / 32, KROW = 2 * DK + 16, VROW = 72;
+  static constexpr int KPL = 32 * KROW, VPL = 32 * NDT * VROW;
+  static constexpr int MK = 2 * KPL + 2 * VPL;  // byte offset of the key masks
+  static constexpr int BUF = MK + 128;
+};
+template <int DK>  // head width: a multiple of 16, at most 64
+__global__ __launch_bounds__(kFaThreads, 2) void mha_flash_kernel(MhaArgs g) {
+  using L = FaLds<DK>;
+  constexpr int NKS = DK / 16, NDT = L::NDT, C4 = DK / 4, NI = NKS;  // NI: float4 items per thread per tile (2 * 32 * C4 / 256)
+  static_assert(DK % 16 == 0 && DK <= 64 && 2 * 32 * C4 == NI * kFaThreads, "head width");
+  extern __shared__ __attribute__((aligned(16))) char fsm[];
+  const int T = g.T, C = g.C;
+  const int tid = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63, l32 = lane & 31, half = lane >> 5;
+  const int b = blockIdx.z, hd = blockIdx.y, q0 = blockIdx.x * kFaQ + wave * 32;
+  const size_t rowb = (size_t)b * T;
+  typedef __attribute__((address_space(1))) const f32x4 gf32x4;
+  typedef __attribute__((address_space(1))) const float gf32;
+  gf32* base = (gf32*)(g.qkv + rowb * 3 * C + hd * DK);
+  gf32* maskg = (gf32*)(g.mask + rowb);
+  const int nt = (T + 31) / 32;
+  const bool wave_active = q0 < T;  // (the last workgroup of a sequence: its idle waves only help with the staging)
+
+  // ---- staging: item i = tid + 256 n: i < 32 C4: K value group (key i / C4, channels 4 (i % C4) ..); else the same of V ----
+  f32x4 stg[NI];
+  float stg_mk = 0.f;
+  auto stage_load = [&](int t) {
+#pragma unroll
+    for (int n = 0; n < NI; ++n) {
+      int i = tid + kFaThreads * n;
+      const bool isv = i >= 32 * C4;
+      if (isv) i -= 32 * C4;
+      const int key = t * 32 + i / C4, c4 = i % C4;
+      const int kc = key < T ? key : T - 1;
+      const f32x4 v = *(gf32x4*)(base + (size_t)kc * 3 * C + (isv ? 2 * C : C) + 4 * c4);
+      stg[n] = key < T ? v : f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+    if (tid < 32) {
+      const int key = t * 32 + tid;
+      stg_mk = key < T ? maskg[key] : -1.0f;  // (-1: no such key)
+    }
+  };
+  auto stage_store = [&](int p) {
+    char* buf = fsm + p * L::BUF;
+#pragma unroll
+    for (int n = 0; n < NI; ++n) {
+      int i = tid + kFaThreads * n;
+      const bool isv = i >= 32 * C4;
+      if (isv) i -= 32 * C4;
+      const int kk = i / C4, c4 = i % C4;
+      union { f16 h[4]; uint2 u; } hi, lo;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) split_f16(stg[n][e], hi.h[e], lo.h[e]);
+      if (!isv) {
+        *reinterpret_cast<uint2*>(buf + kk * L::KROW + c4 * 8) = hi.u;
+        *reinterpret_cast<uint2*>(buf + L::KPL + kk * L::KROW + c4 * 8) = lo.u;
+      } else {
+        char* v = buf + 2 * L::KPL + (4 * c4) * L::VROW + kk * 2;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          *reinterpret_cast<f16*>(v + e * L::VROW) = hi.h[e];
+          *reinterpret_cast<f16*>(v + L::VPL + e * L::VROW) = lo.h[e];
+        }
+      }
+    }
+    if (tid < 32) *reinterpret_cast<float*>(buf + L::MK + tid * 4) = stg_mk;
+  };
+
+  stage_load(0);
+  // zero LDS once: the V^T rows past DK (never staged) must hold finite values
+  for (int i = tid; i < 2 * L::BUF / 4; i += kFaThreads) reinterpret_cast<float*>(fsm)[i] = 0.f;
+  // ---- this lane's query: column l32 of the wave's 32 queries; B operand of X = K Q^T: Q[query][16 s + 8 half + j] ----
+  const int qi = q0 + l32;
+  const bool qok = qi < T;
+  f16x8 qh[NKS], ql[NKS];
+  float mq = 0.f;
+  {
+    const int qc = qok ? qi : T - 1;
+    gf32* src = base + (size_t)qc * 3 * C + 8 * half;
+#pragma unroll
+    for (int s = 0; s < NKS; ++s) {
+      const f32x4 a = *(gf32x4*)(src + 16 * s), c = *(gf32x4*)(src + 16 * s + 4);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        f16 h0, l0, h1, l1;
+        split_f16(div_rn(a[e], g.qscale), h0, l0);  // attentions.py:261: query / sqrt(k_channels)
+        split_f16(div_rn(c[e], g.qscale), h1, l1);
+        qh[s][e] = h0; ql[s][e] = l0; qh[s][4 + e] = h1; ql[s][4 + e] = l1;
+      }
+    }
+    mq = qok ? maskg[qi] : 0.f;
+  }
+  __syncthreads();
+  stage_store(0);
+  __syncthreads();
+
+  f32x16 y[NDT], y2[NDT];
+#pragma unroll
+  for (int dt = 0; dt < NDT; ++dt)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { y[dt][r] = 0.f; y2[dt][r] = 0.f; }
+  float m_run = -3.0e38f, lsum = 0.f;
+  auto pair_with_other_half = [&](float v, auto op) {  // op(v of this lane, v of lane +- 32)
+    return op(v, __shfl_xor(v, 32));
+  };
+
+  for (int t = 0; t < nt; ++t) {
+    const int p = t & 1;
+    if (t + 1 < nt) stage_load(t + 1);
+    if (wave_active) {
+      const char* buf = fsm + p * L::BUF;
+      // ---- X = K Q^T: rows = the tile's 32 keys (A operand from LDS), columns = the wave's 32 queries ----
+      f32x16 x, x2;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) { x[r] = 0.f; x2[r] = 0.f; }
+      const char* ka = buf + l32 * L::KROW + half * 16;
+#pragma unroll
+      for (int s = 0; s < NKS; ++s) {
+        const f16x8 kh = *reinterpret_cast<const f16x8*>(ka + 32 * s), kl = *reinterpret_cast<const f16x8*>(ka + L::KPL + 32 * s);
+        x = __builtin_amdgcn_mfma_f32_32x32x16_f16(kh, qh[s], x, 0, 0, 0);
+        x2 = __builtin_amdgcn_mfma_f32_32x32x16_f16(kh, ql[s], x2, 0, 0, 0);
+        x2 = __builtin_amdgcn_mfma_f32_32x32x16_f16(kl, qh[s], x2, 0, 0, 0);
+      }
+      // register r of this lane: key (r & 3) + 8 (r >> 2) + 4 half of the tile; its mask values: 4 x 16 bytes
+      float sc[16];
+      float tmax = -3.0e38f;
+#pragma unroll
+      for (int gq = 0; gq < 4; ++gq) {
+        const f32x4 mk4 = *reinterpret_cast<const f32x4*>(buf + L::MK + (8 * gq + 4 * half) * 4);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const int r = 4 * gq + e;
+          float v = fmaf(x2[r], 1.0f / kSplitScale, x[r]);
+          v = mk4[e] < 0.f ? -3.0e38f : (mq * mk4[e] == 0.f ? -1e4f : v);  // attentions.py:270-271 masked_fill(mask == 0, -1e4)
+          sc[r] = v;
+          tmax = fmaxf(tmax, v);
+        }
+      }
+      tmax = pair_with_other_half(tmax, [](float a, float c) { return fmaxf(a, c); });
+      const float m_new = fmaxf(m_run, tmax);
+      const float alpha = __expf(m_run - m_new);  // (first tile: exp(-3e38 - m) = 0, and the sums are 0)
+      m_run = m_new;
+      float ps = 0.f;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        sc[r] = __expf(sc[r] - m_new);
+        ps += sc[r];
+      }
+      lsum = fmaf(lsum, alpha, ps);
+      if (__any(alpha != 1.0f)) {  // (the running maximum of some query moved: rare after the first tiles)
+#pragma unroll
+        for (int dt = 0; dt < NDT; ++dt)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) { y[dt][r] *= alpha; y2[dt][r] *= alpha; }
+      }
+      // ---- Y += V^T P^T: P's registers 8 s .. 8 s + 7 are k-step s of the B operand; A = V^T rows (channels) from LDS ----
+      f16x8 ph[2], pl[2];
+#pragma unroll
+      for (int s = 0; s < 2; ++s)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          f16 h0, l0;
+          split_f16_pos(sc[8 * s + j], h0, l0);
+          ph[s][j] = h0; pl[s][j] = l0;
+        }
+#pragma unroll
+      for (int dt = 0; dt < NDT; ++dt) {
+        const char* va = buf + 2 * L::KPL + (32 * dt + l32) * L::VROW + half * 8;
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+          union { uint2 u[2]; f16x8 v; } vh, vl;
+          vh.u[0] = *reinterpret_cast<const uint2*>(va + 32 * s);       // keys 16 s + 4 half + (0..3)
+          vh.u[1] = *reinterpret_cast<const uint2*>(va + 32 * s + 16);  // keys 16 s + 8 + 4 half + (0..3)
+          vl.u[0] = *reinterpret_cast<const uint2*>(va + L::VPL + 32 * s);
+          vl.u[1] = *reinterpret_cast<const uint2*>(va + L::VPL + 32 * s + 16);
+          y[dt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vh.v, ph[s], y[dt], 0, 0, 0);
+          y2[dt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vh.v, pl[s], y2[dt], 0, 0, 0);
+          y2[dt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vl.v, ph[s], y2[dt], 0, 0, 0);
+        }
+      }
+    }
+    if (t + 1 < nt) stage_store(p ^ 1);  // (buffer p ^ 1 was last read in iteration t - 1: every wave is past that barrier)
+    __syncthreads();
+  }
+  if (!wave_active) return;
+  const float ltot = pair_with_other_half(lsum, [](float a, float c) { return a + c; });
+  const float inv = 1.0f / ltot;
+  if (qok) {
+    float* orow = g.out + (rowb + qi) * C + hd * DK;
+#pragma unroll
+    for (int dt = 0; dt < NDT; ++dt)
+#pragma unroll
+      for (int gq = 0; gq < 4; ++gq) {
+        const int d0 = 32 * dt + 8 * gq + 4 * half;  // this lane's registers 4 gq .. 4 gq + 3 of tile dt: channels d0 .. d0 + 3
+        if (d0 < DK) {
+          f32x4 o;
+#pragma unroll
+          for (int e = 0; e < 4; ++e) o[e] = fmaf(y2[dt][4 * gq + e], 1.0f / kSplitScale, y[dt][4 * gq + e]) * inv;
+          *reinterpret_cast<f32x4*>(orow + d0) = o;
+          if (g.out_p) {
+            union { f16 h[4]; uint2 u; } hi, lo;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) split_f16(o[e], hi.h[e], lo.h[e]);
+            const size_t oo = (size_t)(orow - g.out) + d0;
+            *reinterpret_cast<uint2*>(g.out_p + oo) = hi.u;
+            *reinterpret_cast<uint2*>(g.out_p + g.n_out + oo) = lo.u;
+          }
+        }
+      }
+  }
+}
+
 // commons.fused_add_tanh_sigmoid_multiply with g = None (commons.py:102-109): [M, 2H] -> [M, H]
 __global__ void wn_gate_kernel(const float* xin, float* acts, f16* acts_p, int M, int H) {
   const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -834,6 +1073,9 @@ int run_stack(ttsvits_handle* h, const StackBlob& sb, const StackDims& sd, const
   const bool use_mfma = lds_m <= kMhaMaxLds && sd.window <= 15 && (dk == 96 || dk == 48 || dk == 16 || dk == 8);
   const size_t lds = use_mfma ? lds_m : mha_lds_bytes(T, dk, sd.window);
   if (lds > kMhaMaxLds || dk > 256) return TTSDEC_ERR_DIMS;
+  // no relative window, split-fp16 arithmetic, a head width the flash kernel is built for: one pass over the keys on the f16
+  // matrix instruction (the exact-fp32 mode keeps the exact-fp32 kernels)
+  const bool use_flash = sd.window < 0 && h->precision == TTSDEC_PREC_SPLIT_F16 && (dk == 48 || dk == 32 || dk == 64 || dk == 16) && !(C & 3);
   const void* kfn = !use_mfma ? (const void*)mha_kernel
                    : dk == 96 ? (const void*)mha_mfma_kernel<48>
                    : dk == 48 ? (const void*)mha_mfma_kernel<24>
@@ -851,7 +1093,13 @@ int run_stack(ttsvits_handle* h, const StackBlob& sb, const StackDims& sd, const
     a.T = T; a.C = C; a.dk = dk; a.window = sd.window;
     a.ek = sd.window >= 0 ? blob + sb.ek[i] : nullptr; a.ev = sd.window >= 0 ? blob + sb.ev[i] : nullptr;
     a.qscale = sqrtf((float)dk);
-    if (use_mfma) {
+    if (use_flash) {
+      const dim3 grid((T + kFaQ - 1) / kFaQ, sd.heads, B), block(kFaThreads);
+      if (dk == 48) hipLaunchKernelGGL(mha_flash_kernel<48>, grid, block, 2 * FaLds<48>::BUF, st, a);
+      else if (dk == 32) hipLaunchKernelGGL(mha_flash_kernel<32>, grid, block, 2 * FaLds<32>::BUF, st, a);
+      else if (dk == 64) hipLaunchKernelGGL(mha_flash_kernel<64>, grid, block, 2 * FaLds<64>::BUF, st, a);
+      else hipLaunchKernelGGL(mha_flash_kernel<16>, grid, block, 2 * FaLds<16>::BUF, st, a);
+    } else if (use_mfma) {
       const dim3 grid((T + kMhaMRows - 1) / kMhaMRows, sd.heads, B), block(kMhaMThreads);
       if (dk == 96) hipLaunchKernelGGL(mha_mfma_kernel<48>, grid, block, lds, st, a);
       else if (dk == 48) hipLaunchKernelGGL(mha_mfma_kernel<24>, grid, block, lds, st, a);
@@ -1032,7 +1280,7 @@ size_t ttsvits_text_encoder_workspace_bytes(const ttsvits_handle* h, int B, int 
 }
 
 int ttsvits_text_encoder(ttsvits_handle* h, const int64_t* ids, const int32_t* lengths, int B, int T, float* x, float* m, float* logs,
-                         void* workspace, size_t workspace_bytes, void* stream) {
+                         void* workspace, size_t workspace_bytes, void* stream, int32_t* status) {
   if (!h || !ids || !lengths || !x || !m || !logs || !workspace || B <= 0 || T <= 0) return TTSDEC_ERR_INVALID_ARG;
   if (!h->blob) return TTSDEC_ERR_NOT_BOUND;
   if (workspace_bytes < ttsvits_text_encoder_workspace_bytes(h, B, T) || (reinterpret_cast<uintptr_t>(workspace) & 255))
@@ -1049,7 +1297,7 @@ int ttsvits_text_encoder(ttsvits_handle* h, const int64_t* ids, const int32_t* l
   float* stats = p;
   // models.py:370-376
   hipLaunchKernelGGL(embed_scale_kernel, grid1((size_t)M * H), dim3(256), 0, st, reinterpret_cast<const long long*>(ids), lengths,
-                     h->blob + L.emb, d.n_vocab, T, H, sqrtf((float)H), sw.xm, sw.xm_p, mask, M);
+                     h->blob + L.emb, d.n_vocab, T, H, sqrtf((float)H), sw.xm, sw.xm_p, mask, M, status);
   int rc = run_stack(h, L.enc, sd, sw, mask, B, T, st);
   if (rc != TTSDEC_OK) return rc;
   // models.py:377-379: stats = proj(x) * x_mask; m, logs = split(stats)

@@ -63,6 +63,7 @@ class Decoder(PackedWeightsMixin, nn.Module):
             # the device (autograd_path.py); the HIP library is the forward-only, eval-mode hot path
             from . import autograd_path
 
+            autograd_path.warn_eval_on_autograd_path(self)
             return autograd_path.decoder_forward(self, memory, mmask, x, max_steps, p_no_forcing)
         device = memory.device
         memory = memory.detach().to(torch.float32).contiguous()

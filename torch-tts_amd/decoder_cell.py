@@ -141,6 +141,7 @@ class Taco2ProdDecoderCell(PackedWeightsMixin, nn.Module):
             from . import autograd_path
 
             xin = x.flatten(1, 2)[:, -self.dim_mel :] if x.dim() == 3 else x
+            autograd_path.warn_eval_on_autograd_path(self)
             return autograd_path.prod_cell_step(self, xin, (dec_state[0], dec_state[1], dec_state[2]), memory)
         w_att, ctx_att, (hc_att, hc_dec) = dec_state[0], dec_state[1], dec_state[2]
         B = memory.shape[0]
@@ -235,6 +236,7 @@ class Taco2DecoderCell(PackedWeightsMixin, nn.Module):
             from . import autograd_path
 
             xin = x.flatten(1, 2)[:, -self.dim_mel :] if x.dim() == 3 else x
+            autograd_path.warn_eval_on_autograd_path(self)
             return autograd_path.taco2_cell_step(self, xin, (dec_state[0], dec_state[1]), memory)
         w_in, h_dec = dec_state[0], dec_state[1]
         B = memory.shape[0]

@@ -52,6 +52,8 @@ class EncoderEngine:
         self.blob: Optional[torch.Tensor] = None
         self._fingerprint = None
         self._ws: Dict = {}
+        self.status = torch.zeros(1, dtype=torch.int32, device=device)  # bit 0: an id outside the table (ttsenc_forward)
+        self._status_pending = False
 
     def close(self):
         if getattr(self, "_h", None):
@@ -83,15 +85,22 @@ class EncoderEngine:
             raise _lib.TtsdecError(rc, "ttsenc_pack_weights", self._lib.ttsenc_last_hip_error(self._h).decode())
         self.blob, self._fingerprint = blob, fp
 
+    def check_ids(self) -> None:
+        """Raises IndexError if the last forward met a token id outside the table (nn.Embedding does, encoder.py:69).  Reads the
+        device status word: ONE host sync, placed by the caller - Encoder2.forward right behind its launches, Tacotron.forward
+        at the decoder's own sync (none extra)."""
+        if self._status_pending:
+            self._status_pending = False
+            if int(self.status) & 1:
+                raise IndexError(f"token id out of range [0, {self.alphabet_size}) in the encoder's last input")
+
     def forward(self, ids: torch.Tensor, lengths: torch.Tensor) -> torch.Tensor:
         _require_device(ids, "ids")
         B, L = ids.shape
-        l_out = int(lengths.max())
+        l_out = int(lengths.max())  # (the reference's lengths live on the host: pack_padded_sequence wants them there, rnn.py:120)
         ids = ids.to(torch.int64).contiguous()
-        if ids.numel():  # nn.Embedding raises on an out-of-range index (encoder.py:69); the kernel must never read outside the table
-            lo, hi = int(ids.min()), int(ids.max())
-            if lo < 0 or hi >= self.alphabet_size:
-                raise IndexError(f"token id out of range: ids span [{lo}, {hi}], alphabet size {self.alphabet_size}")
+        self.status.zero_()
+        self._status_pending = True
         lens = lengths.to(device=self.device, dtype=torch.int32).contiguous()
         key = (B, L)
         ws = self._ws.get(key)
@@ -102,7 +111,7 @@ class EncoderEngine:
         memory = torch.empty(B, l_out, self.d_out, dtype=torch.float32, device=self.device)
         with torch.cuda.device(self.device):
             rc = self._lib.ttsenc_forward(self._h, ids.data_ptr(), lens.data_ptr(), B, L, l_out, memory.data_ptr(), ws.data_ptr(),
-                                          ws.numel(), _stream(self.device))
+                                          ws.numel(), _stream(self.device), self.status.data_ptr())
         if rc != _lib.OK:
             raise _lib.TtsdecError(rc, "ttsenc_forward", self._lib.ttsenc_last_hip_error(self._h).decode())
         return memory
@@ -137,6 +146,10 @@ class Encoder2(PackedWeightsMixin, nn.Module):
         self.rnn_h0 = nn.Parameter(torch.zeros(1, 1, dim_out))
         self.rnn_c0 = nn.Parameter(torch.zeros(1, 1, dim_out))
         self.use_hip = True  # eval-mode forwards on a ROCm device go through libttsdec
+        # nn.Embedding raises IndexError on an id outside the table; the HIP path finds out from a device status word.  False:
+        # forward reads it before returning (one host sync); True: the caller reads it later through check_ids()
+        # (Tacotron.forward does, at the decoder's own sync)
+        self.defer_id_check = False
         self._engines = _EncCache()
 
     def weight_tensors(self):
@@ -173,4 +186,12 @@ class Encoder2(PackedWeightsMixin, nn.Module):
             eng = EncoderEngine(self.emb.num_embeddings, self.dim_emb, self.dim_out, float(self.conv[1].eps), torch.device("cuda", idx))
             self._engines.by_dev[idx] = eng
         eng.ensure_packed(self.weight_tensors())
-        return eng.forward(x, x_lengths)
+        memory = eng.forward(x, x_lengths)
+        if not self.defer_id_check:
+            eng.check_ids()  # (one sync, behind the queued launches; Tacotron.forward defers it to the decoder's sync)
+        return memory
+
+    def check_ids(self) -> None:
+        """The deferred id range check of the last HIP forward (see defer_id_check)."""
+        for eng in self._engines.by_dev.values():
+            eng.check_ids()

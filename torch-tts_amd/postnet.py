@@ -60,6 +60,7 @@ class MelPostnet(PackedWeightsMixin, nn.Module):
         if self.training or (torch.is_grad_enabled() and (x.requires_grad or any(p.requires_grad for p in self.parameters()))):
             from . import autograd_path  # training semantics (batch-statistics BatchNorm, dropout) or a graph: torch ops on the device
 
+            autograd_path.warn_eval_on_autograd_path(self)
             return autograd_path.mel_postnet(self, x)
         prec = {"f32": _lib.POSTNET_F32, "bf16": _lib.POSTNET_BF16, "split_f16": _lib.POSTNET_SPLIT_F16}[self.precision]
         return self.engine(x.device).postnet(x.detach().to(torch.float32).contiguous(), prec)
@@ -144,6 +145,7 @@ class MelPostnet2(PackedWeightsMixin, nn.Module):
         if self.training or (torch.is_grad_enabled() and (x.requires_grad or any(p.requires_grad for p in self.parameters()))):
             from . import autograd_path
 
+            autograd_path.warn_eval_on_autograd_path(self)
             return autograd_path.mel_postnet2(self, x)
         prec = {"f32": _lib.POSTNET_F32, "bf16": _lib.POSTNET_BF16, "split_f16": _lib.POSTNET_SPLIT_F16}[self.precision]
         return self.engine(x.device).postnet(x.detach().to(torch.float32).contiguous(), prec)

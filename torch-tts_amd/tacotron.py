@@ -39,8 +39,35 @@ class Tacotron(PackedWeightsMixin, nn.Module):
         self.postnet = postnet
         self.apply(weights_init)
 
+    def fast_inference(self, seed: int = 0):
+        """One switch for the fast configuration of the HIP path (inference only):
+          * PreNet dropout drawn on the device (Philox, keyed by `seed`) instead of replaying the reference's CPU generator -
+            the default `dropout_source = "reference_rng"` draws ~80 MB of masks on the host and uploads them per 256 x 600
+            batch, which exists for bit-compatibility with the reference's RNG stream, not for speed;
+          * split-fp16 arithmetic (fp32-class accuracy: 22 significand bits per operand, fp32 accumulate) for the decoder's
+            and the Postnet's GEMMs instead of exact fp32 matrix instructions (about half the step time at 256 utterances).
+        Returns self; `reference_compatible()` switches back."""
+        self.decoder.dropout_source, self.decoder.dropout_seed, self.decoder.precision = "philox", int(seed), "split_f16"
+        if self.postnet is not None and hasattr(self.postnet, "precision"):
+            self.postnet.precision = "split_f16"
+        return self
+
+    def reference_compatible(self):
+        """The defaults: the reference's RNG stream for the always-on PreNet dropout, exact fp32 arithmetic."""
+        self.decoder.dropout_source, self.decoder.precision = "reference_rng", "f32"
+        if self.postnet is not None and hasattr(self.postnet, "precision"):
+            self.postnet.precision = "f32"
+        return self
+
     def forward(self, cond, cond_lengths, x=None, x_lengths=None, xref=None, xref_lengths=None, max_steps: int = 0):
-        memory = self.encoder(cond, cond_lengths)
+        defer = isinstance(self.encoder, Encoder2) and not self.training
+        if defer:  # the encoder's id range check rides on the decoder's sync below instead of a sync of its own
+            prev, self.encoder.defer_id_check = self.encoder.defer_id_check, True
+        try:
+            memory = self.encoder(cond, cond_lengths)
+        finally:
+            if defer:
+                self.encoder.defer_id_check = prev
         kl_loss = torch.scalar_tensor(0)
         if xref is not None and self.refencoder is not None:
             style_embed, style_loss_dict = self.refencoder(xref, xref_lengths)
@@ -49,6 +76,8 @@ class Tacotron(PackedWeightsMixin, nn.Module):
                 kl_loss = style_loss_dict["kl"].mean()
         mmask = lengths_to_mask(cond_lengths)
         y, s, w = self.decoder(memory, mmask, x, max_steps, p_no_forcing=0.1)
+        if defer:
+            self.encoder.check_ids()  # (the decoder has just synchronised: the status word is there)
         y_post = self.postnet(y) if self.postnet else y
         return y, y_post, s, {"w": w, "kl_loss": kl_loss}
 

@@ -96,6 +96,7 @@ class VitsEngine:
         self.blob: Optional[torch.Tensor] = None
         self._fingerprint = None
         self._ws: Dict = {}
+        self.status = torch.zeros(1, dtype=torch.int32, device=device)  # bit 0: an id outside the table (ttsvits_text_encoder)
 
     def close(self):
         if getattr(self, "_h", None):
@@ -161,10 +162,7 @@ class VitsEngine:
         _require_device(ids, "ids")
         B, T = ids.shape
         ids = ids.to(torch.int64).contiguous()
-        if ids.numel():  # nn.Embedding raises on an out-of-range index (models.py:370); the kernel must never read outside the table
-            lo, hi = int(ids.min()), int(ids.max())
-            if lo < 0 or hi >= self.dims["n_vocab"]:
-                raise IndexError(f"token id out of range: ids span [{lo}, {hi}], n_vocab {self.dims['n_vocab']}")
+        self.status.zero_()
         lens = lengths.to(device=self.device, dtype=torch.int32).contiguous()
         H, I = self.dims["hidden_channels"], self.dims["inter_channels"]
         x = torch.empty(B, T, H, device=self.device)
@@ -173,8 +171,12 @@ class VitsEngine:
         ws = self._workspace("te", self._lib.ttsvits_text_encoder_workspace_bytes(self._h, B, T))
         with torch.cuda.device(self.device):
             rc = self._lib.ttsvits_text_encoder(self._h, ids.data_ptr(), lens.data_ptr(), B, T, x.data_ptr(), m.data_ptr(), logs.data_ptr(),
-                                                ws.data_ptr(), ws.numel(), _stream(self.device))
+                                                ws.data_ptr(), ws.numel(), _stream(self.device), self.status.data_ptr())
         self._err(rc, "ttsvits_text_encoder")
+        # nn.Embedding raises IndexError on an id outside the table (models.py:370): the kernel clamps and reports through the status
+        # word - one host sync here, behind the queued launches (no scan of the ids before them)
+        if int(self.status) & 1:
+            raise IndexError(f"token id out of range [0, {self.dims['n_vocab']}) in the text encoder's input")
         return x, m, logs
 
     def flow_reverse(self, z_cl: torch.Tensor, lengths: torch.Tensor) -> torch.Tensor:
