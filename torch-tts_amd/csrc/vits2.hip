@@ -607,21 +607,21 @@ size_t mha_mfma_lds_bytes(int T, int dk, int window) {
 // probabilities, converted to fp16 planes in registers, ARE the B operand of the second product Y = V^T P^T (rows = head
 // channels, columns = queries) - no LDS round trip, no transpose of P.  Y's columns are queries again, so the online
 // rescaling multiplies a lane's own registers.  The k index of that second product is permuted (element j of lane half h
-// of k-step s is key 16 s + 8 (j >> 2) + 4 h + (j & 3)); V is staged TRANSPOSED in LDS ([channel][key]) so that a lane's A
-// fragment of V^T is two 8-byte reads.
+// of k-step s is key 16 s + 8 (j >> 2) + 4 h + (j & 3)); V stays row-major in LDS and the A fragment of V^T comes out of the
+// transposing LDS read (ds_read_b64_tr_b16), two per plane and k-step.
 //   scores: s = (q / sqrt(dk)) . k, -1e4 where mask_q * mask_k == 0 (attentions.py:270-271), keys past T excluded
 //   p = exp(s - running max);  out = sum_k p v / sum_k p      (softmax and P V of attentions.py:283-286, one pass)
 // LDS per buffer: K [32 keys][dk] hi / lo with 16-byte row padding (row stride 2 dk + 16 bytes: the 16 rows of a ds_read_b128
-// group land on 16 distinct 16-byte slots), V^T [32 n_dt rows][32 keys] hi / lo with 72-byte rows (conflict-free 8-byte
-// reads), the 32 key masks.  Two buffers: the next tile's global loads are in flight during a tile's MFMAs and written to LDS
+// group land on 16 distinct 16-byte slots), V [32 keys][dk] hi / lo with 192-byte rows, the 32 key masks.  (A first version
+// staged V transposed with 2-byte LDS stores: 12-way bank conflicts, ~6 000 LDS cycles per tile and CU.)  Two buffers: the next tile's global loads are in flight during a tile's MFMAs and written to LDS
 // behind them (one barrier per tile).
 constexpr int kFaWaves = 4, kFaThreads = 64 * kFaWaves, kFaQ = 32 * kFaWaves;
 template <int DK>
 struct FaLds {
-  static constexpr int NDT = (DK + 31) / 32, KROW = 2 * DK + 16, VROW = 72;
-  static constexpr int KPL = 32 * KROW, VPL = 32 * NDT * VROW;
-  static constexpr int MK = 2 * KPL + 2 * VPL;  // byte offset of the key masks
-  static constexpr int BUF = MK + 128;
+  static constexpr int NDT = (DK + 31) / 32, KROW = 2 * DK + 16, VROW = 192;
+  static constexpr int KPL = 32 * KROW, VPL = 32 * VROW;
+  static constexpr int MK = 2 * KPL + 2 * VPL;  // byte offset of the key masks (32 floats + the "plain tile" word)
+  static constexpr int BUF = MK + 144;
 };
 template <int DK>  // head width: a multiple of 16, at most 64
 __global__ __launch_bounds__(kFaThreads, 2) void mha_flash_kernel(MhaArgs g) {
@@ -631,7 +631,19 @@ __global__ __launch_bounds__(kFaThreads, 2) void mha_flash_kernel(MhaArgs g) {
   extern __shared__ __attribute__((aligned(16))) char fsm[];
   const int T = g.T, C = g.C;
   const int tid = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63, l32 = lane & 31, half = lane >> 5;
-  const int b = blockIdx.z, hd = blockIdx.y, q0 = blockIdx.x * kFaQ + wave * 32;
+  // workgroup -> (utterance, head, query block).  Workgroups go round-robin over the 8 XCDs (b and b + 8 share one, speed
+  // only): the query blocks of one (utterance, head) pair take ids 8 apart, so one XCD's L2 serves the pair's K and V to
+  // all of them (the plain order spread them over five XCDs, each fetching the pair's 230 KB from the Infinity Cache).
+  const int nqb = (T + kFaQ - 1) / kFaQ, heads = C / DK, npair = gridDim.x / nqb;  // grid = npair * nqb
+  int pair, qb;
+  if (npair % 8 == 0) {
+    pair = (blockIdx.x & 7) + 8 * ((blockIdx.x >> 3) / nqb);
+    qb = (blockIdx.x >> 3) % nqb;
+  } else {
+    pair = blockIdx.x / nqb;
+    qb = blockIdx.x % nqb;
+  }
+  const int b = pair / heads, hd = pair % heads, q0 = qb * kFaQ + wave * 32;
   const size_t rowb = (size_t)b * T;
   typedef __attribute__((address_space(1))) const f32x4 gf32x4;
   typedef __attribute__((address_space(1))) const float gf32;
@@ -641,9 +653,14 @@ __global__ __launch_bounds__(kFaThreads, 2) void mha_flash_kernel(MhaArgs g) {
   const bool wave_active = q0 < T;  // (the last workgroup of a sequence: its idle waves only help with the staging)
 
   // ---- staging: item i = tid + 256 n: i < 32 C4: K value group (key i / C4, channels 4 (i % C4) ..); else the same of V ----
-  f32x4 stg[NI];
-  float stg_mk = 0.f;
-  auto stage_load = [&](int t) {
+  // Two register sets: the loads of tiles t + 1 and t + 2 are in flight while tile t is computed (one tile ahead left the
+  // workgroup's two tiles of LDS traffic waiting on a single 12-KB round trip to L2 / the Infinity Cache per tile: 110 us per
+  // launch, latency-bound at ~3 TB/s chip-wide)
+  struct Stage { f32x4 v[NI]; float mk; };
+  Stage stA, stB;
+  auto stage_load = [&](int t, Stage& sg) {
+    f32x4 (&stg)[NI] = sg.v;
+    float& stg_mk = sg.mk;
 #pragma unroll
     for (int n = 0; n < NI; ++n) {
       int i = tid + kFaThreads * n;
@@ -659,7 +676,9 @@ __global__ __launch_bounds__(kFaThreads, 2) void mha_flash_kernel(MhaArgs g) {
       stg_mk = key < T ? maskg[key] : -1.0f;  // (-1: no such key)
     }
   };
-  auto stage_store = [&](int p) {
+  auto stage_store = [&](int p, const Stage& sg) {
+    const f32x4 (&stg)[NI] = sg.v;
+    const float mkv = sg.mk;
     char* buf = fsm + p * L::BUF;
 #pragma unroll
     for (int n = 0; n < NI; ++n) {
@@ -667,26 +686,35 @@ __global__ __launch_bounds__(kFaThreads, 2) void mha_flash_kernel(MhaArgs g) {
       const bool isv = i >= 32 * C4;
       if (isv) i -= 32 * C4;
       const int kk = i / C4, c4 = i % C4;
-      union { f16 h[4]; uint2 u; } hi, lo;
+      // hi = the fp16 below |x| in magnitude (v_cvt_pkrtz: two values per instruction), lo = fp16((x - hi) * 2^11): 21
+      // significand bits for 5 instructions per value where the saturating round-to-nearest split_f16 takes 12
+      typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
+      union { f16x2 h[2]; uint2 u; } hi, lo;
 #pragma unroll
-      for (int e = 0; e < 4; ++e) split_f16(stg[n][e], hi.h[e], lo.h[e]);
+      for (int e = 0; e < 4; e += 2) {
+        const float a = __builtin_amdgcn_fmed3f(stg[n][e], -kSplitMax, kSplitMax), c = __builtin_amdgcn_fmed3f(stg[n][e + 1], -kSplitMax, kSplitMax);
+        hi.h[e >> 1] = __builtin_bit_cast(f16x2, __builtin_amdgcn_cvt_pkrtz(a, c));
+        lo.h[e >> 1] = __builtin_bit_cast(f16x2, __builtin_amdgcn_cvt_pkrtz((a - (float)hi.h[e >> 1][0]) * kSplitScale, (c - (float)hi.h[e >> 1][1]) * kSplitScale));
+      }
       if (!isv) {
         *reinterpret_cast<uint2*>(buf + kk * L::KROW + c4 * 8) = hi.u;
         *reinterpret_cast<uint2*>(buf + L::KPL + kk * L::KROW + c4 * 8) = lo.u;
       } else {
-        char* v = buf + 2 * L::KPL + (4 * c4) * L::VROW + kk * 2;
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-          *reinterpret_cast<f16*>(v + e * L::VROW) = hi.h[e];
-          *reinterpret_cast<f16*>(v + L::VPL + e * L::VROW) = lo.h[e];
-        }
+        *reinterpret_cast<uint2*>(buf + 2 * L::KPL + kk * L::VROW + c4 * 8) = hi.u;
+        *reinterpret_cast<uint2*>(buf + 2 * L::KPL + L::VPL + kk * L::VROW + c4 * 8) = lo.u;
       }
     }
-    if (tid < 32) *reinterpret_cast<float*>(buf + L::MK + tid * 4) = stg_mk;
+    if (tid < 32) *reinterpret_cast<float*>(buf + L::MK + tid * 4) = mkv;
+    // one more word behind the 32 masks: 1 when every key of the tile exists and is unmasked (the common tile: no selects)
+    if (tid < 64) {
+      const bool plain = __all(tid >= 32 || mkv == 1.0f);
+      if (tid == 0) *reinterpret_cast<float*>(buf + L::MK + 128) = plain ? 1.0f : 0.0f;
+    }
   };
 
-  stage_load(0);
-  // zero LDS once: the V^T rows past DK (never staged) must hold finite values
+  stage_load(0, stA);
+  if (nt > 1) stage_load(1, stB);
+  // zero LDS once: the V columns past DK (never staged; read by the second channel tile when DK < 64) must hold finite values
   for (int i = tid; i < 2 * L::BUF / 4; i += kFaThreads) reinterpret_cast<float*>(fsm)[i] = 0.f;
   // ---- this lane's query: column l32 of the wave's 32 queries; B operand of X = K Q^T: Q[query][16 s + 8 half + j] ----
   const int qi = q0 + l32;
@@ -701,16 +729,17 @@ __global__ __launch_bounds__(kFaThreads, 2) void mha_flash_kernel(MhaArgs g) {
       const f32x4 a = *(gf32x4*)(src + 16 * s), c = *(gf32x4*)(src + 16 * s + 4);
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
+        // attentions.py:261: query / sqrt(k_channels); times log2(e): the scores come out in the base-2 domain of v_exp_f32
         f16 h0, l0, h1, l1;
-        split_f16(div_rn(a[e], g.qscale), h0, l0);  // attentions.py:261: query / sqrt(k_channels)
-        split_f16(div_rn(c[e], g.qscale), h1, l1);
+        split_f16(div_rn(a[e], g.qscale) * 1.4426950408889634f, h0, l0);
+        split_f16(div_rn(c[e], g.qscale) * 1.4426950408889634f, h1, l1);
         qh[s][e] = h0; ql[s][e] = l0; qh[s][4 + e] = h1; ql[s][4 + e] = l1;
       }
     }
     mq = qok ? maskg[qi] : 0.f;
   }
   __syncthreads();
-  stage_store(0);
+  stage_store(0, stA);
   __syncthreads();
 
   f32x16 y[NDT], y2[NDT];
@@ -723,9 +752,11 @@ __global__ __launch_bounds__(kFaThreads, 2) void mha_flash_kernel(MhaArgs g) {
     return op(v, __shfl_xor(v, 32));
   };
 
-  for (int t = 0; t < nt; ++t) {
+  // one tile: request tile t + 2 into `ld` (free: its tile went to LDS an iteration ago), compute tile t, store tile t + 1
+  // (requested an iteration ago into `sv`) into the other LDS buffer
+  auto tile_iter = [&](int t, Stage& ld, const Stage& sv) {
     const int p = t & 1;
-    if (t + 1 < nt) stage_load(t + 1);
+    if (t + 2 < nt) stage_load(t + 2, ld);
     if (wave_active) {
       const char* buf = fsm + p * L::BUF;
       // ---- X = K Q^T: rows = the tile's 32 keys (A operand from LDS), columns = the wave's 32 queries ----
@@ -740,66 +771,99 @@ __global__ __launch_bounds__(kFaThreads, 2) void mha_flash_kernel(MhaArgs g) {
         x2 = __builtin_amdgcn_mfma_f32_32x32x16_f16(kh, ql[s], x2, 0, 0, 0);
         x2 = __builtin_amdgcn_mfma_f32_32x32x16_f16(kl, qh[s], x2, 0, 0, 0);
       }
-      // register r of this lane: key (r & 3) + 8 (r >> 2) + 4 half of the tile; its mask values: 4 x 16 bytes
+      // register r of this lane: key (r & 3) + 8 (r >> 2) + 4 half of the tile
       float sc[16];
       float tmax = -3.0e38f;
+      const bool plain = *reinterpret_cast<const float*>(buf + L::MK + 128) != 0.f && __all(mq != 0.f);  // (uniform)
+      if (plain) {
 #pragma unroll
-      for (int gq = 0; gq < 4; ++gq) {
-        const f32x4 mk4 = *reinterpret_cast<const f32x4*>(buf + L::MK + (8 * gq + 4 * half) * 4);
+        for (int r = 0; r < 16; ++r) {
+          sc[r] = fmaf(x2[r], 1.0f / kSplitScale, x[r]);
+          tmax = fmaxf(tmax, sc[r]);
+        }
+      } else {
 #pragma unroll
-        for (int e = 0; e < 4; ++e) {
-          const int r = 4 * gq + e;
-          float v = fmaf(x2[r], 1.0f / kSplitScale, x[r]);
-          v = mk4[e] < 0.f ? -3.0e38f : (mq * mk4[e] == 0.f ? -1e4f : v);  // attentions.py:270-271 masked_fill(mask == 0, -1e4)
-          sc[r] = v;
-          tmax = fmaxf(tmax, v);
+        for (int gq = 0; gq < 4; ++gq) {
+          const f32x4 mk4 = *reinterpret_cast<const f32x4*>(buf + L::MK + (8 * gq + 4 * half) * 4);  // the masks of 4 of its keys
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            const int r = 4 * gq + e;
+            float v = fmaf(x2[r], 1.0f / kSplitScale, x[r]);
+            v = mk4[e] < 0.f ? -3.0e38f : (mq * mk4[e] == 0.f ? -1e4f * 1.4426950408889634f : v);  // attentions.py:270-271 masked_fill(mask == 0, -1e4)
+            sc[r] = v;
+            tmax = fmaxf(tmax, v);
+          }
         }
       }
       tmax = pair_with_other_half(tmax, [](float a, float c) { return fmaxf(a, c); });
-      const float m_new = fmaxf(m_run, tmax);
-      const float alpha = __expf(m_run - m_new);  // (first tile: exp(-3e38 - m) = 0, and the sums are 0)
-      m_run = m_new;
-      float ps = 0.f;
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        sc[r] = __expf(sc[r] - m_new);
-        ps += sc[r];
-      }
-      lsum = fmaf(lsum, alpha, ps);
-      if (__any(alpha != 1.0f)) {  // (the running maximum of some query moved: rare after the first tiles)
+      // Online softmax with a LAZY running maximum (base-2 domain): m_run moves only when a tile's maximum exceeds it by more
+      // than 8, so p = 2^(s - m_run) <= 256 (exact in the split planes) and the 64 accumulator registers are rescaled a few
+      // times per query instead of at almost every tile (with 32 queries per wave SOME maximum moves in 85 % of the tiles).
+      // Every quantity that is on the old scale - the sums and both accumulator sets - is rescaled together, before this
+      // tile's p are formed.
+      const bool move = tmax > m_run + 8.0f;  // (first tile: m_run = -3e38)
+      if (__any(move)) {
+        const float m_new = move ? tmax : m_run;
+        const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);  // (1 where nothing moved; 0 on the first tile, where the sums are 0)
+        m_run = m_new;
+        lsum *= alpha;
 #pragma unroll
         for (int dt = 0; dt < NDT; ++dt)
 #pragma unroll
           for (int r = 0; r < 16; ++r) { y[dt][r] *= alpha; y2[dt][r] *= alpha; }
       }
+      float ps = 0.f;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        sc[r] = __builtin_amdgcn_exp2f(sc[r] - m_run);
+        ps += sc[r];
+      }
+      lsum += ps;
       // ---- Y += V^T P^T: P's registers 8 s .. 8 s + 7 are k-step s of the B operand; A = V^T rows (channels) from LDS ----
       f16x8 ph[2], pl[2];
 #pragma unroll
       for (int s = 0; s < 2; ++s)
 #pragma unroll
-        for (int j = 0; j < 8; ++j) {
-          f16 h0, l0;
-          split_f16_pos(sc[8 * s + j], h0, l0);
-          ph[s][j] = h0; pl[s][j] = l0;
+        for (int j = 0; j < 8; j += 2) {
+          // p in [0, 256]: hi = the fp16 below it (v_cvt_pkrtz, two values per instruction), lo = fp16((p - hi) * 2^11): 21
+          // significand bits, no range or subnormal cases to handle
+          typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
+          const float a = sc[8 * s + j], c = sc[8 * s + j + 1];
+          const f16x2 h2 = __builtin_bit_cast(f16x2, __builtin_amdgcn_cvt_pkrtz(a, c));
+          const f16x2 l2 = __builtin_bit_cast(f16x2, __builtin_amdgcn_cvt_pkrtz((a - (float)h2[0]) * kSplitScale, (c - (float)h2[1]) * kSplitScale));
+          ph[s][j] = h2[0]; ph[s][j + 1] = h2[1];
+          pl[s][j] = l2[0]; pl[s][j + 1] = l2[1];
         }
+      // A fragment of V^T (row = channel 32 dt + l32): element j = V[key 16 s + 8 (j >> 2) + 4 half + (j & 3)][channel] - four
+      // consecutive KEYS of one channel, twice.  V sits row-major in LDS ([key][channel], 192-byte rows); the transposing read
+      // ds_read_b64_tr_b16 hands every lane of a 16-lane group one COLUMN (channel) of a 4-row x 16-column block: lane 4 q + p
+      // of the group supplies the address of row q, columns 4 p .. 4 p + 3, lane i receives column i, row q in element q
+      // (cdna_hip_programming.md T10).  Rows 192 bytes apart put the block's four rows on four disjoint quarters of the banks.
+      const unsigned va0 = (unsigned)(uintptr_t)(__attribute__((address_space(3))) const char*)(buf + 2 * L::KPL) +
+                           (4 * half + ((lane & 15) >> 2)) * L::VROW + (16 * ((lane & 31) >> 4) + 4 * (lane & 3)) * 2;
 #pragma unroll
       for (int dt = 0; dt < NDT; ++dt) {
-        const char* va = buf + 2 * L::KPL + (32 * dt + l32) * L::VROW + half * 8;
 #pragma unroll
         for (int s = 0; s < 2; ++s) {
           union { uint2 u[2]; f16x8 v; } vh, vl;
-          vh.u[0] = *reinterpret_cast<const uint2*>(va + 32 * s);       // keys 16 s + 4 half + (0..3)
-          vh.u[1] = *reinterpret_cast<const uint2*>(va + 32 * s + 16);  // keys 16 s + 8 + 4 half + (0..3)
-          vl.u[0] = *reinterpret_cast<const uint2*>(va + L::VPL + 32 * s);
-          vl.u[1] = *reinterpret_cast<const uint2*>(va + L::VPL + 32 * s + 16);
+          const unsigned a = va0 + 16 * s * L::VROW + 64 * dt;
+          asm volatile("ds_read_b64_tr_b16 %0, %4\n\tds_read_b64_tr_b16 %1, %4 offset:%c5\n\t"
+                       "ds_read_b64_tr_b16 %2, %4 offset:%c6\n\tds_read_b64_tr_b16 %3, %4 offset:%c7\n\ts_waitcnt lgkmcnt(0)"
+                       : "=&v"(vh.u[0]), "=&v"(vh.u[1]), "=&v"(vl.u[0]), "=&v"(vl.u[1])
+                       : "v"(a), "i"(8 * L::VROW), "i"(L::VPL), "i"(L::VPL + 8 * L::VROW)
+                       : "memory");
           y[dt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vh.v, ph[s], y[dt], 0, 0, 0);
           y2[dt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vh.v, pl[s], y2[dt], 0, 0, 0);
           y2[dt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vl.v, ph[s], y2[dt], 0, 0, 0);
         }
       }
     }
-    if (t + 1 < nt) stage_store(p ^ 1);  // (buffer p ^ 1 was last read in iteration t - 1: every wave is past that barrier)
+    if (t + 1 < nt) stage_store(p ^ 1, sv);  // (buffer p ^ 1 was last read in iteration t - 1: every wave is past that barrier)
     __syncthreads();
+  };
+  for (int t = 0; t < nt; t += 2) {
+    tile_iter(t, stA, stB);
+    if (t + 1 < nt) tile_iter(t + 1, stB, stA);
   }
   if (!wave_active) return;
   const float ltot = pair_with_other_half(lsum, [](float a, float c) { return a + c; });
@@ -1094,7 +1158,7 @@ int run_stack(ttsvits_handle* h, const StackBlob& sb, const StackDims& sd, const
     a.ek = sd.window >= 0 ? blob + sb.ek[i] : nullptr; a.ev = sd.window >= 0 ? blob + sb.ev[i] : nullptr;
     a.qscale = sqrtf((float)dk);
     if (use_flash) {
-      const dim3 grid((T + kFaQ - 1) / kFaQ, sd.heads, B), block(kFaThreads);
+      const dim3 grid(((T + kFaQ - 1) / kFaQ) * sd.heads * B), block(kFaThreads);
       if (dk == 48) hipLaunchKernelGGL(mha_flash_kernel<48>, grid, block, 2 * FaLds<48>::BUF, st, a);
       else if (dk == 32) hipLaunchKernelGGL(mha_flash_kernel<32>, grid, block, 2 * FaLds<32>::BUF, st, a);
       else if (dk == 64) hipLaunchKernelGGL(mha_flash_kernel<64>, grid, block, 2 * FaLds<64>::BUF, st, a);
