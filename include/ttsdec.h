@@ -381,17 +381,23 @@ typedef struct ttsvits_dims {
   int32_t flow_tf_layers;   /* 2: pre_transformer = Encoder(half, half, 2 heads, 2 layers, k=3, no window) */
   int32_t flow_tf_heads;    /* 2                                                         */
   int32_t flow_tf_kernel;   /* 3                                                         */
+  int32_t gin_channels;     /* 0, or the speaker-embedding width (a multiple of 4): each coupling layer's WN gets cond_layer
+                             * (modules.py:149-153) and the text encoder spk_emb_linear (attentions.py:42-46)                */
+  int32_t cond_layer_idx;   /* text-encoder layer at whose input the projected embedding is added (attentions.py:47-52: 2
+                             * unless configured); read only when gin_channels > 0 and n_layers > 0                           */
 } ttsvits_dims;
 typedef struct ttsvits_handle ttsvits_handle;
 
 /* Source tensors for ttsvits_pack_weights (device fp32, the reference's parameter shapes), in this order:
  *   enc_p.emb.weight;
+ *   when gin_channels > 0: enc_p.encoder.spk_emb_linear.{weight,bias};
  *   per text-encoder layer i: attn_layers.i.conv_{q,k,v,o}.{weight,bias} (8), emb_rel_k, emb_rel_v,
  *       norm_layers_1.i.{gamma,beta}, ffn_layers.i.conv_1.{weight,bias}, conv_2.{weight,bias},
  *       norm_layers_2.i.{gamma,beta}                                            (18 per layer);
  *   enc_p.proj.{weight,bias};
  *   per coupling layer f (flow.flows.{2f}): per pre_transformer layer the same 16 tensors without the
- *       emb_rel pair; pre.{weight,bias}; per WN layer j: in_layers.j EFFECTIVE weight (g*v/||v||), bias,
+ *       emb_rel pair; pre.{weight,bias}; when gin_channels > 0: enc.cond_layer EFFECTIVE weight [2*flow_hidden*
+ *       flow_wn_layers, gin(, 1)], bias; per WN layer j: in_layers.j EFFECTIVE weight (g*v/||v||), bias,
  *       res_skip_layers.j effective weight, bias; post.{weight,bias}.
  * A NULL entry leaves that tensor zero (a module that owns only the text encoder or only the flow). */
 int ttsvits_create(const ttsvits_dims* dims, ttsvits_handle** out);
@@ -408,13 +414,16 @@ int ttsvits_pack_weights(ttsvits_handle* h, const float* const* src, int n_src, 
 int ttsvits_bind_weights(ttsvits_handle* h, const void* blob);
 size_t ttsvits_text_encoder_workspace_bytes(const ttsvits_handle* h, int B, int T);
 /* ids [B, T] int64, lengths [B] int32 (device).  x [B, T, hidden], m and logs [B, T, inter]; padded frames are zero.
+ * g: NULL, or the speaker embedding [B, gin_channels] fp32 (device) - the reference's g [B, gin, 1] (models.py:369, 376;
+ * attentions.py:80-84); TTSDEC_ERR_INVALID_ARG when g is given and the handle has gin_channels == 0.
  * status: as for ttsenc_forward (bit 0: an id outside [0, n_vocab), models.py:370). */
-int ttsvits_text_encoder(ttsvits_handle* h, const int64_t* ids, const int32_t* lengths, int B, int T, float* x, float* m,
-                         float* logs, void* workspace, size_t workspace_bytes, void* stream, int32_t* status);
+int ttsvits_text_encoder(ttsvits_handle* h, const int64_t* ids, const int32_t* lengths, const float* g, int B, int T, float* x,
+                         float* m, float* logs, void* workspace, size_t workspace_bytes, void* stream, int32_t* status);
 size_t ttsvits_flow_workspace_bytes(const ttsvits_handle* h, int B, int T);
-/* z [B, T, inter] -> out [B, T, inter]; lengths [B] int32 (device) give y_mask. */
-int ttsvits_flow_reverse(ttsvits_handle* h, const float* z, const int32_t* lengths, int B, int T, float* out, void* workspace,
-                         size_t workspace_bytes, void* stream);
+/* z [B, T, inter] -> out [B, T, inter]; lengths [B] int32 (device) give y_mask.  g: NULL or the speaker embedding
+ * [B, gin_channels] (the reference's g [B, gin, 1], models.py:506, 511; modules.py:185-199), as above. */
+int ttsvits_flow_reverse(ttsvits_handle* h, const float* z, const int32_t* lengths, const float* g, int B, int T, float* out,
+                         void* workspace, size_t workspace_bytes, void* stream);
 
 #ifdef __cplusplus
 }

@@ -47,6 +47,10 @@ class Vits2Dims:
     flow_tf_layers: int = 2  # pre_transformer: Encoder(half, half, n_heads=2, n_layers=2, kernel_size=3, window_size=None)
     flow_tf_heads: int = 2
     flow_tf_kernel: int = 3
+    # speaker conditioning (0 = none): WN.cond_layer per coupling layer (modules.py:149-153) and the text encoder's
+    # spk_emb_linear, added at the input of layer cond_layer_idx (attentions.py:41-52, 80-84)
+    gin_channels: int = 0
+    cond_layer_idx: int = 2
 
 
 def sequence_mask(lengths: Tensor, T: int) -> Tensor:
@@ -106,11 +110,14 @@ def ffn(x: Tensor, x_mask: Tensor, wts: Weights, prefix: str, kernel: int) -> Te
 
 
 def encoder_stack(x: Tensor, x_mask: Tensor, wts: Weights, prefix: str, n_layers: int, n_heads: int,
-                  window: Optional[int], kernel: int) -> Tensor:
-    """attentions.Encoder.forward in eval mode, g=None (attentions.py:76-93)."""
+                  window: Optional[int], kernel: int, g: Optional[Tensor] = None, cond_layer_idx: int = -1) -> Tensor:
+    """attentions.Encoder.forward in eval mode (attentions.py:76-93); g [B, gin, 1] enters at layer cond_layer_idx (:80-84)."""
     attn_mask = x_mask.unsqueeze(2) * x_mask.unsqueeze(-1)
     x = x * x_mask
     for i in range(n_layers):
+        if i == cond_layer_idx and g is not None:
+            gp = F.linear(g.transpose(1, 2), wts[prefix + ".spk_emb_linear.weight"], wts[prefix + ".spk_emb_linear.bias"]).transpose(1, 2)
+            x = (x + gp) * x_mask
         y = mha(x, attn_mask, wts, f"{prefix}.attn_layers.{i}", n_heads, window)
         x = layer_norm_c(x + y, wts[f"{prefix}.norm_layers_1.{i}.gamma"], wts[f"{prefix}.norm_layers_1.{i}.beta"])
         y = ffn(x, x_mask, wts, f"{prefix}.ffn_layers.{i}", kernel)
@@ -118,13 +125,15 @@ def encoder_stack(x: Tensor, x_mask: Tensor, wts: Weights, prefix: str, n_layers
     return x * x_mask
 
 
-def text_encoder(ids: Tensor, lengths: Tensor, wts: Weights, dims: Vits2Dims, prefix: str = "enc_p") -> Tuple[Tensor, Tensor, Tensor, Tensor]:
+def text_encoder(ids: Tensor, lengths: Tensor, wts: Weights, dims: Vits2Dims, prefix: str = "enc_p",
+                 g: Optional[Tensor] = None) -> Tuple[Tensor, Tensor, Tensor, Tensor]:
     """TextEncoder.forward (models.py:369-380): returns (x, m, logs, x_mask)."""
     H = dims.hidden_channels
     x = F.embedding(ids, wts[prefix + ".emb.weight"]) * math.sqrt(H)  # [B, T, H]
     x = x.transpose(1, -1)
     x_mask = sequence_mask(lengths, x.shape[2]).unsqueeze(1).to(x.dtype)
-    x = encoder_stack(x * x_mask, x_mask, wts, prefix + ".encoder", dims.n_layers, dims.n_heads, dims.window_size, dims.kernel_size)
+    x = encoder_stack(x * x_mask, x_mask, wts, prefix + ".encoder", dims.n_layers, dims.n_heads, dims.window_size, dims.kernel_size,
+                      g=g, cond_layer_idx=dims.cond_layer_idx if dims.gin_channels else -1)
     stats = F.conv1d(x, wts[prefix + ".proj.weight"], wts[prefix + ".proj.bias"]) * x_mask
     m, logs = torch.split(stats, dims.inter_channels, dim=1)
     return x, m, logs, x_mask
@@ -138,14 +147,19 @@ def weight_norm_weight(wts: Weights, prefix: str) -> Tensor:
     return v * (g / v.flatten(1).norm(dim=1).view(-1, 1, 1))
 
 
-def wn(x: Tensor, x_mask: Tensor, wts: Weights, prefix: str, n_layers: int, kernel: int, dilation_rate: int = 1) -> Tensor:
-    """modules.WN.forward with g=None (modules.py:185-210) and commons.fused_add_tanh_sigmoid_multiply (:102-109)."""
+def wn(x: Tensor, x_mask: Tensor, wts: Weights, prefix: str, n_layers: int, kernel: int, dilation_rate: int = 1,
+       g: Optional[Tensor] = None) -> Tensor:
+    """modules.WN.forward (modules.py:185-210) and commons.fused_add_tanh_sigmoid_multiply (:102-109); g [B, gin, 1 or T]."""
     H = x.shape[1]
     output = torch.zeros_like(x)
+    if g is not None:
+        g = F.conv1d(g, weight_norm_weight(wts, f"{prefix}.cond_layer"), wts[f"{prefix}.cond_layer.bias"])  # :189-190
     for i in range(n_layers):
         d = dilation_rate**i
         pad = (kernel * d - d) // 2
         x_in = F.conv1d(x, weight_norm_weight(wts, f"{prefix}.in_layers.{i}"), wts[f"{prefix}.in_layers.{i}.bias"], padding=pad, dilation=d)
+        if g is not None:
+            x_in = x_in + g[:, i * 2 * H:(i + 1) * 2 * H, :]  # g_l, :193-196
         acts = torch.tanh(x_in[:, :H]) * torch.sigmoid(x_in[:, H:])
         rs = F.conv1d(acts, weight_norm_weight(wts, f"{prefix}.res_skip_layers.{i}"), wts[f"{prefix}.res_skip_layers.{i}.bias"])
         if i < n_layers - 1:
@@ -156,26 +170,26 @@ def wn(x: Tensor, x_mask: Tensor, wts: Weights, prefix: str, n_layers: int, kern
     return output * x_mask
 
 
-def coupling_reverse(x: Tensor, x_mask: Tensor, wts: Weights, prefix: str, dims: Vits2Dims) -> Tensor:
+def coupling_reverse(x: Tensor, x_mask: Tensor, wts: Weights, prefix: str, dims: Vits2Dims, g: Optional[Tensor] = None) -> Tensor:
     """ResidualCouplingTransformersLayer.forward(reverse=True), mean_only (models.py:506-531)."""
     half = dims.inter_channels // 2
     x0, x1 = torch.split(x, [half, half], 1)
     x0_ = encoder_stack(x0 * x_mask, x_mask, wts, prefix + ".pre_transformer", dims.flow_tf_layers, dims.flow_tf_heads, None, dims.flow_tf_kernel)
     x0_ = x0_ + x0
     h = F.conv1d(x0_, wts[prefix + ".pre.weight"], wts[prefix + ".pre.bias"]) * x_mask
-    h = wn(h, x_mask, wts, prefix + ".enc", dims.flow_wn_layers, dims.flow_kernel)
+    h = wn(h, x_mask, wts, prefix + ".enc", dims.flow_wn_layers, dims.flow_kernel, g=g)
     m = F.conv1d(h, wts[prefix + ".post.weight"], wts[prefix + ".post.bias"]) * x_mask
     x1 = (x1 - m) * x_mask  # logs = 0 in mean-only mode: exp(-logs) = 1
     return torch.cat([x0, x1], 1)
 
 
-def flow_reverse(z: Tensor, y_mask: Tensor, wts: Weights, dims: Vits2Dims, prefix: str = "flow") -> Tensor:
+def flow_reverse(z: Tensor, y_mask: Tensor, wts: Weights, dims: Vits2Dims, prefix: str = "flow", g: Optional[Tensor] = None) -> Tensor:
     """ResidualCouplingTransformersBlock.forward(reverse=True) (models.py:803-810): flows are
     [layer_0, Flip, layer_1, Flip, ...]; reversed: Flip, layer_{n-1}, ..., Flip, layer_0."""
     x = z
     for i in reversed(range(dims.n_flows)):
         x = torch.flip(x, [1])  # modules.Flip (modules.py:374-381)
-        x = coupling_reverse(x, y_mask, wts, f"{prefix}.flows.{2 * i}", dims)
+        x = coupling_reverse(x, y_mask, wts, f"{prefix}.flows.{2 * i}", dims, g=g)
     return x
 
 
@@ -215,6 +229,7 @@ def random_vits2_weights(dims: Vits2Dims, seed: int = 0) -> Weights:
     H, I = dims.hidden_channels, dims.inter_channels
     w["enc_p.emb.weight"] = rn(dims.n_vocab, H, scale=H**-0.5)
     _encoder_weights(w, "enc_p.encoder", H, dims.filter_channels, dims.n_layers, dims.n_heads, dims.window_size, dims.kernel_size, g)
+    gin = dims.gin_channels
     w["enc_p.proj.weight"] = rn(2 * I, H, 1, scale=H**-0.5)
     w["enc_p.proj.bias"] = rn(2 * I, scale=0.1)
     half, Fh = I // 2, dims.flow_hidden
@@ -234,4 +249,13 @@ def random_vits2_weights(dims: Vits2Dims, seed: int = 0) -> Weights:
             w[f"{p}.enc.res_skip_layers.{j}.bias"] = rn(cr, scale=0.1)
         w[p + ".post.weight"] = rn(half, Fh, 1, scale=Fh**-0.5)
         w[p + ".post.bias"] = rn(half, scale=0.1)
+    if gin:  # (drawn last: the unconditioned tensors above do not depend on gin_channels)
+        w["enc_p.encoder.spk_emb_linear.weight"] = rn(H, gin, scale=gin**-0.5)
+        w["enc_p.encoder.spk_emb_linear.bias"] = rn(H, scale=0.1)
+        for i in range(dims.n_flows):
+            p = f"flow.flows.{2 * i}.enc.cond_layer"
+            nc = 2 * Fh * dims.flow_wn_layers
+            w[p + ".weight_v"] = rn(nc, gin, 1, scale=gin**-0.5)
+            w[p + ".weight_g"] = 0.5 + torch.rand(nc, 1, 1, generator=g)
+            w[p + ".bias"] = rn(nc, scale=0.1)
     return w

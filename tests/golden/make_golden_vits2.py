@@ -198,8 +198,36 @@ print("models.py vs the composition (max abs diff):", via_models)
 assert all(v == 0.0 for v in via_models.values()), via_models
 assert torch.equal(rmask, x_mask)
 
+# ---- speaker conditioning (gin_channels > 0): models.TextEncoder / ResidualCouplingTransformersBlock with g [B, gin, 1] ----
+# (placed after everything above so that the earlier arrays keep their RNG draws; a third encoder layer because
+# attentions.py:47-52 conditions at layer 2 and asserts 2 < n_layers)
+DG = dict(D, n_layers=3, gin_channels=8, cond_layer_idx=2)
+with torch.no_grad():
+    te_g = models.TextEncoder(DG["n_vocab"], I, H, DG["filter_channels"], DG["n_heads"], DG["n_layers"], DG["kernel_size"], 0.1,
+                              gin_channels=DG["gin_channels"]).eval()
+    randomize(te_g.encoder); randomize(te_g.proj)
+    te_g.encoder.spk_emb_linear.weight.normal_(0.0, 0.5)
+    fl_g = models.ResidualCouplingTransformersBlock(I, Fh, DG["flow_kernel"], 1, DG["flow_wn_layers"], n_flows=DG["n_flows"],
+                                                    gin_channels=DG["gin_channels"], use_transformer_flows=True,
+                                                    transformer_flow_type="pre_conv").eval()
+    randomize(fl_g)
+    for k, v in te_g.state_dict().items():
+        out[f"wg/enc_p.{k}"] = v.detach().numpy().copy()
+    for k, v in fl_g.state_dict().items():
+        if "post_transformer" not in k:
+            out[f"wg/flow.{k}"] = v.detach().numpy().copy()
+    g_spk = torch.randn(B, DG["gin_channels"], 1)
+    gx, gm, glogs, _ = te_g(ids, lengths, g=g_spk)               # models.py:369-380 with attentions.py:80-84
+    gx0, _, _, _ = te_g(ids, lengths, g=None)
+    gflow = fl_g(z, y_mask, g=g_spk, reverse=True)                # models.py:803-810 with modules.py:189-199
+    gflow0 = fl_g(z, y_mask, g=None, reverse=True)
+    assert float((gx - gx0).abs().max()) > 1e-2 and float((gflow - gflow0).abs().max()) > 1e-2  # (g matters in both)
+out["g/spk"] = g_spk.numpy()
+out["g/te/x"] = gx.numpy(); out["g/te/m"] = gm.numpy(); out["g/te/logs"] = glogs.numpy(); out["g/te/x_no_g"] = gx0.numpy()
+out["g/flow/out"] = gflow.numpy(); out["g/flow/out_no_g"] = gflow0.numpy()
+
 np.savez_compressed(os.path.join(HERE, "vits2_small.npz"), **out)
-json.dump({"dims": D, "reference": "kgoba/torch-tts @ 2024_10_08, vits2/{attentions,modules,commons,models}.py imported on CPU",
+json.dump({"dims": D, "dims_g": DG, "reference": "kgoba/torch-tts @ 2024_10_08, vits2/{attentions,modules,commons,models}.py imported on CPU",
            "glue": "te/* and flow/* equal, bit for bit, the outputs of models.TextEncoder.forward and "
                    "models.ResidualCouplingTransformersBlock.forward(reverse=True) themselves (vits2/models.py imported with "
                    "monotonic_align/core.pyx compiled into a scratch directory); the step-by-step composition in "

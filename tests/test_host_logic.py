@@ -296,12 +296,22 @@ def test_vits2_modules_keys_tensor_counts_and_refusals():
                                                    use_transformer_flows=True)
     mine = {"flow." + k for k in fl.state_dict() if "post_transformer" not in k}
     assert mine == {k for k in ref_keys if k.startswith("flow.")}
+    # speaker-conditioned variants (gin_channels > 0): the reference's extra keys, and two more tensors per owner in the C ABI's list
+    dg = json.load(open(os.path.join(ROOT, "tests", "golden", "vits2_meta.json")))["dims_g"]
+    ref_keys_g = {k[3:] for k in z.files if k.startswith("wg/")}
+    te_g = T.vits2.TextEncoder(dg["n_vocab"], dg["inter_channels"], dg["hidden_channels"], dg["filter_channels"], dg["n_heads"], dg["n_layers"],
+                               dg["kernel_size"], 0.1, gin_channels=dg["gin_channels"])
+    assert {"enc_p." + k for k in te_g.state_dict()} == {k for k in ref_keys_g if k.startswith("enc_p.")}
+    fl_g = T.vits2.ResidualCouplingTransformersBlock(dg["inter_channels"], dg["flow_hidden"], dg["flow_kernel"], 1, dg["flow_wn_layers"],
+                                                     n_flows=dg["n_flows"], gin_channels=dg["gin_channels"], use_transformer_flows=True)
+    assert {"flow." + k for k in fl_g.state_dict() if "post_transformer" not in k} == {k for k in ref_keys_g if k.startswith("flow.")}
+    assert te_g.encoder.cond_layer_idx == 2 and len(fl_g.flows[0].weight_tensors()) == len(fl.flows[0].weight_tensors()) + 2
     # tensor counts the C ABI expects (include/ttsdec.h): 1 + 18/layer + 2 ; per flow 16/tf-layer + 2 + 4/WN-layer + 2
     lib = _lib.load()
     import ctypes as C
 
     h = C.c_void_p()
-    dims = _lib.VitsDims(*[int(d[n]) for n, _ in _lib.VitsDims._fields_])
+    dims = _lib.VitsDims(*[int(d.get(n, 0)) for n, _ in _lib.VitsDims._fields_])
     assert lib.ttsvits_create(C.byref(dims), C.byref(h)) == _lib.OK
     n_text = 1 + 18 * d["n_layers"] + 2
     n_flow = d["n_flows"] * (16 * d["flow_tf_layers"] + 2 + 4 * d["flow_wn_layers"] + 2)
@@ -309,9 +319,15 @@ def test_vits2_modules_keys_tensor_counts_and_refusals():
     assert len([te.emb.weight] + te.encoder.weight_tensors() + [te.proj.weight, te.proj.bias]) == n_text
     assert sum(len(fl.flows[2 * i].weight_tensors()) for i in range(d["n_flows"])) == n_flow
     assert lib.ttsvits_packed_bytes(h) % 256 == 0 and lib.ttsvits_text_encoder_workspace_bytes(h, 2, 13) > 0
-    assert lib.ttsvits_flow_reverse(h, 256, 256, 1, 4, 256, 256, 1 << 30, None) == _lib.ERR_NOT_BOUND
+    assert lib.ttsvits_flow_reverse(h, 256, 256, None, 1, 4, 256, 256, 1 << 30, None) == _lib.ERR_NOT_BOUND
     lib.ttsvits_destroy(h)
-    bad = _lib.VitsDims(*[int(d[n]) for n, _ in _lib.VitsDims._fields_])
+    dims_g = _lib.VitsDims(*[int(dg.get(n, 0)) for n, _ in _lib.VitsDims._fields_])
+    assert lib.ttsvits_create(C.byref(dims_g), C.byref(h)) == _lib.OK
+    assert lib.ttsvits_num_weight_tensors(h) == (1 + 2 + 18 * dg["n_layers"] + 2) + dg["n_flows"] * (16 * dg["flow_tf_layers"] + 2 + 2 + 4 * dg["flow_wn_layers"] + 2)
+    lib.ttsvits_destroy(h)
+    dims_g.cond_layer_idx = dg["n_layers"]  # attentions.py:50-52
+    assert lib.ttsvits_create(C.byref(dims_g), C.byref(h)) == _lib.ERR_DIMS
+    bad = _lib.VitsDims(*[int(d.get(n, 0)) for n, _ in _lib.VitsDims._fields_])
     bad.inter_channels = 18  # half = 9 is not a multiple of 4
     assert lib.ttsvits_create(C.byref(bad), C.byref(h)) == _lib.ERR_DIMS
     with pytest.raises(RuntimeError):

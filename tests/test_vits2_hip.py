@@ -35,7 +35,7 @@ def _text_encoder(d, wts):
     import torch_tts_amd as T
 
     te = T.vits2.TextEncoder(d["n_vocab"], d["inter_channels"], d["hidden_channels"], d["filter_channels"], d["n_heads"], d["n_layers"],
-                             d["kernel_size"], 0.1)
+                             d["kernel_size"], 0.1, gin_channels=d.get("gin_channels", 0))
     sd = {k[len("enc_p."):]: v for k, v in wts.items() if k.startswith("enc_p.")}
     te.load_state_dict(sd, strict=True)
     return te.cuda().eval()
@@ -45,7 +45,7 @@ def _flow(d, wts):
     import torch_tts_amd as T
 
     fl = T.vits2.ResidualCouplingTransformersBlock(d["inter_channels"], d["flow_hidden"], d["flow_kernel"], 1, d["flow_wn_layers"],
-                                                   n_flows=d["n_flows"], use_transformer_flows=True)
+                                                   n_flows=d["n_flows"], gin_channels=d.get("gin_channels", 0), use_transformer_flows=True)
     sd = {k[len("flow."):]: v for k, v in wts.items() if k.startswith("flow.")}
     missing, unexpected = fl.load_state_dict(sd, strict=False)
     assert not unexpected and all("post_transformer" in k for k in missing), (missing, unexpected)
@@ -149,3 +149,71 @@ def test_flow_reverse_long_sequence_uses_the_scalar_attention_fallback():
     with torch.no_grad():
         out = fl(z.cuda(), ymask.cuda(), reverse=True)
     _close(out, ref64, "flow out (T=1300)", rtol=1e-4, atol=1e-5)
+
+
+# ---- speaker conditioning (gin_channels > 0) ----
+def test_speaker_conditioning_golden(gv):
+    """g [B, gin, 1] through both entry points against outputs of models.TextEncoder / ResidualCouplingTransformersBlock themselves
+    (tests/golden/make_golden_vits2.py, the g/* arrays); g=None on the same conditioned modules takes the unconditioned branch."""
+    z = np.load(os.path.join(HERE, "golden", "vits2_small.npz"))
+    wg = {k[3:]: torch.from_numpy(z[k]) for k in z.files if k.startswith("wg/")}
+    dg = json.load(open(os.path.join(HERE, "golden", "vits2_meta.json")))["dims_g"]
+    c = gv["c"]
+    g = c["g/spk"].cuda()
+    ymask = V.sequence_mask(c["flow/lengths"], 17).unsqueeze(1).float().cuda()
+    for prec in ("split_f16", "f32"):
+        te, fl = _text_encoder(dg, wg), _flow(dg, wg)
+        te.precision = fl.precision = prec
+        with torch.no_grad():
+            x, m, logs, _ = te(c["te/ids"].cuda(), c["te/lengths"].cuda(), g=g)
+            x0, _, _, _ = te(c["te/ids"].cuda(), c["te/lengths"].cuda())
+            out = fl(c["flow/z"].cuda(), ymask, g=g, reverse=True)
+            out0 = fl(c["flow/z"].cuda(), ymask, reverse=True)
+            out2 = fl(c["flow/z"].cuda(), ymask, g=g[:, :, 0], reverse=True)  # ([B, gin] is accepted as well)
+        _close(x, c["g/te/x"], f"{prec} x"); _close(m, c["g/te/m"], f"{prec} m"); _close(logs, c["g/te/logs"], f"{prec} logs")
+        _close(x0, c["g/te/x_no_g"], f"{prec} x without g")
+        _close(out, c["g/flow/out"], f"{prec} flow out"); _close(out0, c["g/flow/out_no_g"], f"{prec} flow out without g")
+        assert torch.equal(out, out2)
+
+
+@pytest.mark.parametrize("B,T,lengths", [(3, 200, [200, 131, 7])])
+def test_speaker_conditioning_default_dims_vs_oracle(B, T, lengths):
+    """ModelConfig-default widths with the multi-speaker gin_channels = 256 (cli.py) against the oracle, fp32 and fp64."""
+    d = V.Vits2Dims(gin_channels=256)
+    wts = V.random_vits2_weights(d, seed=8)
+    gen = torch.Generator().manual_seed(4)
+    z = torch.randn(B, d.inter_channels, T, generator=gen)
+    ids = torch.randint(0, d.n_vocab, (B, T), generator=gen)
+    g = torch.randn(B, d.gin_channels, 1, generator=gen)
+    lens = torch.tensor(lengths)
+    ymask = V.sequence_mask(lens, T).unsqueeze(1).float()
+    w64 = {k: v.double() for k, v in wts.items()}
+    ref = V.flow_reverse(z, ymask, wts, d, g=g)
+    ref64 = V.flow_reverse(z.double(), ymask.double(), w64, d, g=g.double()).float()
+    assert float((ref - V.flow_reverse(z, ymask, wts, d)).abs().max()) > 1e-2
+    fl = _flow({**d.__dict__}, wts)
+    te = _text_encoder({**d.__dict__}, wts)
+    ox, om, ol, _ = V.text_encoder(ids, lens, wts, d, g=g)
+    with torch.no_grad():
+        out = fl(z.cuda(), ymask.cuda(), g=g.cuda(), reverse=True)
+        x, m, logs, _ = te(ids.cuda(), lens.cuda(), g=g.cuda())
+    _close(out, ref64, "flow out vs fp64 oracle", rtol=1e-4, atol=1e-5)
+    _close(out, ref, "flow out", rtol=2e-4, atol=2e-5)
+    _close(x, ox, "x"); _close(m, om, "m"); _close(logs, ol, "logs")
+
+
+def test_speaker_conditioning_refusals():
+    import torch_tts_amd as T
+
+    fl = T.vits2.ResidualCouplingTransformersBlock(16, 24, 5, 1, 3, n_flows=2, gin_channels=8, use_transformer_flows=True).cuda().eval()
+    x, mk = torch.zeros(2, 16, 9, device="cuda"), torch.ones(2, 1, 9, device="cuda")
+    with torch.no_grad():
+        with pytest.raises(NotImplementedError):
+            fl(x, mk, g=torch.zeros(2, 8, 9, device="cuda"), reverse=True)  # time-varying g
+        with pytest.raises(ValueError):
+            fl(x, mk, g=torch.zeros(2, 4, 1, device="cuda"), reverse=True)  # wrong width
+        plain = T.vits2.ResidualCouplingTransformersBlock(16, 24, 5, 1, 3, n_flows=2, use_transformer_flows=True).cuda().eval()
+        with pytest.raises(ValueError):
+            plain(x, mk, g=torch.zeros(2, 8, 1, device="cuda"), reverse=True)  # g for a module built without gin_channels
+    with pytest.raises(AssertionError):
+        T.vits2.TextEncoder(11, 16, 32, 48, 2, 2, 3, 0.1, gin_channels=8)  # attentions.py:50-52: cond_layer_idx 2 needs 3 layers

@@ -78,3 +78,29 @@ def test_sequences_shorter_than_the_window(gv):
     for Ts in (1, 3):
         x, _, _, _ = V.text_encoder(c[f"short{Ts}/ids"], c[f"short{Ts}/lengths"], gv["wts"], d)
         close(x, c[f"short{Ts}/x"])
+
+
+def test_speaker_conditioning_matches_models_py(gv):
+    """gin_channels > 0: g [B, gin, 1] through WN.cond_layer (modules.py:189-199) and the text encoder's spk_emb_linear
+    (attentions.py:80-84); the vectors are outputs of models.TextEncoder / ResidualCouplingTransformersBlock themselves."""
+    z = np.load(os.path.join(HERE, "golden", "vits2_small.npz"))
+    wg = {k[3:]: torch.from_numpy(z[k]) for k in z.files if k.startswith("wg/")}
+    c, dg = gv["c"], V.Vits2Dims(**gv["meta"]["dims_g"])
+    assert dg.gin_channels == 8 and dg.cond_layer_idx == 2 and dg.n_layers == 3
+    g = c["g/spk"]
+    x, m, logs, _ = V.text_encoder(c["te/ids"], c["te/lengths"], wg, dg, g=g)
+    close(x, c["g/te/x"], 5e-6); close(m, c["g/te/m"], 5e-6); close(logs, c["g/te/logs"], 5e-6)
+    x0, _, _, _ = V.text_encoder(c["te/ids"], c["te/lengths"], wg, dg, g=None)
+    close(x0, c["g/te/x_no_g"], 5e-6)
+    ymask = V.sequence_mask(c["flow/lengths"], 17).unsqueeze(1).float()
+    close(V.flow_reverse(c["flow/z"], ymask, wg, dg, g=g), c["g/flow/out"], 5e-6)
+    close(V.flow_reverse(c["flow/z"], ymask, wg, dg, g=None), c["g/flow/out_no_g"], 5e-6)
+    assert float((c["g/flow/out"] - c["g/flow/out_no_g"]).abs().max()) > 1e-2  # (the conditioning is not a no-op in the fixture)
+    # random weights cover the conditioned keys too
+    d2 = V.Vits2Dims(n_vocab=11, inter_channels=8, hidden_channels=16, filter_channels=24, n_layers=3, flow_hidden=8, flow_wn_layers=2, n_flows=2,
+                     gin_channels=4)
+    w2 = V.random_vits2_weights(d2, seed=3)
+    out = V.flow_reverse(torch.randn(2, 8, 12), V.sequence_mask(torch.tensor([12, 5]), 12).unsqueeze(1).float(), w2, d2, g=torch.randn(2, 4, 1))
+    assert bool(torch.isfinite(out).all())
+    xx, _, _, _ = V.text_encoder(torch.randint(0, 11, (2, 9)), torch.tensor([9, 4]), w2, d2, g=torch.randn(2, 4, 1))
+    assert bool(torch.isfinite(xx).all())

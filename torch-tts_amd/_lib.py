@@ -115,7 +115,7 @@ class EncDims(C.Structure):
 class VitsDims(C.Structure):
     _fields_ = [(n, C.c_int32) for n in (
         "n_vocab", "inter_channels", "hidden_channels", "filter_channels", "n_heads", "n_layers", "kernel_size", "window_size",
-        "flow_hidden", "flow_kernel", "flow_wn_layers", "n_flows", "flow_tf_layers", "flow_tf_heads", "flow_tf_kernel")]
+        "flow_hidden", "flow_kernel", "flow_wn_layers", "n_flows", "flow_tf_layers", "flow_tf_heads", "flow_tf_kernel", "gin_channels", "cond_layer_idx")]
 
 
 class TtsdecError(RuntimeError):
@@ -254,11 +254,11 @@ def load() -> C.CDLL:
         lib.ttsvits_text_encoder_workspace_bytes.restype = sz
         lib.ttsvits_text_encoder_workspace_bytes.argtypes = [vp, i32, i32]
         lib.ttsvits_text_encoder.restype = i32
-        lib.ttsvits_text_encoder.argtypes = [vp, vp, vp, i32, i32, vp, vp, vp, vp, sz, vp, vp]
+        lib.ttsvits_text_encoder.argtypes = [vp, vp, vp, vp, i32, i32, vp, vp, vp, vp, sz, vp, vp]
         lib.ttsvits_flow_workspace_bytes.restype = sz
         lib.ttsvits_flow_workspace_bytes.argtypes = [vp, i32, i32]
         lib.ttsvits_flow_reverse.restype = i32
-        lib.ttsvits_flow_reverse.argtypes = [vp, vp, vp, i32, i32, vp, vp, sz, vp]
+        lib.ttsvits_flow_reverse.argtypes = [vp, vp, vp, vp, i32, i32, vp, vp, sz, vp]
         _lib = lib
         return _lib
 

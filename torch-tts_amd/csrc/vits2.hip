@@ -35,9 +35,11 @@ struct StackDims {
 struct FlowBlob {
   StackBlob tf;
   size_t pre_w, pre_b, in_w[kMaxWn], in_b[kMaxWn], rs_w[kMaxWn], rs_b[kMaxWn], post_w, post_b;
+  size_t cond_w, cond_b;  // WN.cond_layer (gin_channels > 0): [2 Fh n_layers, gin], [2 Fh n_layers]
 };
 struct VitsBlob {  // offsets in floats
   size_t emb;
+  size_t spk_w, spk_b;  // encoder.spk_emb_linear (gin_channels > 0): [hidden, gin], [hidden]
   StackBlob enc;
   size_t proj_w, proj_b;
   FlowBlob flow[kMaxFlows];
@@ -81,12 +83,14 @@ VitsBlob make_layout(const ttsvits_dims& d) {
   };
   const size_t H = d.hidden_channels, I = d.inter_channels, half = I / 2, Fh = d.flow_hidden;
   L.emb = take((size_t)d.n_vocab * H);
+  if (d.gin_channels > 0) { L.spk_w = take_w(H * d.gin_channels); L.spk_b = take(H); }
   stack(L.enc, enc_dims(d));
   L.proj_w = take_w(2 * I * H); L.proj_b = take(2 * I);
   for (int f = 0; f < d.n_flows; ++f) {
     FlowBlob& fb = L.flow[f];
     stack(fb.tf, tf_dims(d));
     fb.pre_w = take_w(Fh * half); fb.pre_b = take(Fh);
+    if (d.gin_channels > 0) { fb.cond_w = take_w(2 * Fh * d.flow_wn_layers * d.gin_channels); fb.cond_b = take(2 * Fh * d.flow_wn_layers); }
     for (int j = 0; j < d.flow_wn_layers; ++j) {
       const size_t cr = j < d.flow_wn_layers - 1 ? 2 * Fh : Fh;
       fb.in_w[j] = take_w(2 * Fh * d.flow_kernel * Fh); fb.in_b[j] = take(2 * Fh);
@@ -99,8 +103,11 @@ VitsBlob make_layout(const ttsvits_dims& d) {
 }
 
 int n_stack_tensors(const StackDims& sd) { return sd.layers * (sd.window >= 0 ? 18 : 16); }
-int n_text_tensors(const ttsvits_dims& d) { return 1 + n_stack_tensors(enc_dims(d)) + 2; }
-int n_flow_tensors(const ttsvits_dims& d) { return d.n_flows * (n_stack_tensors(tf_dims(d)) + 2 + 4 * d.flow_wn_layers + 2); }
+int n_cond_tensors(const ttsvits_dims& d) { return d.gin_channels > 0 ? 2 : 0; }
+int n_text_tensors(const ttsvits_dims& d) { return 1 + n_cond_tensors(d) + n_stack_tensors(enc_dims(d)) + 2; }
+int n_flow_tensors(const ttsvits_dims& d) {
+  return d.n_flows * (n_stack_tensors(tf_dims(d)) + 2 + n_cond_tensors(d) + 4 * d.flow_wn_layers + 2);
+}
 
 int vits_fail(ttsvits_handle* h, const char* where) {
   hipError_t e = hipGetLastError();
@@ -893,12 +900,24 @@ __global__ __launch_bounds__(kFaThreads, 2) void mha_flash_kernel(MhaArgs g) {
   }
 }
 
+// attentions.Encoder.forward:80-84: at layer cond_layer_idx, x = (x + spk_emb_linear(g)) * x_mask with g [B, gin, 1] broadcast over
+// the frames; gvec [B, C] is the projected embedding.  In place on the layer's input (and its split planes).
+__global__ void add_spk_kernel(float* x, f16* x_p, const float* gvec, const float* mask, int M, int C, int T) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= (size_t)M * C) return;
+  const size_t m = i / C, c = i % C;
+  const float v = mul_rn(add_rn(x[i], gvec[(m / T) * C + c]), mask[m]);
+  x[i] = v;
+  if (x_p) split_f16(v, x_p[i], x_p[(size_t)M * C + i]);
+}
+
 // commons.fused_add_tanh_sigmoid_multiply with g = None (commons.py:102-109): [M, 2H] -> [M, H]
-__global__ void wn_gate_kernel(const float* xin, float* acts, f16* acts_p, int M, int H) {
+__global__ void wn_gate_kernel(const float* xin, float* acts, f16* acts_p, int M, int H, const float* gl, int T, int ldg) {
   const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= (size_t)M * H) return;
   const size_t m = i / H, c = i % H;
-  const float a = xin[m * 2 * H + c], s = xin[m * 2 * H + H + c];
+  float a = xin[m * 2 * H + c], s = xin[m * 2 * H + H + c];
+  if (gl != nullptr) { a = add_rn(a, gl[(m / T) * ldg + c]); s = add_rn(s, gl[(m / T) * ldg + H + c]); }
   const float v = mul_rn(tanhf(a), sigmoid_f(s));
   acts[i] = v;
   if (acts_p) split_f16(v, acts_p[i], acts_p[(size_t)M * H + i]);
@@ -942,13 +961,21 @@ __device__ __forceinline__ void split4_store(const f32x4& v, f16* planes, size_t
   *reinterpret_cast<f16x4v*>(planes + 4 * i4) = hi;
   *reinterpret_cast<f16x4v*>(planes + n + 4 * i4) = lo;
 }
+// (gl != nullptr: g_l of modules.py:193-199, the speaker conditioning of this WN layer - constant over an utterance's frames, so a
+// [B, ldg] matrix whose row is the frame's utterance; the reference adds it to x_in before the two activations, commons.py:102-109)
 template <bool kFast>
-__global__ void wn_gate4_kernel(const float* xin, float* acts, f16* acts_p, uint32_t M, uint32_t H4) {
+__global__ void wn_gate4_kernel(const float* xin, float* acts, f16* acts_p, uint32_t M, uint32_t H4, const float* gl, uint32_t T, uint32_t ldg) {
   const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= M * H4) return;
   const uint32_t m = i / H4, c4 = i - m * H4;
   const f32x4* row = reinterpret_cast<const f32x4*>(xin) + (size_t)m * 2 * H4;
-  const f32x4 a = row[c4], s = row[H4 + c4];
+  f32x4 a = row[c4], s = row[H4 + c4];
+  if (gl != nullptr) {
+    const f32x4* grow = reinterpret_cast<const f32x4*>(gl + (size_t)(m / T) * ldg);
+    const f32x4 ga = grow[c4], gs = grow[H4 + c4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) { a[e] = add_rn(a[e], ga[e]); s[e] = add_rn(s[e], gs[e]); }
+  }
   f32x4 v;
 #pragma unroll
   for (int e = 0; e < 4; ++e) v[e] = kFast ? mul_rn(tanh_fast(a[e]), sigmoid_fast(s[e])) : mul_rn(tanhf(a[e]), sigmoid_f(s[e]));
@@ -1127,8 +1154,9 @@ constexpr size_t kMhaMaxLds = 150 * 1024;
 
 // attentions.Encoder.forward (attentions.py:76-93), eval mode.  Input: sw.x = sw.xm = x * mask.
 // Result: sw.xm (= x * mask of the last layer).
+// gvec / cond_idx: the text encoder's speaker conditioning (add_spk_kernel), nullptr / -1 without.
 int run_stack(ttsvits_handle* h, const StackBlob& sb, const StackDims& sd, const StackWs& sw, const float* mask, int B, int T,
-              hipStream_t st) {
+              hipStream_t st, const float* gvec = nullptr, int cond_idx = -1) {
   const float* blob = h->blob;
   const int M = B * T, C = sd.C, dk = C / sd.heads;
   // matrix-core attention when the score tile fits LDS (T <= ~1150) and dk is one of the built sizes;
@@ -1148,8 +1176,10 @@ int run_stack(ttsvits_handle* h, const StackBlob& sb, const StackDims& sd, const
     return vits_fail(h, "hipFuncSetAttribute(mha kernel)");
   const float* xin = sw.xm;  // layer 0 attends over x * mask; later layers over the unmasked LayerNorm output
   for (int i = 0; i < sd.layers; ++i) {
-    const float* xa = i == 0 ? sw.xm : sw.x;
-    const f16* xa_p = i == 0 ? sw.xm_p : sw.x_p;
+    float* xa = i == 0 ? sw.xm : sw.x;
+    f16* xa_p = i == 0 ? sw.xm_p : sw.x_p;
+    if (gvec != nullptr && i == cond_idx)
+      hipLaunchKernelGGL(add_spk_kernel, grid1((size_t)M * C), dim3(256), 0, st, xa, sw.cx.split ? xa_p : nullptr, gvec, mask, M, C, T);
     gemm_generic(sw.cx, xa, xa_p, C, C, blob + sb.wqkv[i], (size_t)3 * C * C, blob + sb.bqkv[i], M, 3 * C, sw.qkv, nullptr, 3 * C, 0, nullptr,
                  nullptr, 1, T, st);
     MhaArgs a;
@@ -1253,6 +1283,9 @@ bool dims_ok(const ttsvits_dims& d) {
   if (!(d.kernel_size & 1) || !(d.flow_kernel & 1) || !(d.flow_tf_kernel & 1) || d.kernel_size < 1 || d.flow_kernel < 1 || d.flow_tf_kernel < 1)
     return false;
   if (d.window_size > 64 || d.hidden_channels > 1024 || d.inter_channels > 2048) return false;
+  if (d.gin_channels < 0 || (d.gin_channels & 3) || d.gin_channels > 4096) return false;
+  // attentions.py:50-52 asserts cond_layer_idx < n_layers when the encoder is speaker-conditioned
+  if (d.gin_channels > 0 && d.n_layers > 0 && (d.cond_layer_idx < 0 || d.cond_layer_idx >= d.n_layers)) return false;
   return true;
 }
 
@@ -1302,6 +1335,11 @@ int ttsvits_pack_weights(ttsvits_handle* h, const float* const* src, int n_src, 
   // (launch_copy / launch_conv_transpose skip NULL sources: a module that owns only the text encoder
   // or only the flow packs what it has)
   launch_copy(src[k++], b + L.emb, (size_t)d.n_vocab * H, st);
+  if (d.gin_channels > 0) {
+    launch_copy(src[k++], b + L.spk_w, H * d.gin_channels, st);
+    launch_copy(src[k++], b + L.spk_b, H, st);
+    pack_planes(b, L.spk_w, H * d.gin_channels, st);
+  }
   pack_stack(src, k, b, L.enc, enc_dims(d), st);
   launch_copy(src[k++], b + L.proj_w, 2 * I * H, st);
   launch_copy(src[k++], b + L.proj_b, 2 * I, st);
@@ -1312,6 +1350,12 @@ int ttsvits_pack_weights(ttsvits_handle* h, const float* const* src, int n_src, 
     launch_copy(src[k++], b + fb.pre_w, Fh * half, st);
     launch_copy(src[k++], b + fb.pre_b, Fh, st);
     pack_planes(b, fb.pre_w, Fh * half, st);
+    if (d.gin_channels > 0) {
+      const size_t nc = 2 * Fh * d.flow_wn_layers;
+      launch_copy(src[k++], b + fb.cond_w, nc * d.gin_channels, st);
+      launch_copy(src[k++], b + fb.cond_b, nc, st);
+      pack_planes(b, fb.cond_w, nc * d.gin_channels, st);
+    }
     for (int j = 0; j < d.flow_wn_layers; ++j) {
       const size_t cr = j < d.flow_wn_layers - 1 ? 2 * Fh : Fh;
       if (src[k]) launch_conv_transpose(src[k], b + fb.in_w[j], (int)(2 * Fh), (int)Fh, d.flow_kernel, st);
@@ -1340,12 +1384,14 @@ int ttsvits_bind_weights(ttsvits_handle* h, const void* blob) {
 size_t ttsvits_text_encoder_workspace_bytes(const ttsvits_handle* h, int B, int T) {
   if (!h || B <= 0 || T <= 0) return 0;
   const size_t M = (size_t)B * T;
-  return (stack_ws_floats(enc_dims(h->d), M) + up(M, kAlign) + up(M * 2 * h->d.inter_channels, kAlign)) * sizeof(float);
+  return (stack_ws_floats(enc_dims(h->d), M) + up(M, kAlign) + up(M * 2 * h->d.inter_channels, kAlign) +
+          up((size_t)B * h->d.hidden_channels, kAlign)) * sizeof(float);
 }
 
-int ttsvits_text_encoder(ttsvits_handle* h, const int64_t* ids, const int32_t* lengths, int B, int T, float* x, float* m, float* logs,
-                         void* workspace, size_t workspace_bytes, void* stream, int32_t* status) {
+int ttsvits_text_encoder(ttsvits_handle* h, const int64_t* ids, const int32_t* lengths, const float* g, int B, int T, float* x, float* m,
+                         float* logs, void* workspace, size_t workspace_bytes, void* stream, int32_t* status) {
   if (!h || !ids || !lengths || !x || !m || !logs || !workspace || B <= 0 || T <= 0) return TTSDEC_ERR_INVALID_ARG;
+  if (g != nullptr && h->d.gin_channels <= 0) return TTSDEC_ERR_INVALID_ARG;
   if (!h->blob) return TTSDEC_ERR_NOT_BOUND;
   if (workspace_bytes < ttsvits_text_encoder_workspace_bytes(h, B, T) || (reinterpret_cast<uintptr_t>(workspace) & 255))
     return TTSDEC_ERR_WORKSPACE;
@@ -1358,11 +1404,17 @@ int ttsvits_text_encoder(ttsvits_handle* h, const int64_t* ids, const int32_t* l
   const StackDims sd = enc_dims(d);
   StackWs sw = carve_stack(p, sd, (size_t)M, h->precision == TTSDEC_PREC_SPLIT_F16);
   float* mask = p; p += up((size_t)M, kAlign);
-  float* stats = p;
+  float* stats = p; p += up((size_t)M * 2 * I, kAlign);
+  float* gvec = p;
+  GemmCtx exact;  // (the [B, gin] projections of g are a few KFLOP: always the exact fp32 instruction)
+  exact.planes = nullptr; exact.split = false;
+  if (g != nullptr)  // attentions.py:81: spk_emb_linear(g)
+    gemm_generic(exact, g, nullptr, d.gin_channels, d.gin_channels, h->blob + L.spk_w, (size_t)H * d.gin_channels, h->blob + L.spk_b, B, H, gvec,
+                 nullptr, H, 0, nullptr, nullptr, 1, 1, st);
   // models.py:370-376
   hipLaunchKernelGGL(embed_scale_kernel, grid1((size_t)M * H), dim3(256), 0, st, reinterpret_cast<const long long*>(ids), lengths,
                      h->blob + L.emb, d.n_vocab, T, H, sqrtf((float)H), sw.xm, sw.xm_p, mask, M, status);
-  int rc = run_stack(h, L.enc, sd, sw, mask, B, T, st);
+  int rc = run_stack(h, L.enc, sd, sw, mask, B, T, st, g != nullptr ? gvec : nullptr, d.cond_layer_idx);
   if (rc != TTSDEC_OK) return rc;
   // models.py:377-379: stats = proj(x) * x_mask; m, logs = split(stats)
   gemm_generic(sw.cx, sw.xm, sw.xm_p, H, H, h->blob + L.proj_w, (size_t)2 * I * H, h->blob + L.proj_b, M, 2 * I, stats, nullptr, 2 * I, 0, mask,
@@ -1381,13 +1433,15 @@ size_t ttsvits_flow_workspace_bytes(const ttsvits_handle* h, int B, int T) {
   if (!h || B <= 0 || T <= 0) return 0;
   const size_t M = (size_t)B * T, I = h->d.inter_channels, Fh = h->d.flow_hidden;
   const size_t fl = up(M, kAlign) + 2 * up(M * I, kAlign) + up(M * (I / 2), kAlign) + 2 * up(M * Fh, kAlign) + up(M * Fh, kAlign) +
-                    2 * up(M * 2 * Fh, kAlign) + up(M * (Fh > I / 2 ? Fh : I / 2), kAlign) + 3 * up(M * Fh, kAlign);
+                    2 * up(M * 2 * Fh, kAlign) + up(M * (Fh > I / 2 ? Fh : I / 2), kAlign) + 3 * up(M * Fh, kAlign) +
+                    up((size_t)B * 2 * Fh * h->d.flow_wn_layers, kAlign);
   return (stack_ws_floats(tf_dims(h->d), M) + fl) * sizeof(float);
 }
 
-int ttsvits_flow_reverse(ttsvits_handle* h, const float* z, const int32_t* lengths, int B, int T, float* out, void* workspace,
-                         size_t workspace_bytes, void* stream) {
+int ttsvits_flow_reverse(ttsvits_handle* h, const float* z, const int32_t* lengths, const float* g, int B, int T, float* out,
+                         void* workspace, size_t workspace_bytes, void* stream) {
   if (!h || !z || !lengths || !out || !workspace || B <= 0 || T <= 0) return TTSDEC_ERR_INVALID_ARG;
+  if (g != nullptr && h->d.gin_channels <= 0) return TTSDEC_ERR_INVALID_ARG;
   if (!h->blob) return TTSDEC_ERR_NOT_BOUND;
   if (workspace_bytes < ttsvits_flow_workspace_bytes(h, B, T) || (reinterpret_cast<uintptr_t>(workspace) & 255)) return TTSDEC_ERR_WORKSPACE;
   if (!device_is_current(h->device)) return TTSDEC_ERR_DEVICE;
@@ -1415,6 +1469,10 @@ int ttsvits_flow_reverse(ttsvits_handle* h, const float* z, const int32_t* lengt
   f16* hx_p = reinterpret_cast<f16*>(take((size_t)M * Fh));  // planes of hx / acts / ho, written by their producers
   f16* acts_p = reinterpret_cast<f16*>(take((size_t)M * Fh));
   f16* ho_p = reinterpret_cast<f16*>(take((size_t)M * Fh));
+  const int ncond = 2 * Fh * d.flow_wn_layers;
+  float* cond = take((size_t)B * ncond);  // WN.cond_layer(g) of the current coupling layer, [B, 2 Fh n_layers]
+  GemmCtx exact;
+  exact.planes = nullptr; exact.split = false;
   hipLaunchKernelGGL(frame_mask_kernel, grid1(M), dim3(256), 0, st, lengths, T, mask, M);
   const float* cur = z;
   for (int f = d.n_flows - 1; f >= 0; --f) {  // models.py:807-809: reversed(flows) = Flip, layer_f, ...
@@ -1429,15 +1487,19 @@ int ttsvits_flow_reverse(ttsvits_handle* h, const float* z, const int32_t* lengt
     else hipLaunchKernelGGL(add_x0_kernel, grid1((size_t)M * half), dim3(256), 0, st, sw.xm, sw.xm_p, xb, M, I);
     // h = pre(x0_) * mask                                                           :510
     gemm_generic(fcx, sw.xm, sw.xm_p, half, half, blob + fb.pre_w, (size_t)Fh * half, blob + fb.pre_b, M, Fh, hx, hx_p, Fh, 0, mask, nullptr, 1, T, st);
-    // h = WN(h, mask)                                                               :511, modules.py:185-210
+    // h = WN(h, mask, g)                                                            :511, modules.py:185-210
+    if (g != nullptr)  // g = cond_layer(g)  (modules.py:189-190; a 1x1 conv of [B, gin, 1]: one small GEMM per coupling layer)
+      gemm_generic(exact, g, nullptr, d.gin_channels, d.gin_channels, blob + fb.cond_w, (size_t)ncond * d.gin_channels, blob + fb.cond_b, B, ncond,
+                   cond, nullptr, ncond, 0, nullptr, nullptr, 1, 1, st);
     for (int j = 0; j < d.flow_wn_layers; ++j) {
+      const float* gl = g != nullptr ? cond + (size_t)j * 2 * Fh : nullptr;  // g_l = g[:, 2 Fh j : 2 Fh (j + 1)]      modules.py:194-196
       const bool last = j == d.flow_wn_layers - 1;
       gemm_generic(fcx, hx, hx_p, Fh, Fh, blob + fb.in_w[j], (size_t)2 * Fh * d.flow_kernel * Fh, blob + fb.in_b[j], M, 2 * Fh, xin, nullptr, 2 * Fh, 0,
                    nullptr, nullptr, d.flow_kernel, T, st);
       const bool vec4 = Fh % 4 == 0 && (size_t)M * Fh < ((size_t)1 << 32);
-      if (vec4 && fcx.split) hipLaunchKernelGGL(wn_gate4_kernel<true>, grid1((size_t)M * Fh / 4), dim3(256), 0, st, xin, acts, acts_p, (uint32_t)M, (uint32_t)Fh / 4);
-      else if (vec4) hipLaunchKernelGGL(wn_gate4_kernel<false>, grid1((size_t)M * Fh / 4), dim3(256), 0, st, xin, acts, acts_p, (uint32_t)M, (uint32_t)Fh / 4);
-      else hipLaunchKernelGGL(wn_gate_kernel, grid1((size_t)M * Fh), dim3(256), 0, st, xin, acts, acts_p, M, Fh);
+      if (vec4 && fcx.split) hipLaunchKernelGGL(wn_gate4_kernel<true>, grid1((size_t)M * Fh / 4), dim3(256), 0, st, xin, acts, acts_p, (uint32_t)M, (uint32_t)Fh / 4, gl, (uint32_t)T, (uint32_t)ncond);
+      else if (vec4) hipLaunchKernelGGL(wn_gate4_kernel<false>, grid1((size_t)M * Fh / 4), dim3(256), 0, st, xin, acts, acts_p, (uint32_t)M, (uint32_t)Fh / 4, gl, (uint32_t)T, (uint32_t)ncond);
+      else hipLaunchKernelGGL(wn_gate_kernel, grid1((size_t)M * Fh), dim3(256), 0, st, xin, acts, acts_p, M, Fh, gl, T, ncond);
       const int cr = last ? Fh : 2 * Fh;
       gemm_generic(fcx, acts, acts_p, Fh, Fh, blob + fb.rs_w[j], (size_t)cr * Fh, blob + fb.rs_b[j], M, cr, rs, nullptr, cr, 0, nullptr, nullptr, 1, T, st);
       if (vec4) hipLaunchKernelGGL(wn_update4_kernel, grid1((size_t)M * Fh / 4), dim3(256), 0, st, hx, ho, rs, mask, hx_p, ho_p, (uint32_t)M, (uint32_t)Fh / 4, last ? 1 : 0, j == 0 ? 1 : 0);

@@ -60,10 +60,15 @@ class Encoder(nn.Module):
 
     def __init__(self, hidden_channels, filter_channels, n_heads, n_layers, kernel_size=1, p_dropout=0.0, window_size=4, **kwargs):
         super().__init__()
-        if kwargs.get("gin_channels", 0):
-            raise NotImplementedError("speaker-conditioned encoder (gin_channels != 0) is outside the HIP path")
         self.hidden_channels, self.filter_channels, self.n_heads = hidden_channels, filter_channels, n_heads
         self.n_layers, self.kernel_size, self.window_size = n_layers, kernel_size, window_size
+        # attentions.py:41-52: a speaker-conditioned encoder adds spk_emb_linear(g) to the input of layer cond_layer_idx (2 unless given)
+        self.gin_channels = int(kwargs.get("gin_channels", 0) or 0)
+        self.cond_layer_idx = n_layers
+        if self.gin_channels:
+            self.spk_emb_linear = nn.Linear(self.gin_channels, hidden_channels)
+            self.cond_layer_idx = kwargs.get("cond_layer_idx", 2)
+            assert self.cond_layer_idx < n_layers, "cond_layer_idx should be less than n_layers"
         self.attn_layers = nn.ModuleList(_MultiHeadAttention(hidden_channels, hidden_channels, n_heads, window_size=window_size) for _ in range(n_layers))
         self.norm_layers_1 = nn.ModuleList(_LayerNorm(hidden_channels) for _ in range(n_layers))
         self.ffn_layers = nn.ModuleList(_FFN(hidden_channels, hidden_channels, filter_channels, kernel_size) for _ in range(n_layers))
@@ -87,7 +92,9 @@ class VitsEngine:
     def __init__(self, dims: Dict[str, int], device: torch.device):
         self._lib = _lib.load()
         self.device = device
-        self.dims = dict(dims)
+        self.dims = dict(gin_channels=0, cond_layer_idx=0)
+        self.dims.update(dims)
+        dims = self.dims
         h = C.c_void_p()
         d = _lib.VitsDims(*[int(dims[n]) for n, _ in _lib.VitsDims._fields_])
         with torch.cuda.device(device):  # the handle binds to the device current at create
@@ -158,9 +165,26 @@ class VitsEngine:
             self._ws[kind] = ws
         return ws
 
-    def text_encoder(self, ids: torch.Tensor, lengths: torch.Tensor):
+    def _speaker(self, g: Optional[torch.Tensor], B: int) -> Optional[torch.Tensor]:
+        """g as the C ABI takes it: [B, gin] fp32 from the reference's [B, gin, 1] (models.py: g = emb_g(sid).unsqueeze(-1))."""
+        if g is None:
+            return None
+        gin = self.dims["gin_channels"]
+        if not gin:
+            raise ValueError("g was given to a module built with gin_channels = 0")
+        _require_device(g, "g")
+        if g.dim() == 3:
+            if g.shape[2] != 1:
+                raise NotImplementedError("a time-varying g [B, gin, T] is outside the HIP path (the reference's callers pass [B, gin, 1])")
+            g = g[:, :, 0]
+        if tuple(g.shape) != (B, gin):
+            raise ValueError(f"g must be [B, gin_channels(, 1)] = [{B}, {gin}(, 1)], got {tuple(g.shape)}")
+        return g.to(torch.float32).contiguous()
+
+    def text_encoder(self, ids: torch.Tensor, lengths: torch.Tensor, g: Optional[torch.Tensor] = None):
         _require_device(ids, "ids")
         B, T = ids.shape
+        g = self._speaker(g, B)
         ids = ids.to(torch.int64).contiguous()
         self.status.zero_()
         lens = lengths.to(device=self.device, dtype=torch.int32).contiguous()
@@ -170,7 +194,8 @@ class VitsEngine:
         logs = torch.empty(B, T, I, device=self.device)
         ws = self._workspace("te", self._lib.ttsvits_text_encoder_workspace_bytes(self._h, B, T))
         with torch.cuda.device(self.device):
-            rc = self._lib.ttsvits_text_encoder(self._h, ids.data_ptr(), lens.data_ptr(), B, T, x.data_ptr(), m.data_ptr(), logs.data_ptr(),
+            rc = self._lib.ttsvits_text_encoder(self._h, ids.data_ptr(), lens.data_ptr(), g.data_ptr() if g is not None else None, B, T,
+                                                x.data_ptr(), m.data_ptr(), logs.data_ptr(),
                                                 ws.data_ptr(), ws.numel(), _stream(self.device), self.status.data_ptr())
         self._err(rc, "ttsvits_text_encoder")
         # nn.Embedding raises IndexError on an id outside the table (models.py:370): the kernel clamps and reports through the status
@@ -179,16 +204,18 @@ class VitsEngine:
             raise IndexError(f"token id out of range [0, {self.dims['n_vocab']}) in the text encoder's input")
         return x, m, logs
 
-    def flow_reverse(self, z_cl: torch.Tensor, lengths: torch.Tensor) -> torch.Tensor:
+    def flow_reverse(self, z_cl: torch.Tensor, lengths: torch.Tensor, g: Optional[torch.Tensor] = None) -> torch.Tensor:
         """z_cl [B, T, inter] channel-last."""
         _require_device(z_cl, "z")
         B, T, _ = z_cl.shape
+        g = self._speaker(g, B)
         z_cl = z_cl.to(torch.float32).contiguous()
         lens = lengths.to(device=self.device, dtype=torch.int32).contiguous()
         out = torch.empty_like(z_cl)
         ws = self._workspace("flow", self._lib.ttsvits_flow_workspace_bytes(self._h, B, T))
         with torch.cuda.device(self.device):
-            rc = self._lib.ttsvits_flow_reverse(self._h, z_cl.data_ptr(), lens.data_ptr(), B, T, out.data_ptr(), ws.data_ptr(), ws.numel(),
+            rc = self._lib.ttsvits_flow_reverse(self._h, z_cl.data_ptr(), lens.data_ptr(), g.data_ptr() if g is not None else None, B, T,
+                                                out.data_ptr(), ws.data_ptr(), ws.numel(),
                                                 _stream(self.device))
         self._err(rc, "ttsvits_flow_reverse")
         return out
@@ -223,32 +250,30 @@ class TextEncoder(PackedWeightsMixin, nn.Module):
     def __init__(self, n_vocab, out_channels, hidden_channels, filter_channels, n_heads, n_layers, kernel_size, p_dropout, gin_channels=0):
         super().__init__()
         self._watch_state_dict_loads()
-        if gin_channels:
-            raise NotImplementedError("speaker-conditioned text encoder is outside the HIP path")
         self.n_vocab, self.out_channels, self.hidden_channels, self.filter_channels = n_vocab, out_channels, hidden_channels, filter_channels
         self.n_heads, self.n_layers, self.kernel_size, self.p_dropout, self.gin_channels = n_heads, n_layers, kernel_size, p_dropout, gin_channels
         self.emb = nn.Embedding(n_vocab, hidden_channels)
         nn.init.normal_(self.emb.weight, 0.0, hidden_channels**-0.5)
-        self.encoder = Encoder(hidden_channels, filter_channels, n_heads, n_layers, kernel_size, p_dropout)
+        self.encoder = Encoder(hidden_channels, filter_channels, n_heads, n_layers, kernel_size, p_dropout, gin_channels=gin_channels)  # models.py:358-366
         self.proj = nn.Conv1d(hidden_channels, out_channels * 2, 1)
         self.precision = "split_f16"  # arithmetic of the GEMMs: "split_f16" (fp32-class, default) or "f32" (exact)
         self._engines = _EngCache()
 
     def _dims(self):
         d = dict(n_vocab=self.n_vocab, inter_channels=self.out_channels, hidden_channels=self.hidden_channels, filter_channels=self.filter_channels,
-                 n_heads=self.n_heads, n_layers=self.n_layers, kernel_size=self.kernel_size, window_size=self.encoder.window_size)
+                 n_heads=self.n_heads, n_layers=self.n_layers, kernel_size=self.kernel_size, window_size=self.encoder.window_size,
+                 gin_channels=self.gin_channels, cond_layer_idx=self.encoder.cond_layer_idx if self.gin_channels else 0)
         d.update(_DEFAULT_FLOW)
         return d
 
     def forward(self, x, x_lengths, g=None):
-        if g is not None:
-            raise NotImplementedError("g (speaker embedding) is outside the HIP path")
         if torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters()):
             raise NotImplementedError("the HIP text encoder is inference-only: call under torch.no_grad()")
         eng = self._engines.get(self._dims(), x.device)
         eng.set_precision(self.precision)
-        eng.ensure_packed([self.emb.weight] + self.encoder.weight_tensors() + [self.proj.weight, self.proj.bias])
-        xo, m, logs = eng.text_encoder(x, x_lengths)
+        spk = [self.encoder.spk_emb_linear.weight, self.encoder.spk_emb_linear.bias] if self.gin_channels else []
+        eng.ensure_packed([self.emb.weight] + spk + self.encoder.weight_tensors() + [self.proj.weight, self.proj.bias])
+        xo, m, logs = eng.text_encoder(x, x_lengths, g)
         T = x.shape[1]
         x_mask = (torch.arange(T, device=x.device)[None, :] < x_lengths.to(x.device)[:, None]).unsqueeze(1).to(xo.dtype)
         return xo.transpose(1, 2), m.transpose(1, 2), logs.transpose(1, 2), x_mask
@@ -259,10 +284,12 @@ class _WN(nn.Module):
 
     def __init__(self, hidden_channels, kernel_size, dilation_rate, n_layers, gin_channels=0, p_dropout=0):
         super().__init__()
-        if gin_channels or dilation_rate != 1:
-            raise NotImplementedError("WN with speaker conditioning or dilation_rate != 1 is outside the HIP path")
-        self.hidden_channels, self.n_layers, self.kernel = hidden_channels, n_layers, kernel_size
+        if dilation_rate != 1:
+            raise NotImplementedError("WN with dilation_rate != 1 is outside the HIP path")
+        self.hidden_channels, self.n_layers, self.kernel, self.gin_channels = hidden_channels, n_layers, kernel_size, gin_channels
         self.in_layers, self.res_skip_layers = nn.ModuleList(), nn.ModuleList()
+        if gin_channels != 0:  # modules.py:149-153
+            self.cond_layer = nn.utils.weight_norm(nn.Conv1d(gin_channels, 2 * hidden_channels * n_layers, 1), name="weight")
         for i in range(n_layers):
             self.in_layers.append(nn.utils.weight_norm(nn.Conv1d(hidden_channels, 2 * hidden_channels, kernel_size, padding=(kernel_size - 1) // 2), name="weight"))
             rs = 2 * hidden_channels if i < n_layers - 1 else hidden_channels
@@ -270,6 +297,8 @@ class _WN(nn.Module):
 
     def weight_tensors(self):
         out = []
+        if self.gin_channels != 0:
+            out += [torch._weight_norm(self.cond_layer.weight_v, self.cond_layer.weight_g, 0), self.cond_layer.bias]
         for i in range(self.n_layers):
             for l in (self.in_layers[i], self.res_skip_layers[i]):
                 w = torch._weight_norm(l.weight_v, l.weight_g, 0)  # effective weight g * v / ||v||
@@ -310,6 +339,7 @@ class ResidualCouplingTransformersBlock(PackedWeightsMixin, nn.Module):
         if not use_transformer_flows or transformer_flow_type != "pre_conv":
             raise NotImplementedError("only use_transformer_flows=True with transformer_flow_type='pre_conv' (the ModelConfig default) is built")
         self.channels, self.hidden_channels, self.kernel_size, self.n_layers, self.n_flows = channels, hidden_channels, kernel_size, n_layers, n_flows
+        self.gin_channels = gin_channels
         self.flows = nn.ModuleList()
         for _ in range(n_flows):
             self.flows.append(ResidualCouplingTransformersLayer(channels, hidden_channels, kernel_size, dilation_rate, n_layers,
@@ -321,23 +351,24 @@ class ResidualCouplingTransformersBlock(PackedWeightsMixin, nn.Module):
     def _dims(self):
         return dict(n_vocab=1, inter_channels=self.channels, hidden_channels=4, filter_channels=4, n_heads=1, n_layers=0, kernel_size=1, window_size=0,
                     flow_hidden=self.hidden_channels, flow_kernel=self.kernel_size, flow_wn_layers=self.n_layers, n_flows=self.n_flows,
-                    flow_tf_layers=2, flow_tf_heads=2, flow_tf_kernel=3)
+                    flow_tf_layers=2, flow_tf_heads=2, flow_tf_kernel=3, gin_channels=self.gin_channels, cond_layer_idx=0)
 
     def forward(self, x, x_mask, g=None, reverse=False):
-        if not reverse or g is not None:
-            raise NotImplementedError("only the reverse (inference) direction without speaker conditioning is on the HIP path")
+        if not reverse:
+            raise NotImplementedError("only the reverse (inference) direction is on the HIP path")
         if torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters()):
             raise NotImplementedError("the HIP flow is inference-only: call under torch.no_grad()")
         eng = self._engines.get(self._dims(), x.device)
         eng.set_precision(self.precision)
 
         def tensors() -> List[Optional[torch.Tensor]]:
-            ts: List[Optional[torch.Tensor]] = [None] * 3  # emb, proj.weight, proj.bias of the (absent) text encoder
+            # emb, (spk_emb_linear.{weight,bias},) proj.weight, proj.bias of the (absent) text encoder
+            ts: List[Optional[torch.Tensor]] = [None] * (5 if self.gin_channels else 3)
             for i in range(self.n_flows):
                 ts += self.flows[2 * i].weight_tensors()  # (materialises the weight-normed conv weights)
             return ts
 
         eng.ensure_packed(tensors, key_tensors=list(self.parameters()))
         lengths = x_mask[:, 0, :].sum(dim=1).round().to(torch.int32)  # sequence_mask is a prefix mask
-        out = eng.flow_reverse(x.transpose(1, 2), lengths)
+        out = eng.flow_reverse(x.transpose(1, 2), lengths, g)
         return out.transpose(1, 2)
