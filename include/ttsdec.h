@@ -173,17 +173,22 @@ int ttsdec_get_precision(const ttsdec_handle* h);
  * TTSDEC_NO_LEAN_SKINNY=1 (short-K row GEMMs of the VITS2 path back on the 128 x 128 tile). */
 enum {
   TTSDEC_OPT_GRAPH = 0,        /* "graph": 0 = launch every step kernel from the host instead of replaying a captured hipGraph  */
-  TTSDEC_OPT_OVERLAP,          /* "overlap": two-role launches 0 = none, 1 = frame || lstm_att, 2 = also attention || lstm_dec  */
+  TTSDEC_OPT_OVERLAP,          /* "overlap": two-role launches 0 = none, 1 = frame || lstm_att, 2 = also attention || lstm_dec;
+                                * 3 = the whole step as ONE launch where it applies (split-fp16, projection head role and query
+                                * role on, 33..256 utterances; level 2 elsewhere).  Never the default: measured slower, DESIGN.md */
   TTSDEC_OPT_CHUNK_A,          /* "chunk_a": 0 = row-major fp16 activation planes instead of the chunked layout                */
   TTSDEC_OPT_CHUNK_B,          /* "chunk_b": 0 = row-major LSTM weight planes                                                  */
   TTSDEC_OPT_PROJ_REGW,        /* "proj_regw": 0 = mel/stop projection on the LDS-staged split-K GEMM                          */
   TTSDEC_OPT_HEAD_PROJ,        /* "head_proj": 1 / 0 = that projection as a role at the head of the next step's first launch   */
   TTSDEC_OPT_QUERY_ROLE,       /* "query_role": 1 / 0 = the attention query GEMM as a job of the attention role's workgroups
                                 * (overlap 2, at most 256 utterances) instead of a launch of its own                          */
+  TTSDEC_OPT_MERGED_TUNE,      /* "merged_tune": measurement knobs of the one-launch step (overlap = 3): bit 0 = the decoder LSTM waits for
+                                * h_att before its first tile, bit 1 = wave priority 2 / 0 for the attention / decoder LSTM roles,
+                                * bits 8-15 = extra sleeps between the query role's polls for h_att                              */
   TTSDEC_OPT_PROFILE_ABLATION, /* "profile_ablation": ttsdec_profile_step only, kernel-internal ablation switches              */
-  TTSDEC_OPT_DEBUG_FLAGS,      /* "debug_flags": TEST HOOK. bit 0 / 1 / 2: the frame / attention / projection-head role of a
-                                * two-role launch does not signal its consumers, which then run into the bounded-spin
-                                * time-out (T_out[1] bit 2)                                                                   */
+  TTSDEC_OPT_DEBUG_FLAGS,      /* "debug_flags": TEST HOOK. bit 0 / 1 / 2 / 3: the frame / attention / projection-head role of a
+                                * two-role launch / the attention LSTM's tiles of the one-launch step do not signal their
+                                * consumers, which then run into the bounded-spin time-out (T_out[1] bit 2)                   */
   TTSDEC_OPT_SPIN_LIMIT,       /* "spin_limit": TEST HOOK. polls before a consumer role gives up (default 65536, ~30 ms)       */
   TTSDEC_OPT_COUNT
 };

@@ -1106,6 +1106,8 @@ _STEP_OPTIONS = [
     {"head_proj": 1}, {"head_proj": 1, "overlap": 1}, {"head_proj": 1, "graph": 0},
     {"head_proj": 0},
     {"query_role": 0}, {"query_role": 1, "overlap": 2}, {"query_role": 1, "overlap": 2, "head_proj": 0, "graph": 0}, {"query_role": 1, "chunk_a": 0},
+    # the whole step as one launch (split-fp16, 33..256 utterances; elsewhere the option means level 2)
+    {"overlap": 3, "query_role": 1}, {"overlap": 3, "query_role": 1, "graph": 0}, {"overlap": 3, "query_role": 1, "chunk_a": 0, "chunk_b": 0},
 ]
 
 
@@ -1132,12 +1134,16 @@ def test_all_step_orders_and_layouts_vs_oracle(H, prec, monkeypatch):
                     from torch_tts_amd import _lib
                     names = set(eng.profile_step(mem.cuda(), 1, _lib.DROPOUT_OFF, None, 0))
                     lv = opt["overlap"]
-                    fa = "prenet+lstm_att" in names or "proj+prenet+lstm_att" in names
-                    assert fa == (lv >= 1) and any(n.endswith("attention+lstm_dec") for n in names) == (lv >= 2), (opt, names)
-                    if opt.get("query_role") == 1:
-                        assert "query+attention+lstm_dec" in names and "query" not in names, (opt, names)
-                    if opt.get("head_proj") == 1 and prec == "split_f16":
-                        assert "proj+prenet+lstm_att" in names and "proj" not in names, (opt, names)
+                    if lv == 3 and prec == "split_f16" and B > 32:
+                        assert names == {"step"}, (opt, names)
+                    else:
+                        assert "step" not in names, (opt, names)
+                        fa = "prenet+lstm_att" in names or "proj+prenet+lstm_att" in names
+                        assert fa == (lv >= 1) and any(n.endswith("attention+lstm_dec") for n in names) == (lv >= 2), (opt, names)
+                        if opt.get("query_role") == 1:
+                            assert "query+attention+lstm_dec" in names and "query" not in names, (opt, names)
+                        if opt.get("head_proj") == 1 and prec == "split_f16":
+                            assert "proj+prenet+lstm_att" in names and "proj" not in names, (opt, names)
             what = f"B={B} {prec} {opt}"
             assert not fired and y.shape == oy.shape, what
             H.assert_close(y, oy, RTOL, ATOL, "y " + what)
@@ -1186,13 +1192,15 @@ def test_role_timeout_flags_the_call_and_the_module_falls_back(H):
     ny, ns, nw = O.decode(wts, dims, mem, max_steps=T_ - 1, dropout="off")
     memd = mem.cuda()
     for prec in ("f32", "split_f16"):
-        for bit in (1, 2, 4):  # the frame role / the attention role / the projection head role stays silent
-            if bit == 4 and prec == "f32":
-                continue  # (the head role exists in split-fp16 mode only)
+        for bit in (1, 2, 4, 8):  # the frame role / the attention role / the projection head role / the attention LSTM's tiles stay silent
+            if bit >= 4 and prec == "f32":
+                continue  # (the head role and the one-launch step exist in split-fp16 mode only)
             dec = H.make_decoder(dims, wts)
             dec.precision = prec
             eng = dec.engine(torch.device("cuda:0"))
-            eng.set_option("overlap", 2)
+            eng.set_option("overlap", 3 if bit == 8 else 2)
+            if bit == 8:
+                eng.set_option("query_role", 1)
             eng.set_option("spin_limit", 64)
             eng.set_option("debug_flags", bit)
             y = torch.empty(B, T_, 80, device="cuda"); s = torch.empty(B, T_, device="cuda"); w = torch.empty(B, T_, 9, device="cuda")

@@ -1,12 +1,14 @@
 #!/usr/bin/env python3
 """Reads the stamp file written under TTSDEC_STAMPS (csrc/api.hip) and prints, per two-role launch of the last step:
-role placement over CUs and the start / gate / end times (us, relative to the launch's first start)."""
+role placement over CUs and the start / gate / end times (us, relative to the launch's first start).
+A second argument "merged": the one-launch step (option overlap = 3) - both role pairs are timed from the launch's first stamp."""
 import sys
 from collections import Counter
 
 import numpy as np
 
 a = np.fromfile(sys.argv[1], dtype=np.uint64).reshape(-1, 1024, 8)
+merged = len(sys.argv) > 2 and sys.argv[2] == "merged"
 t0_kind0 = None
 for kind, name in ((0, "frame || lstm_att"), (1, "attention || lstm_dec")):
     s = a[kind]
@@ -24,6 +26,8 @@ for kind, name in ((0, "frame || lstm_att"), (1, "attention || lstm_dec")):
         if a.shape[0] > 2 and (a[2][:, 2] > 0).any():
             t0 = min(t0, int(a[2][:, 2][a[2][:, 2] > 0].min()))  # the projection head role starts the launch
         t0_kind0 = t0
+    elif merged and t0_kind0 is not None:
+        t0 = t0_kind0
     us = lambda col: (s[:, col].astype(np.int64) - t0) / 100.0
     print(f"== {name}: {used.sum()} workgroups stamped")
     for r, rn in ((0, "producer"), (1, "lstm")):
@@ -38,10 +42,19 @@ for kind, name in ((0, "frame || lstm_att"), (1, "attention || lstm_dec")):
                 ok = s[:, col][m] > 0
                 if ok.any():
                     print(f"           {what:20s} {v[ok].min():6.2f}..{v[ok].max():6.2f} (mean {v[ok].mean():6.2f})")
+        if r == 0 and kind == 1 and merged:
+            v = us(6)[m]
+            ok = s[:, 6][m] > 0
+            if ok.any():
+                print(f"           role entry (before the query tiles) {v[ok].min():6.2f}..{v[ok].max():6.2f} (mean {v[ok].mean():6.2f})")
         if r == 1:
             gi, go = us(3)[m], us(4)[m]
             ok = s[:, 3][m] > 0
             print(f"           gate reached {gi[ok].min():6.2f}..{gi[ok].max():6.2f} (mean {gi[ok].mean():6.2f})  passed {go[ok].min():6.2f}..{go[ok].max():6.2f} (mean {go[ok].mean():6.2f})")
+            ok2 = s[:, 6][m] > 0
+            if kind == 1 and ok2.any():  # (one-launch step: the decoder LSTM's h_att segment)
+                g2i, g2o = us(6)[m], us(7)[m]
+                print(f"           h_att gate reached {g2i[ok2].min():6.2f}..{g2i[ok2].max():6.2f} (mean {g2i[ok2].mean():6.2f})  passed {g2o[ok2].min():6.2f}..{g2o[ok2].max():6.2f} (mean {g2o[ok2].mean():6.2f})")
     per_cu = Counter()
     for c, r in zip(cu, role):
         per_cu[(c, r)] += 1

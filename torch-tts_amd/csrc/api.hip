@@ -91,6 +91,7 @@ struct ttsdec_handle {
   bool proj_regw;         // mel/stop projection on the register-weight kernel where it applies (option "proj_regw")
   int opt_graph, opt_chunk_a, opt_chunk_b, opt_proj_regw;  // the options behind those four: -1 = default (on), 0, 1
   int head_proj;          // that projection as a role at the head of the NEXT step's frame launch: 1 / 0, -1 = by batch size; TTSDEC_HEAD_PROJ
+  int merged_tune;        // measurement: knobs of the one-launch step (include/ttsdec.h)
   int query_role;         // attention query as a job of the attention role's workgroups (step_order): 1 / 0, -1 = default
   int profile_ablation;   // ttsdec_profile_step only: the kernels' dbg switches (measurement ablations)
   int debug_flags;        // test hooks, copied into Ctrl::debug_flags: bit 0 = the frame role does not signal, bit 1 = the attention
@@ -363,7 +364,8 @@ struct StepIo {
 // N_AG / N_DG are those LSTMs alone on the lean tile (profiling).  N_JFA = N_FA with the PREVIOUS step's mel/stop projection as a
 // role at its head (then no N_J in the step), N_JFIN = the projection of a call's last step.
 // N_QTD = N_TD whose attention-role workgroups first compute the query GEMM between them (then no N_Q in the step).
-enum Node { N_F, N_FIN, N_P0, N_P1, N_A, N_Q, N_T, N_D, N_J, N_FA, N_TD, N_AG, N_DG, N_JFA, N_JFIN, N_QTD };
+// N_STEP = N_JFA + N_QTD as one launch.
+enum Node { N_F, N_FIN, N_P0, N_P1, N_A, N_Q, N_T, N_D, N_J, N_FA, N_TD, N_AG, N_DG, N_JFA, N_JFIN, N_QTD, N_STEP };
 // PART_GATED: the whole cell with the segment that waits for the other role of the launch LAST
 enum LstmPart { PART_WHOLE = 0, PART_EARLY = 1, PART_LATE = 2, PART_GATED = 3 };
 
@@ -380,6 +382,7 @@ bool split_ok(const ttsdec_dims& d) { return !((d.d_pre | d.d_ctx | d.h_att | d.
 const StepOrder& step_order(const ttsdec_handle* h, int B);
 bool head_proj(const ttsdec_handle* h, int B);
 bool query_role(const ttsdec_handle* h, int B);
+bool step_merged(const ttsdec_handle* h, int B);
 int& option_ref(ttsdec_handle* h, int o);
 void apply_env_options(ttsdec_handle* h);
 void drop_graph(ttsdec_handle* h);
@@ -487,10 +490,11 @@ void launch_node(const ttsdec_handle* h, const StepBufs& sb, const StepIo& io, N
       a.dep_cnt = dep(DEP_FRAME);
       a.live_lag = 1;  // (same launch as the frame kernel: see lstm_body)
     } else if (part == PART_GATED) {
-      // [h_att | h_dec | ctx]: ctx is written by the attention role of the same launch
-      a.a = act(make_seg3(x0, k0, k0, x2, H, H, x1, D, D)); a.a_lo = act(make_seg3(x0l, k0, k0, x2l, H, H, x1l, D, D));
-      a.w = make_seg3(W0(false), wld_ih, k0, W2(false), wld_hh, H, W1(false), wld_ih, D);
-      a.w_lo = make_seg3(W0(true), wld_ih, k0, W2(true), wld_hh, H, W1(true), wld_ih, D);
+      // [h_dec | h_att | ctx]: ctx is written by the attention role of the same launch; h_att second, so that the one-launch
+      // step (N_STEP), where it comes from the attention LSTM's tiles of the same launch, starts on the segment nobody is waited for
+      a.a = act(make_seg3(x2, H, H, x0, k0, k0, x1, D, D)); a.a_lo = act(make_seg3(x2l, H, H, x0l, k0, k0, x1l, D, D));
+      a.w = make_seg3(W2(false), wld_hh, H, W0(false), wld_ih, k0, W1(false), wld_ih, D);
+      a.w_lo = make_seg3(W2(true), wld_hh, H, W0(true), wld_ih, k0, W1(true), wld_ih, D);
       a.K = k0 + D + H;
       a.dep_n = 32; a.dep_rows = 1; a.dep_seg = 2; a.dep_which = 1;  // (one attention workgroup per batch row)
       a.dep_cnt = dep(DEP_ATTN);
@@ -529,6 +533,43 @@ void launch_node(const ttsdec_handle* h, const StepBufs& sb, const StepIo& io, N
     return a;
   };
 
+  // the attention query GEMM (decoder_cell.py:188 -> attention.py:105) as a job of the attention role's workgroups
+  auto query_role_args = [&]() {
+    ProjArgs pq;
+    memset(&pq, 0, sizeof(pq));
+    pq.prec = prec ? PREC_F16S : PREC_F32;
+    if (prec) {
+      pq.a = act(make_seg1(sb.h_att_h[1 - p], Ha, Ha)); pq.a_lo = act(make_seg1(sb.h_att_l[1 - p], Ha, Ha));
+      pq.W = plane(bl.wq_h); pq.W_lo = plane(bl.wq_l);
+    } else {
+      pq.a = make_seg1(sb.h_att[1 - p], Ha, Ha);
+      pq.W = blob + bl.wq;
+    }
+    pq.ldw = query_ld(d); pq.M = B; pq.N = D; pq.K = query_k(d); pq.ksplit = proj_split(pq.K);
+    pq.split_stride = (size_t)B * D; pq.out = sb.q; pq.ldo = D; pq.ctrl = ctrl; pq.slot = io.slot; pq.mode = PROJ_QUERY;
+    pq.dep_cnt = dep(DEP_QUERY);
+    return pq;
+  };
+  auto query_attn_args = [&](const ProjArgs& pq) {
+    AttnArgs a = attn_args();
+    a.dep_signal = 1; a.dep_cnt = dep(DEP_ATTN);
+    a.q_parts = pq.ksplit;
+    a.q_tiles = proj_grid_size(B, D, pq.ksplit); a.q_wait_n = proj_grid_size(32, D, pq.ksplit); a.q_cnt = pq.dep_cnt;
+    return a;
+  };
+  // the mel/stop projection on the register-weight kernel, split-fp16 Prod cell: cat[h_dec, ctx] of buffer parity 1 - pp
+  auto head_proj_args = [&](int pp, int mode) {
+    ProjArgs pa;
+    memset(&pa, 0, sizeof(pa));
+    pa.a = act(make_seg2(sb.h_dec_h[1 - pp], Hd, Hd, sb.ctx_h, D, D));
+    pa.a_lo = act(make_seg2(sb.h_dec_l[1 - pp], Hd, Hd, sb.ctx_l, D, D));
+    pa.W = plane(bl.proj_h); pa.W_lo = plane(bl.proj_l); pa.ldw = proj_ld(d); pa.prec = PREC_F16S;
+    pa.M = B; pa.N = proj_n(d); pa.K = proj_k(d); pa.ksplit = proj_parts(h, prec); pa.split_stride = (size_t)B * proj_ldp(d);
+    pa.out = sb.jparts; pa.ldo = proj_ldp(d); pa.ctrl = ctrl; pa.slot = io.slot; pa.node = io.node_pos;
+    pa.mode = mode;
+    return pa;
+  };
+
   switch (node) {
     case N_F:
     case N_FIN:
@@ -547,25 +588,34 @@ void launch_node(const ttsdec_handle* h, const StepBufs& sb, const StepIo& io, N
       break;
     }
     case N_QTD: {
-      // the query GEMM (decoder_cell.py:188 -> attention.py:105) as a job of the attention role's workgroups
-      ProjArgs pq;
-      memset(&pq, 0, sizeof(pq));
-      pq.prec = prec ? PREC_F16S : PREC_F32;
-      if (prec) {
-        pq.a = act(make_seg1(sb.h_att_h[1 - p], Ha, Ha)); pq.a_lo = act(make_seg1(sb.h_att_l[1 - p], Ha, Ha));
-        pq.W = plane(bl.wq_h); pq.W_lo = plane(bl.wq_l);
-      } else {
-        pq.a = make_seg1(sb.h_att[1 - p], Ha, Ha);
-        pq.W = blob + bl.wq;
-      }
-      pq.ldw = query_ld(d); pq.M = B; pq.N = D; pq.K = query_k(d); pq.ksplit = proj_split(pq.K);
-      pq.split_stride = (size_t)B * D; pq.out = sb.q; pq.ldo = D; pq.ctrl = ctrl; pq.slot = io.slot; pq.mode = PROJ_QUERY;
-      pq.dep_cnt = dep(DEP_QUERY);
-      AttnArgs a = attn_args();
-      a.dep_signal = 1; a.dep_cnt = dep(DEP_ATTN);
-      a.q_parts = pq.ksplit;
-      a.q_tiles = proj_grid_size(B, D, pq.ksplit); a.q_wait_n = proj_grid_size(32, D, pq.ksplit); a.q_cnt = pq.dep_cnt;
-      launch_attn_lstm(a, lstm_args(1, PART_GATED), &pq, st);
+      const ProjArgs pq = query_role_args();
+      launch_attn_lstm(query_attn_args(pq), lstm_args(1, PART_GATED), &pq, st);
+      break;
+    }
+    case N_STEP: {
+      // the whole step as one launch (fused_kernels.hip step_kernel): N_JFA's and N_QTD's roles, the boundary between the two
+      // launches replaced by the DEP_HATT hand-off; every role live by t - 1 <= stop_t
+      ProjArgs pa = head_proj_args(1 - p, PROJ_HEAD);
+      FrameArgs f = frame_args(false);
+      f.dep_signal = 1; f.dep_cnt = dep(DEP_FRAME);
+      pa.dep_cnt = f.wait_cnt = dep(DEP_PROJ);
+      f.wait_n = proj_grid_size(32, pa.N, pa.ksplit);
+      LstmArgs la = lstm_args(0, PART_GATED);
+      la.sig_cnt = dep(DEP_HATT);
+      const int bu = B <= 64 ? 8 : 16;  // (units per LSTM tile: fused_kernels.hip Lean64x8 / Lean64x16)
+      const int la_tiles = (Ha + bu - 1) / bu;  // attention-LSTM tiles per 32-row block and step
+      ProjArgs pq = query_role_args();
+      pq.wait_cnt = dep(DEP_HATT); pq.wait_n = la_tiles; pq.live_lag = 1;
+      AttnArgs a = query_attn_args(pq);
+      a.live_lag = 1;
+      LstmArgs ld = lstm_args(1, PART_GATED);
+      ld.live_lag = 1;
+      ld.dep2_seg = 1; ld.dep2_n = la_tiles; ld.dep2_cnt = dep(DEP_HATT);
+      const int tune = h->merged_tune > 0 ? h->merged_tune : 0;  // (measurement option)
+      if (tune & 1) ld.dep2_seg = 0;  // the decoder LSTM starts nothing before its rows' h_att is complete
+      f.dbg |= (tune & 0xff) << 8;
+      pq.wait_sleep = (tune >> 8) & 0xff;
+      launch_step_merged(pa, f, la, pq, a, ld, st);
       break;
     }
     case N_AG:
@@ -701,6 +751,8 @@ const StepOrder kOrderProdH2 = {3, {N_JFA, N_Q, N_TD}, {"proj+prenet+lstm_att", 
 // ... and with the query as a job of the attention role's workgroups: two launches per step
 const StepOrder kOrderProdO2Q = {3, {N_FA, N_QTD, N_J}, {"prenet+lstm_att", "query+attention+lstm_dec", "proj"}};
 const StepOrder kOrderProdH2Q = {2, {N_JFA, N_QTD}, {"proj+prenet+lstm_att", "query+attention+lstm_dec"}};
+// ... and the boundary between those two replaced by a hand-off: one launch per step
+const StepOrder kOrderProdS = {1, {N_STEP}, {"step"}};
 // the two-role step: LJSpeech-type cell, either arithmetic mode
 int overlap_level(const ttsdec_handle* h, int B) {
   const ttsdec_dims& d = h->d;
@@ -736,9 +788,16 @@ bool query_role(const ttsdec_handle* h, int B) {
   if (h->query_role > 0) return true;
   return lstm_prec(h) && B >= 64 && proj_grid_size(B, d.d_ctx, ps) <= B;
 }
+// The one-launch step (option overlap = 3): the configuration in which both two-role launches carry their extra roles - split-fp16
+// Prod cell, projection head role, query role - at batches the lean tiles take.
+bool step_merged(const ttsdec_handle* h, int B) {
+  if (overlap_level(h, B) < 3 || !lstm_prec(h)) return false;
+  return head_proj(h, B) && query_role(h, B) && step_merged_supported(B, h->d.h_att, h->d.h_dec);
+}
 const StepOrder& step_order(const ttsdec_handle* h, int B) {
   const ttsdec_dims& d = h->d;
   if (const int lv = overlap_level(h, B)) {
+    if (step_merged(h, B)) return kOrderProdS;
     if (lv >= 2 && query_role(h, B)) return head_proj(h, B) ? kOrderProdH2Q : kOrderProdO2Q;
     if (head_proj(h, B)) return lv >= 2 ? kOrderProdH2 : kOrderProdH;
     return lv >= 2 ? kOrderProdO2 : kOrderProdO;
@@ -809,7 +868,7 @@ int ensure_graph(ttsdec_handle* h, const StepBufs& sb, const void* ws, int B, in
 
 // ---- options (include/ttsdec.h TTSDEC_OPT_*) ----
 const char* const kOptionNames[TTSDEC_OPT_COUNT] = {"graph",     "overlap",    "chunk_a",          "chunk_b",     "proj_regw",
-                                                    "head_proj", "query_role", "profile_ablation", "debug_flags", "spin_limit"};
+                                                    "head_proj", "query_role", "merged_tune", "profile_ablation", "debug_flags", "spin_limit"};
 int& option_ref(ttsdec_handle* h, int o) {
   switch (o) {
     case TTSDEC_OPT_OVERLAP: return h->overlap;
@@ -818,6 +877,7 @@ int& option_ref(ttsdec_handle* h, int o) {
     case TTSDEC_OPT_PROJ_REGW: return h->opt_proj_regw;
     case TTSDEC_OPT_HEAD_PROJ: return h->head_proj;
     case TTSDEC_OPT_QUERY_ROLE: return h->query_role;
+    case TTSDEC_OPT_MERGED_TUNE: return h->merged_tune;
     case TTSDEC_OPT_PROFILE_ABLATION: return h->profile_ablation;
     case TTSDEC_OPT_DEBUG_FLAGS: return h->debug_flags;
     case TTSDEC_OPT_SPIN_LIMIT: return h->spin_limit;
@@ -898,7 +958,7 @@ int ttsdec_create(const ttsdec_dims* dims, ttsdec_handle** out) {
   // measured SLOWER on MI355X - 126 vs 96 us per step at B=256: the early GEMM's 256 workgroups hold every CU's LDS, so
   // the small kernels queue behind them - and was removed; see DESIGN.md.)
   for (int o = 0; o < TTSDEC_OPT_COUNT; ++o) option_ref(h, o) = -1;
-  h->profile_ablation = 0; h->debug_flags = 0; h->spin_limit = 0;
+  h->profile_ablation = 0; h->debug_flags = 0; h->spin_limit = 0; h->merged_tune = 0;
   apply_env_options(h);
   h->device = current_device_or_minus1();
   *out = h;

@@ -45,7 +45,8 @@ struct Ctrl {
   // measurement only (TTSDEC_STAMPS=1): per-workgroup wall-clock stamps of the two-role launches, else nullptr
   unsigned long long* stamps;
   // test hooks (include/ttsdec.h TTSDEC_OPT_DEBUG_FLAGS / _SPIN_LIMIT): bit 0 = the frame role does not signal, bit 1 = the
-  // attention role does not, bit 2 = the projection head role does not; polls before role_wait gives up
+  // attention role does not, bit 2 = the projection head role does not, bit 3 = the attention LSTM's tiles (one-launch step) do
+  // not; polls before role_wait gives up
   int debug_flags, spin_limit;
   // measurement only (ttsdec_profile_loop): when set, workgroup 0 of every step kernel stores its entry time at
   // loop_stamps[slot * kLoopStampNodes + position of the launch in the step order] - the launches' start times inside the
@@ -323,6 +324,13 @@ __device__ __forceinline__ void role_signal(unsigned int* counter) {
   __syncthreads();
   if (threadIdx.x == 0) __hip_atomic_fetch_add(counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
+// a producer whose rows span two of the consumers' 32-row blocks (c1 may be nullptr)
+__device__ __forceinline__ void role_signal2(unsigned int* c0, unsigned int* c1) {
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  if (threadIdx.x == 0) __hip_atomic_fetch_add(c0, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  if (threadIdx.x == 64 && c1 != nullptr) __hip_atomic_fetch_add(c1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
 constexpr int kRoleSpinLimit = 1 << 17;  // x ~0.25 us of s_sleep + the poll's round trip: > 30 ms, far beyond any producer's run time
 // Arrival counters of the two-role launches (in the workspace, zeroed by every ttsdec_decode call): one per 32-ROW BLOCK of the
 // batch and hand-off kind, each on a 128-byte line of its own.  A consumer waits for the producers of ITS rows only - 8 frame
@@ -330,11 +338,12 @@ constexpr int kRoleSpinLimit = 1 << 17;  // x ~0.25 us of s_sleep + the poll's r
 // workgroup waits for the slowest producer of the whole chip, and no counter takes more than 64 adds per step (96 adds to
 // ONE word took the projection role's signal ~1.5 us; MI355X_MICROARCH.md "fanin").
 constexpr int kDepLine = 32;  // unsigned ints per counter line
-enum DepKind { DEP_FRAME = 0, DEP_ATTN = 1, DEP_PROJ = 2, DEP_QUERY = 3, DEP_KINDS = 4 };
+// (DEP_HATT: the attention LSTM's tiles -> the query role and the decoder LSTM, in the one-launch step - fused_kernels.hip step_kernel)
+enum DepKind { DEP_FRAME = 0, DEP_ATTN = 1, DEP_PROJ = 2, DEP_QUERY = 3, DEP_HATT = 4, DEP_KINDS = 5 };
 // the poll alone: for a consumer that takes every handed-off byte with sc1 loads (load_wt), or that only wants to know.
 // Two counters (c1 may be nullptr): a consumer whose rows span two of the producers' 32-row blocks.
 __device__ __forceinline__ void role_poll(const unsigned int* c0, unsigned int target0, Ctrl* ctrl, const unsigned int* c1 = nullptr,
-                                          unsigned int target1 = 0) {
+                                          unsigned int target1 = 0, int long_sleep = 0) {
   if (target0 == 0 && (c1 == nullptr || target1 == 0)) return;
   int spins = 0;
   for (;;) {
@@ -342,6 +351,7 @@ __device__ __forceinline__ void role_poll(const unsigned int* c0, unsigned int t
     const unsigned int v1 = c1 != nullptr ? __hip_atomic_load(c1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : target1;
     if (v0 >= target0 && v1 >= target1) break;
     __builtin_amdgcn_s_sleep(8);
+    for (int i = 0; i < long_sleep; ++i) __builtin_amdgcn_s_sleep(8);  // (waits known to be long: fewer polls beside the tile streams)
     if (++spins > (ctrl != nullptr ? ctrl->spin_limit : kRoleSpinLimit)) {
       if (ctrl != nullptr) atomicOr(&ctrl->range_err, 2);
       break;
@@ -360,6 +370,9 @@ __device__ __forceinline__ void role_wait(const unsigned int* counter, unsigned 
 // polling wave after its poll matched and by the other waves after a workgroup barrier behind it, the consumer needs no
 // agent-scope acquire - 1.7 us less per hop (MI355X_MICROARCH.md, "Hand-offs measured with sc1 loads in place of the acquire").
 __device__ __forceinline__ float load_wt(const float* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ unsigned long long load_wt8(gbyte* p) {  // 8 bytes of the same kind (global_load_dwordx2 sc1)
+  return __hip_atomic_load((__attribute__((address_space(1))) const unsigned long long*)p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
 
 // Workgroup barrier for data exchanged through LDS: waits for this wave's LDS traffic only.  __syncthreads() also drains
 // the wave's outstanding GLOBAL loads and stores (s_waitcnt vmcnt(0)) - behind freshly issued stores that is a whole write

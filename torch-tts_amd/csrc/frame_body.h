@@ -554,7 +554,39 @@ __device__ __forceinline__ void proj_body(ProjArgs g, float* red, int id) {
   // role paid two memory round trips in series, each several us beside the LSTM role's tile stream ----
   f16x8 ah[F16 ? kProjNS : 1], al[F16 ? kProjNS : 1];
   f32x4 af[F16 ? 1 : 2 * kProjNS];
-  {
+  if (g.wait_cnt != nullptr && g.ctrl != nullptr) {
+    // one-launch step: the operand comes from workgroups of this very launch (PROJ_QUERY: h_att from the attention LSTM's tiles
+    // of this tile's 32-row block) - one wave polls, the others take their runs behind the barrier it then joins, all with sc1
+    // loads (common.h load_wt8; one poller per workgroup: gemm_tile.h on what 1024 pollers of one counter cost)
+    const Ctrl* c = g.ctrl;
+    const int t = c->t_cur + g.slot;
+    if (!(t < c->t_end && t - 1 <= c->stop_t)) return;  // (live_lag: see below; the same for every wave)
+    if (wave == 0) role_poll(g.wait_cnt + (m0 / kProjTile) * kDepLine, (unsigned int)(t - c->t_call + 1) * (unsigned int)g.wait_n, g.ctrl, nullptr, 0, g.wait_sleep);
+    __builtin_amdgcn_s_barrier();
+    const int m = m0 + l32 < g.M ? m0 + l32 : g.M - 1;
+    // (16-byte sc1 loads: buffer loads with the sc1 policy bit - the atomic-load builtins stop at 8 bytes, and every load
+    // instruction of this role queues behind the LSTM roles' tile stream; the operand is ONE segment - the host's business)
+    typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+    gbyte *base_h = as_global(g.a.p0), *base_l = as_global(g.a_lo.p0);
+    const __amdgpu_buffer_rsrc_t rh = __builtin_amdgcn_make_buffer_rsrc((void*)g.a.p0, 0, 0x7fffffff, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rl = __builtin_amdgcn_make_buffer_rsrc((void*)g.a_lo.p0, 0, 0x7fffffff, 0x00020000);
+    if constexpr (F16) {
+#pragma unroll
+      for (int j = 0; j < kProjNS; ++j)
+        if (j < spw) {
+          const int oh = (int)(seg_elem_ptr<2>(g.a, m, kbeg + 8 * j) - base_h), ol = (int)(seg_elem_ptr<2>(g.a_lo, m, kbeg + 8 * j) - base_l);
+          ah[j] = __builtin_bit_cast(f16x8, (u32x4)__builtin_amdgcn_raw_buffer_load_b128(rh, oh, 0, 16));
+          al[j] = __builtin_bit_cast(f16x8, (u32x4)__builtin_amdgcn_raw_buffer_load_b128(rl, ol, 0, 16));
+        }
+    } else {
+#pragma unroll
+      for (int j = 0; j < 2 * kProjNS; ++j)
+        if (j < 2 * spw) {
+          const int oa = (int)(seg_elem_ptr<4>(g.a, m, kbeg + 4 * j) - base_h);
+          af[j] = __builtin_bit_cast(f32x4, (u32x4)__builtin_amdgcn_raw_buffer_load_b128(rh, oa, 0, 16));
+        }
+    }
+  } else {
     const int m = m0 + l32 < g.M ? m0 + l32 : g.M - 1;
     if constexpr (F16) {
 #pragma unroll
@@ -578,7 +610,7 @@ __device__ __forceinline__ void proj_body(ProjArgs g, float* red, int id) {
     // changed by that - see lstm_body's live_lag)
     if (g.mode == PROJ_HEAD) live = t < c->t_end && t - 1 <= c->stop_t && t > c->t_call;
     else if (g.mode == PROJ_FINAL) live = c->t_end > c->t_call && c->t_end - 1 <= c->stop_t;
-    else live = t < c->t_end && t <= c->stop_t;
+    else live = t < c->t_end && t - (g.live_lag ? 1 : 0) <= c->stop_t;  // (live_lag: a role of the one-launch step, see lstm_body)
     if (!live) return;
     signal = g.mode == PROJ_HEAD || g.mode == PROJ_QUERY;
   }

@@ -116,6 +116,66 @@ __global__ __launch_bounds__(kGemmThreads, WPE) void attn_lstm_kernel(AttnArgs a
   }
 }
 
+// ---- the whole step as ONE launch ----
+// [proj(t-1) | frame(t) | lstm_att(t) | query(t) -> attention(t) | lstm_dec(t)] by block id: the two launches above back to back
+// inside one grid, so the step loses the boundary between them (the first launch's drain, the release / acquire pair and the
+// second's dispatch: ~4.5-5.4 us of the step at B = 256, time stamps) and the decoder LSTM's workgroups take over a CU's slot the
+// moment an attention-LSTM workgroup leaves it instead of after the slowest one of the chip.
+// What the boundary ordered is ordered by one more hand-off: every attention-LSTM tile stores its split planes write-through
+// and signals the DEP_HATT counter(s) of the 32-row block(s) it covers (lstm_body, LstmArgs::sig_cnt); the query tiles of a
+// row block (proj_body, ProjArgs::wait_cnt) and the decoder LSTM's h_att segment (a second gate, LstmArgs::dep2_*) wait for
+// all of that block's tiles and read them with sc1 loads.
+// Progress: every role waits only for roles with lower block ids (the attention workgroups also for each other's query tiles),
+// the grid dispatches in id order, and the roles in front of the attention role end without it - so every attention workgroup
+// becomes resident (n_attn <= the chip's 512 slots, checked by the host) and everything a workgroup waits for is resident or
+// done.  Every poll is bounded regardless (common.h role_poll).
+// Liveness: all roles of the launch go by t - 1 <= stop_t (live_lag), because the frame role may lower stop_t to t - 1 while
+// they read it: the step after the one at which the stop rule fires is still computed (and never read).
+struct StepGrid {
+  int n_proj, n_frame, frame_cols, n_la, la_cols, n_attn, ld_cols;
+  int tune;  // measurement (option merged_tune): bit 1 = wave priorities 2 / 0 for the attention / decoder LSTM roles
+};
+template <int K0H, int PH, class Cfg, int NJ>
+__global__ __launch_bounds__(kGemmThreads, 4) void step_kernel(FrameArgs f, LstmArgs la, ProjArgs pj, AttnArgs a, LstmArgs ld, ProjArgs pq,
+                                                                StepGrid n) {
+  constexpr int PREC = Cfg::kPrec;
+  __shared__ __attribute__((aligned(16)))
+  float smem[cmax<cmax<Cfg::kLdsFloats, FrameLds<K0H, PH, PREC>::kFloats>(), cmax<kProjLdsFloats, attn_lds_floats<NJ>()>()>()];
+  loop_stamp(f.ctrl, f.slot, f.node);
+  int id = blockIdx.x;
+  if (id < n.n_proj) {
+    __builtin_amdgcn_s_setprio(3);
+    proj_body<PREC>(pj, smem, id);
+    return;
+  }
+  id -= n.n_proj;
+  if (id < n.n_frame) {
+    __builtin_amdgcn_s_setprio(3);
+    frame_body<K0H, PH, PREC, 6, true, true>(f, smem, id % n.frame_cols, id / n.frame_cols);
+    return;
+  }
+  id -= n.n_frame;
+  if (id < n.n_la) {
+    if (n.tune & 2) __builtin_amdgcn_s_setprio(2);
+    lstm_body<Cfg, true, true>(la, smem, id % n.la_cols, id / n.la_cols);
+    return;
+  }
+  id -= n.n_la;
+  if (id < n.n_attn) {
+    __builtin_amdgcn_s_setprio(3);
+    const stamp_ptr st = stamps_of(a.ctrl);  // measurement only (TTSDEC_STAMPS)
+    if (threadIdx.x == 0) stamp(st, 1, 6, now_rt());
+    for (int tile = id; tile < a.q_tiles; tile += n.n_attn) {
+      proj_body<PREC>(pq, smem, tile);
+      __syncthreads();  // (the reduction tile in LDS is reused by the next tile / the attention pass)
+    }
+    attn_body<NJ>(a, smem, id);
+    return;
+  }
+  id -= n.n_attn;
+  lstm_body<Cfg, true, true>(ld, smem, id % n.ld_cols, id / n.ld_cols);
+}
+
 // the early part on its own (profiling / ablation: what the role costs without a partner)
 template <class Cfg>
 __global__ __launch_bounds__(kGemmThreads, 4) void lstm_lean_kernel(LstmArgs l) {
@@ -188,6 +248,41 @@ void launch_attn_lstm(const AttnArgs& a, const LstmArgs& l, const ProjArgs* q, h
   else memset(&pq, 0, sizeof(pq));
   if (a.D / 4 <= 64) { if (f16) launch_attn_lstm_nj<1, PREC_F16S>(a, l, pq, st); else launch_attn_lstm_nj<1, PREC_F32>(a, l, pq, st); }
   else { if (f16) launch_attn_lstm_nj<2, PREC_F16S>(a, l, pq, st); else launch_attn_lstm_nj<2, PREC_F32>(a, l, pq, st); }
+}
+
+// ---- one-launch step ----
+constexpr int kChipSlots = 512;  // 256 CUs x two 512-thread workgroups of <= 80 KiB LDS and <= 128 VGPRs
+template <int PH, int NJ, class Cfg>
+static void launch_step_merged_cfg(const ProjArgs& pj, const FrameArgs& f, const LstmArgs& la, const ProjArgs& pq, const AttnArgs& a,
+                                   const LstmArgs& ld, int bu, hipStream_t st) {
+  StepGrid n;
+  n.tune = f.dbg >> 8;
+  n.frame_cols = (f.P + kFrameCols - 1) / kFrameCols;
+  n.n_frame = n.frame_cols * ((f.M + kFrameRows - 1) / kFrameRows);
+  n.n_proj = proj_grid_size(pj.M, pj.N, pj.ksplit);
+  const int lrows = (la.M + 63) / 64;
+  n.la_cols = (la.H + bu - 1) / bu; n.n_la = n.la_cols * lrows;
+  n.ld_cols = (ld.H + bu - 1) / bu;
+  n.n_attn = a.B;
+  dim3 grid(n.n_proj + n.n_frame + n.n_la + n.n_attn + n.ld_cols * lrows), block(kGemmThreads);
+  hipLaunchKernelGGL((step_kernel<40, PH, Cfg, NJ>), grid, block, 0, st, f, la, pj, a, ld, pq, n);
+}
+bool step_merged_supported(int B, int Ha, int Hd) {
+  (void)Ha; (void)Hd;
+  // (batches the small-batch tile takes keep the two launches: their roles do not share CUs; the attention role's workgroups -
+  // one per utterance - must all fit the chip at once)
+  return B > kSmallFatMaxRows && B <= kChipSlots / 2;
+}
+void launch_step_merged(const ProjArgs& pj, const FrameArgs& f, const LstmArgs& la, const ProjArgs& pq, const AttnArgs& a, const LstmArgs& ld,
+                        hipStream_t st) {
+  if (f.M <= 0 || la.prec != 1) return;  // (split-fp16 only: the host never asks for it otherwise)
+  using TL = LeanTiles<PREC_F16S>;
+  const bool small = la.M <= kLean8MaxRows, nj1 = a.D / 4 <= 64, ph256 = f.Ph == 256;
+#define TTS_STEP(PH_, NJ_) \
+  (small ? launch_step_merged_cfg<PH_, NJ_, TL::Lean64x8>(pj, f, la, pq, a, ld, 8, st) : launch_step_merged_cfg<PH_, NJ_, TL::Lean64x16>(pj, f, la, pq, a, ld, 16, st))
+  if (ph256) { if (nj1) TTS_STEP(256, 1); else TTS_STEP(256, 2); }
+  else { if (nj1) TTS_STEP(128, 1); else TTS_STEP(128, 2); }
+#undef TTS_STEP
 }
 
 void launch_lstm_lean(const LstmArgs& l, hipStream_t st) {

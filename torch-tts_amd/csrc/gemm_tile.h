@@ -142,10 +142,11 @@ __device__ __forceinline__ void wait_vmcnt() {
 // polling one counter saturated its memory channel and slowed the producers - 110 vs 88 us per step.)
 // gate.seg = -1: no gate.
 // kAuxA: cache policy of the A operand's LDS-DMA (16 = sc1: past this CU's vector L1, for operands handed over inside the launch).
+// gate.seg2 (< gate.seg, or -1): a second gated segment, waited for with gate.wait(1) (the one-launch step's decoder LSTM).
 struct NoGate {
   static constexpr int kAuxA = 0;
-  int seg = -1;
-  __device__ __forceinline__ void wait() const {}
+  int seg = -1, seg2 = -1;
+  __device__ __forceinline__ void wait(int) const {}
 };
 
 template <class Cfg, class LoaderA, class LoaderB, class Gate = NoGate>
@@ -172,12 +173,19 @@ __device__ __forceinline__ void gemm_tile(const LoaderA& la, const LoaderB& lb, 
   const int nt0 = (len0 + KT - 1) / KT, nt1 = (len1 + KT - 1) / KT, nt2 = (len2 + KT - 1) / KT;
   const int nk = nt0 + (nseg > 1 ? nt1 : 0) + (nseg > 2 ? nt2 : 0);
   // first tile of the gated segment (uniform), or -1
-  const int gate_tile = (!live || gate.seg < 0 || gate.seg >= nseg) ? -1 : (gate.seg == 0 ? 0 : (gate.seg == 1 ? nt0 : nt0 + nt1));
-  auto gate_sync = [&]() {  // every wave of the workgroup, at the same point of the tile sequence
-    if (wave8 == 4) gate.wait();
+  auto first_tile = [&](int seg) { return (!live || seg < 0 || seg >= nseg) ? -1 : (seg == 0 ? 0 : (seg == 1 ? nt0 : nt0 + nt1)); };
+  const int gate_tile = first_tile(gate.seg), gate_tile2 = first_tile(gate.seg2);
+  auto gate_sync1 = [&](int which) {  // every wave of the workgroup, at the same point of the tile sequence
+    if (wave8 == 4) gate.wait(which);
     __builtin_amdgcn_s_barrier();
   };
-  if (gate_tile >= 0 && gate_tile < S - 1) gate_sync();  // (the segment starts inside the prologue tiles)
+  auto gate_at = [&](int tile) {  // in front of the issue of K tile `tile` (uniform)
+    if (tile == gate_tile2) gate_sync1(1);
+    if (tile == gate_tile) gate_sync1(0);
+  };
+  // (segments that start inside the prologue tiles)
+  if (gate_tile2 >= 0 && gate_tile2 < S - 1) gate_sync1(1);
+  if (gate_tile >= 0 && gate_tile < S - 1) gate_sync1(0);
 
   f32x16 acc, acc2;
 #pragma unroll
@@ -312,7 +320,7 @@ __device__ __forceinline__ void gemm_tile(const LoaderA& la, const LoaderB& lb, 
       // big tiles: tile t has landed (fragments are read right after this barrier)
       wait_vmcnt<Cfg::kWaitCnt>();
       __builtin_amdgcn_s_barrier();       // the MFMA waves are done reading the stage tile t-1 occupied
-      if (t + S - 1 == gate_tile) gate_sync();
+      gate_at(t + S - 1);
       if (dbg != 3) issue_tile();         // tile t+S-1 into that stage (dbg 3: measurement ablation)
     }
     wait_vmcnt<0>();  // trailing zero-block loads must land before the ring is reused
@@ -326,7 +334,7 @@ __device__ __forceinline__ void gemm_tile(const LoaderA& la, const LoaderB& lb, 
         __builtin_amdgcn_s_barrier();
         for (int t = 0; t < nk; ++t) {
           __builtin_amdgcn_s_barrier();
-          if (t + S - 1 == gate_tile) gate_sync();
+          gate_at(t + S - 1);
         }
       }
     } else if constexpr (Cfg::kBig) {
@@ -357,7 +365,7 @@ __device__ __forceinline__ void gemm_tile(const LoaderA& la, const LoaderB& lb, 
       const int nk_run = live ? nk : 0;
       for (int t = 0; t < nk_run; ++t) {
         __builtin_amdgcn_s_barrier();  // tile t is in LDS
-        if (t + S - 1 == gate_tile) gate_sync();
+        gate_at(t + S - 1);
         const char* st = lds + rstage * Cfg::kStageBytes;
         rstage = (rstage + 1 == S) ? 0 : rstage + 1;
         f16x8 ah[TM][NS], al[TM][NS], bh[TN][NS], bl[TN][NS];
@@ -437,7 +445,7 @@ __device__ __forceinline__ void gemm_tile(const LoaderA& la, const LoaderB& lb, 
       auto tile_step = [&](auto cur_c, int t) {
         constexpr int cur = decltype(cur_c)::value;
         __builtin_amdgcn_s_barrier();        // B(t+1): tile t+1 is in LDS
-        if (t + S - 1 == gate_tile) gate_sync();
+        gate_at(t + S - 1);
         // tile t's fragments were requested a whole tile ago: retire them here (no stall), in a
         // form the compiler's wait-count model sees, so it does not later drain the next reads
         __builtin_amdgcn_s_waitcnt(0xC07F);  // lgkmcnt(0) only
@@ -489,7 +497,7 @@ __device__ __forceinline__ void gemm_tile(const LoaderA& la, const LoaderB& lb, 
       auto tile_step = [&](auto cur_c, int t) {
         constexpr int cur = decltype(cur_c)::value;
         __builtin_amdgcn_s_barrier();
-        if (t + S - 1 == gate_tile) gate_sync();
+        gate_at(t + S - 1);
         __builtin_amdgcn_s_waitcnt(0xC07F);  // lgkmcnt(0) only (see the fp32 path)
         read_frags(std::integral_constant<int, cur ^ 1>{});
         // Interleave the next tile's fragment reads with this tile's MFMAs (two ds_read_b128 per MFMA gap are

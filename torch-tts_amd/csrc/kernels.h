@@ -113,6 +113,13 @@ struct LstmArgs {
   // arrivals per block, or - dep_rows = 1 - one per batch row of the block.  dep_n = 0: no gate.
   int dep_n, dep_seg, dep_which, dep_rows;
   unsigned int* dep_cnt;
+  // One-launch step (fused_kernels.hip step_kernel): a SECOND gated K segment, dep2_seg < dep_seg, waiting for dep2_n arrivals per
+  // 32-row block and step at dep2_cnt (the decoder LSTM's h_att segment, produced by the attention LSTM's tiles of the launch);
+  // and sig_cnt != nullptr: this cell is such a producer - its split planes are stored write-through and every tile signals
+  // sig_cnt[32-row block * kDepLine] for the row blocks it covers once its outputs have left.
+  int dep2_n, dep2_seg;
+  unsigned int* dep2_cnt;
+  unsigned int* sig_cnt;
 };
 void launch_lstm(const LstmArgs& a, hipStream_t st);
 void launch_lstm_pair(const LstmArgs& a0, const LstmArgs& a1, hipStream_t st);  // two same-shape fp32 cells, one launch
@@ -138,6 +145,7 @@ struct AttnArgs {
   // sc1 loads.  q_tiles = 0: q comes from an earlier launch.
   int q_tiles, q_wait_n;
   unsigned int* q_cnt;
+  int live_lag;  // 1: the role shares its launch with its step's frame role (one-launch step): live while t - 1 <= stop_t, see lstm_body
   int B, L, D, t_rel, t_stride;
   Ctrl* ctrl;  // != nullptr: memory, w_out, t_rel, t_stride come from *ctrl
   int slot;
@@ -218,6 +226,11 @@ struct ProjArgs {
   // last step, a launch of its own in front of the end-of-call frame launch.
   int mode;
   unsigned int* dep_cnt;
+  // One-launch step: the A operand is produced inside the launch (PROJ_QUERY: h_att by the attention LSTM's tiles) - wait for
+  // wait_n arrivals per step at wait_cnt[32-row block of the tile * kDepLine], then take it with sc1 loads.  live_lag as AttnArgs.
+  int wait_n, live_lag;
+  int wait_sleep;  // extra s_sleep(8)s between the polls of that wait (a wait of many microseconds beside the LSTM roles' streams)
+  unsigned int* wait_cnt;
 };
 // PROJ_QUERY: live like PROJ_STEP, signals like PROJ_HEAD - the attention query as a job of the attention role's workgroups
 enum ProjMode { PROJ_STEP = 0, PROJ_HEAD = 1, PROJ_FINAL = 2, PROJ_QUERY = 3 };
@@ -235,6 +248,11 @@ void launch_proj_frame_lstm(const ProjArgs& pj, const FrameArgs& f, const LstmAr
 int proj_grid_size(int M, int N, int ksplit);  // workgroups of the projection kernel / role
 void launch_attn_lstm(const AttnArgs& a, const LstmArgs& l, const ProjArgs* q, hipStream_t st);  // [query ->] attention || decoder LSTM
 void launch_lstm_lean(const LstmArgs& l, hipStream_t st);                       // an LSTM on the lean tile alone (profiling)
+// The whole step as ONE launch: [proj(t-1) | frame | lstm_att | query -> attention | lstm_dec] by block id, every role waiting
+// only for roles with lower ids (fused_kernels.hip step_kernel).  False: the configuration is not covered (nothing launched).
+bool step_merged_supported(int B, int Ha, int Hd);
+void launch_step_merged(const ProjArgs& pj, const FrameArgs& f, const LstmArgs& la, const ProjArgs& pq, const AttnArgs& a, const LstmArgs& ld,
+                        hipStream_t st);
 
 // ---- state init / bookkeeping ----
 struct InitArgs {

@@ -66,13 +66,22 @@ struct LoaderWLstm {
 template <bool SC1>
 struct RoleGateT {
   static constexpr int kAuxA = SC1 ? 16 : 0;
-  int seg;
+  int seg, seg2;
   const unsigned int *counter, *counter1;  // the arrival counters of this workgroup's (up to two) 32-row blocks
   unsigned int target, target1;
+  const unsigned int *counter2, *counter21;  // the same for the second gated segment (seg2; LstmArgs::dep2_*)
+  unsigned int target2, target21;
   Ctrl* ctrl;
   int kind;
   stamp_ptr st;  // (loaded by the caller, once: see common.h stamp)
-  __device__ __forceinline__ void wait() const {
+  __device__ __forceinline__ void wait(int which) const {
+    if (which == 1) {
+      stamp(st, kind, 6, now_rt());
+      if constexpr (SC1) role_poll(counter2, target2, ctrl, counter21, target21);
+      else role_wait(counter2, target2, ctrl, counter21, target21);
+      stamp(st, kind, 7, now_rt());
+      return;
+    }
     stamp(st, kind, 3, now_rt());
     if constexpr (SC1) role_poll(counter, target, ctrl, counter1, target1);
     else role_wait(counter, target, ctrl, counter1, target1);
@@ -134,7 +143,8 @@ __device__ __forceinline__ void lstm_body(LstmArgs g, float* smem, int bx, int b
   const LoaderWLstm<BU, EB> lb{g.w, g.w_lo, u0, g.H};
   RoleGateT<kWhole> gate;  // (kWhole = a role of a two-role launch)
   const stamp_ptr st = g.dep_n > 0 ? stamps_of(g.ctrl) : (stamp_ptr) nullptr;  // measurement only (TTSDEC_STAMPS)
-  gate.seg = -1; gate.counter = gate.counter1 = nullptr; gate.target = gate.target1 = 0; gate.ctrl = g.ctrl; gate.kind = g.dep_which; gate.st = st;
+  gate.seg = gate.seg2 = -1; gate.counter = gate.counter1 = gate.counter2 = gate.counter21 = nullptr;
+  gate.target = gate.target1 = gate.target2 = gate.target21 = 0; gate.ctrl = g.ctrl; gate.kind = g.dep_which; gate.st = st;
   if (threadIdx.x == 0) {
     stamp(st, g.dep_which, 0, (1ull << 32) | __builtin_amdgcn_s_getreg((4 << 0) | (0 << 6) | (31 << 11)));
     stamp(st, g.dep_which, 1, __builtin_amdgcn_s_getreg((20 << 0) | (0 << 6) | (3 << 11)));
@@ -157,6 +167,15 @@ __device__ __forceinline__ void lstm_body(LstmArgs g, float* smem, int bx, int b
       if (BM == 64 && per_block(rb + 1) > 0) {
         gate.counter1 = g.dep_cnt + (rb + 1) * kDepLine;
         gate.target1 = steps * per_block(rb + 1);
+      }
+      if (g.dep2_n > 0) {  // (one-launch step: the h_att segment, dep2_n tiles of the attention LSTM per 32-row block)
+        gate.seg2 = g.dep2_seg;
+        gate.counter2 = g.dep2_cnt + rb * kDepLine;
+        gate.target2 = steps * (unsigned int)g.dep2_n;
+        if (BM == 64 && per_block(rb + 1) > 0) {
+          gate.counter21 = g.dep2_cnt + (rb + 1) * kDepLine;
+          gate.target21 = steps * (unsigned int)g.dep2_n;
+        }
       }
     }
   }
@@ -211,10 +230,24 @@ __device__ __forceinline__ void lstm_body(LstmArgs g, float* smem, int bx, int b
     g.h_out[idx] = h;
     if (g.h_out_h != nullptr) {
       const size_t o = g.out_mpad > 0 ? chunk_idx(m, unit, g.out_mpad) : idx;
-      split_f16(h, g.h_out_h[o], g.h_out_l[o]);
+      if (kWhole && g.sig_cnt != nullptr) {  // consumed by other workgroups of this very launch: write-through (role_signal)
+        f16 hi, lo;
+        split_f16(h, hi, lo);
+        store_wt(g.h_out_h + o, hi);
+        store_wt(g.h_out_l + o, lo);
+      } else {
+        split_f16(h, g.h_out_h[o], g.h_out_l[o]);
+      }
     }
     if (g.seq_out != nullptr) g.seq_out[((size_t)m * g.seq_Lout + seq_pos) * g.seq_out_ld + g.seq_out_off + unit] = h;
     g.c[idx] = add_rn(mul_rn(g.pz, c_prev), mul_rn(q, c_new));
+  }
+  if constexpr (kWhole) {
+    if (g.sig_cnt != nullptr && !(g.ctrl != nullptr && (g.ctrl->debug_flags & 8))) {
+      static_assert(BM == 32 || BM == 64, "signalling LSTM tiles span one or two 32-row blocks");
+      const int rb = m0 / 32;
+      role_signal2(g.sig_cnt + rb * kDepLine, (BM == 64 && g.M > 32 * (rb + 1)) ? g.sig_cnt + (rb + 1) * kDepLine : nullptr);
+    }
   }
   if (threadIdx.x == 0) stamp(st, g.dep_which, 5, now_rt());
 }
@@ -233,7 +266,8 @@ template <int NJ>
 __device__ __forceinline__ void attn_body(AttnArgs g, float* part, int b) {
   if (g.ctrl != nullptr) {
     const Ctrl* c = g.ctrl;
-    const StepNow now = step_now(c, g.slot);
+    StepNow now = step_now(c, g.slot);
+    if (g.live_lag) now.live = now.t < c->t_end && now.t - 1 <= c->stop_t;  // (a role of the one-launch step: see lstm_body)
     if (!now.live) return;
     g.memory = c->memory;
     g.w_out = c->w;
