@@ -80,6 +80,9 @@ __global__ __launch_bounds__(kGemmThreads, WPE) void frame_lstm_kernel(FrameArgs
     }
     id -= n_proj;
   }
+  // (Measured and dropped, profiles/r03_y: the frame role LAST in the grid, so that its workgroups draw the first-dispatched
+  // LSTM workgroups as CU partners, and the frame role at normal wave priority - the 32 LSTM workgroups that share a CU with a
+  // frame workgroup stay the launch's tail either way: they reach their gate ~6 us after the others, 2.5 us after x_pre is there.)
   if (id < n_frame) {
     __builtin_amdgcn_s_setprio(3);  // the producer role is the launch's critical path: it wins issue arbitration
     frame_body<K0H, PH, PREC, 6, WPE == 4, kHead>(f, smem, id % frame_cols, id / frame_cols);
