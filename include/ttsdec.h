@@ -174,8 +174,9 @@ int ttsdec_get_precision(const ttsdec_handle* h);
 enum {
   TTSDEC_OPT_GRAPH = 0,        /* "graph": 0 = launch every step kernel from the host instead of replaying a captured hipGraph  */
   TTSDEC_OPT_OVERLAP,          /* "overlap": two-role launches 0 = none, 1 = frame || lstm_att, 2 = also attention || lstm_dec;
-                                * 3 = the whole step as ONE launch where it applies (split-fp16, projection head role and query
-                                * role on, 33..256 utterances; level 2 elsewhere).  Never the default: measured slower, DESIGN.md */
+                                * 3 = the whole step as ONE launch where it applies (split-fp16, projection head role on, at most
+                                * 256 utterances; level 2 elsewhere).  Never the default: measured slower at every batch size,
+                                * DESIGN.md section 4.5                                                                        */
   TTSDEC_OPT_CHUNK_A,          /* "chunk_a": 0 = row-major fp16 activation planes instead of the chunked layout                */
   TTSDEC_OPT_CHUNK_B,          /* "chunk_b": 0 = row-major LSTM weight planes                                                  */
   TTSDEC_OPT_PROJ_REGW,        /* "proj_regw": 0 = mel/stop projection on the LDS-staged split-K GEMM                          */

@@ -791,8 +791,11 @@ bool query_role(const ttsdec_handle* h, int B) {
 // The one-launch step (option overlap = 3): the configuration in which both two-role launches carry their extra roles - split-fp16
 // Prod cell, projection head role, query role - at batches the lean tiles take.
 bool step_merged(const ttsdec_handle* h, int B) {
-  if (overlap_level(h, B) < 3 || !lstm_prec(h)) return false;
-  return head_proj(h, B) && query_role(h, B) && step_merged_supported(B, h->d.h_att, h->d.h_dec);
+  const ttsdec_dims& d = h->d;
+  if (overlap_level(h, B) < 3 || !lstm_prec(h) || !head_proj(h, B)) return false;
+  const int ps = proj_split(query_k(d));  // (the query on the register-weight body: whole K slices)
+  if (!(ps > 0 && ps <= kQuerySplit && !(d.h_att & 7))) return false;
+  return step_merged_supported(B, d.h_att, d.h_dec);
 }
 const StepOrder& step_order(const ttsdec_handle* h, int B) {
   const ttsdec_dims& d = h->d;

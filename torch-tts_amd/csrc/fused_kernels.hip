@@ -134,13 +134,16 @@ __global__ __launch_bounds__(kGemmThreads, WPE) void attn_lstm_kernel(AttnArgs a
 // done.  Every poll is bounded regardless (common.h role_poll).
 // Liveness: all roles of the launch go by t - 1 <= stop_t (live_lag), because the frame role may lower stop_t to t - 1 while
 // they read it: the step after the one at which the stop rule fires is still computed (and never read).
+// Small batches (the stand-alone small-batch LSTM tile, one workgroup per CU, WPE = 2): fewer attention workgroups than query
+// tiles, so the query tiles get workgroups of their own (n_q of them, between the attention LSTM and the attention role);
+// nothing shares a CU there, and the decoder LSTM's h_dec segment streams on the CUs the first half of the step leaves idle.
 struct StepGrid {
-  int n_proj, n_frame, frame_cols, n_la, la_cols, n_attn, ld_cols;
+  int n_proj, n_frame, frame_cols, n_la, la_cols, n_q, n_attn, ld_cols;
   int tune;  // measurement (option merged_tune): bit 1 = wave priorities 2 / 0 for the attention / decoder LSTM roles
 };
-template <int K0H, int PH, class Cfg, int NJ>
-__global__ __launch_bounds__(kGemmThreads, 4) void step_kernel(FrameArgs f, LstmArgs la, ProjArgs pj, AttnArgs a, LstmArgs ld, ProjArgs pq,
-                                                                StepGrid n) {
+template <int K0H, int PH, class Cfg, int NJ, int WPE>
+__global__ __launch_bounds__(kGemmThreads, WPE) void step_kernel(FrameArgs f, LstmArgs la, ProjArgs pj, AttnArgs a, LstmArgs ld, ProjArgs pq,
+                                                                  StepGrid n) {
   constexpr int PREC = Cfg::kPrec;
   __shared__ __attribute__((aligned(16)))
   float smem[cmax<cmax<Cfg::kLdsFloats, FrameLds<K0H, PH, PREC>::kFloats>(), cmax<kProjLdsFloats, attn_lds_floats<NJ>()>()>()];
@@ -154,7 +157,7 @@ __global__ __launch_bounds__(kGemmThreads, 4) void step_kernel(FrameArgs f, Lstm
   id -= n.n_proj;
   if (id < n.n_frame) {
     __builtin_amdgcn_s_setprio(3);
-    frame_body<K0H, PH, PREC, 6, true, true>(f, smem, id % n.frame_cols, id / n.frame_cols);
+    frame_body<K0H, PH, PREC, 6, WPE == 4, true>(f, smem, id % n.frame_cols, id / n.frame_cols);
     return;
   }
   id -= n.n_frame;
@@ -164,18 +167,23 @@ __global__ __launch_bounds__(kGemmThreads, 4) void step_kernel(FrameArgs f, Lstm
     return;
   }
   id -= n.n_la;
-  if (id < n.n_attn) {
+  if (id < n.n_q + n.n_attn) {
     __builtin_amdgcn_s_setprio(3);
+    const bool is_q = id < n.n_q;  // a query-tile workgroup (small batches), else the attention workgroup of utterance id - n_q
+    const int aid = id - n.n_q;
     const stamp_ptr st = stamps_of(a.ctrl);  // measurement only (TTSDEC_STAMPS)
-    if (threadIdx.x == 0) stamp(st, 1, 6, now_rt());
-    for (int tile = id; tile < a.q_tiles; tile += n.n_attn) {
+    if (threadIdx.x == 0 && !is_q) stamp(st, 1, 6, now_rt());
+    // query tiles: this workgroup's one (query workgroups), none (attention workgroups beside them), or tiles aid, aid + n_attn, ...
+    const int t0 = n.n_q > 0 ? (is_q ? id : 0) : aid, t1 = n.n_q > 0 ? (is_q ? id + 1 : 0) : a.q_tiles, ts = n.n_q > 0 ? 1 : n.n_attn;
+    for (int tile = t0; tile < t1; tile += ts) {
       proj_body<PREC>(pq, smem, tile);
       __syncthreads();  // (the reduction tile in LDS is reused by the next tile / the attention pass)
     }
-    attn_body<NJ>(a, smem, id);
+    if (is_q) return;
+    attn_body<NJ>(a, smem, aid);
     return;
   }
-  id -= n.n_attn;
+  id -= n.n_q + n.n_attn;
   lstm_body<Cfg, true, true>(ld, smem, id % n.ld_cols, id / n.ld_cols);
 }
 
@@ -255,34 +263,42 @@ void launch_attn_lstm(const AttnArgs& a, const LstmArgs& l, const ProjArgs* q, h
 
 // ---- one-launch step ----
 constexpr int kChipSlots = 512;  // 256 CUs x two 512-thread workgroups of <= 80 KiB LDS and <= 128 VGPRs
-template <int PH, int NJ, class Cfg>
+template <int PH, int NJ, class Cfg, int WPE>
 static void launch_step_merged_cfg(const ProjArgs& pj, const FrameArgs& f, const LstmArgs& la, const ProjArgs& pq, const AttnArgs& a,
-                                   const LstmArgs& ld, int bu, hipStream_t st) {
+                                   const LstmArgs& ld, hipStream_t st) {
+  constexpr int BU = Cfg::BN / 4;
   StepGrid n;
   n.tune = f.dbg >> 8;
   n.frame_cols = (f.P + kFrameCols - 1) / kFrameCols;
   n.n_frame = n.frame_cols * ((f.M + kFrameRows - 1) / kFrameRows);
   n.n_proj = proj_grid_size(pj.M, pj.N, pj.ksplit);
-  const int lrows = (la.M + 63) / 64;
-  n.la_cols = (la.H + bu - 1) / bu; n.n_la = n.la_cols * lrows;
-  n.ld_cols = (ld.H + bu - 1) / bu;
+  const int lrows = (la.M + Cfg::BM - 1) / Cfg::BM;
+  n.la_cols = (la.H + BU - 1) / BU; n.n_la = n.la_cols * lrows;
+  n.ld_cols = (ld.H + BU - 1) / BU;
   n.n_attn = a.B;
-  dim3 grid(n.n_proj + n.n_frame + n.n_la + n.n_attn + n.ld_cols * lrows), block(kGemmThreads);
-  hipLaunchKernelGGL((step_kernel<40, PH, Cfg, NJ>), grid, block, 0, st, f, la, pj, a, ld, pq, n);
+  n.n_q = a.q_tiles > a.B ? a.q_tiles : 0;  // (fewer attention workgroups than query tiles: the tiles get workgroups of their own)
+  dim3 grid(n.n_proj + n.n_frame + n.n_la + n.n_q + n.n_attn + n.ld_cols * lrows), block(kGemmThreads);
+  hipLaunchKernelGGL((step_kernel<40, PH, Cfg, NJ, WPE>), grid, block, 0, st, f, la, pj, a, ld, pq, n);
+}
+static int step_roles_in_front(int B, int P, int n_out, int ksplit) {  // the workgroups in front of the attention LSTM's
+  return proj_grid_size(B, n_out, ksplit) + frame_grid_size(B, P);
 }
 bool step_merged_supported(int B, int Ha, int Hd) {
   (void)Ha; (void)Hd;
-  // (batches the small-batch tile takes keep the two launches: their roles do not share CUs; the attention role's workgroups -
-  // one per utterance - must all fit the chip at once)
-  return B > kSmallFatMaxRows && B <= kChipSlots / 2;
+  // (the attention role's workgroups - one per utterance - and, where they also run the query tiles, each other's: all
+  // resident at once)
+  return B >= 1 && B <= kChipSlots / 2;
 }
 void launch_step_merged(const ProjArgs& pj, const FrameArgs& f, const LstmArgs& la, const ProjArgs& pq, const AttnArgs& a, const LstmArgs& ld,
                         hipStream_t st) {
   if (f.M <= 0 || la.prec != 1) return;  // (split-fp16 only: the host never asks for it otherwise)
   using TL = LeanTiles<PREC_F16S>;
-  const bool small = la.M <= kLean8MaxRows, nj1 = a.D / 4 <= 64, ph256 = f.Ph == 256;
-#define TTS_STEP(PH_, NJ_) \
-  (small ? launch_step_merged_cfg<PH_, NJ_, TL::Lean64x8>(pj, f, la, pq, a, ld, 8, st) : launch_step_merged_cfg<PH_, NJ_, TL::Lean64x16>(pj, f, la, pq, a, ld, 16, st))
+  const LeanKind kind = lean_kind(la.M, step_roles_in_front(f.M, f.P, pj.N, pj.ksplit), la.H > ld.H ? la.H : ld.H);
+  const bool nj1 = a.D / 4 <= 64, ph256 = f.Ph == 256;
+#define TTS_STEP(PH_, NJ_)                                                                                   \
+  (kind == SMALL_FAT ? launch_step_merged_cfg<PH_, NJ_, TL::SmallFat, 2>(pj, f, la, pq, a, ld, st)            \
+   : kind == LEAN_64x8 ? launch_step_merged_cfg<PH_, NJ_, TL::Lean64x8, 4>(pj, f, la, pq, a, ld, st)         \
+                       : launch_step_merged_cfg<PH_, NJ_, TL::Lean64x16, 4>(pj, f, la, pq, a, ld, st))
   if (ph256) { if (nj1) TTS_STEP(256, 1); else TTS_STEP(256, 2); }
   else { if (nj1) TTS_STEP(128, 1); else TTS_STEP(128, 2); }
 #undef TTS_STEP
