@@ -508,17 +508,41 @@ constexpr int kProjTile = 32;  // rows and columns of a workgroup's output tile
 constexpr int kProjNS = 4;     // k16 steps per wave at most
 
 // address of element (row, k) of a segmented activation operand with EB-byte elements
-template <int EB>
+// (The segment index differs from lane to lane here.  Selecting between the struct's MEMBERS with it lets the compiler turn
+// "select of loads" into one indexed load from the kernel-argument struct - which it then copies to scratch: 216 bytes per lane
+// and ten scratch loads per fragment in the stand-alone projection kernel, 6.5 -> 14 us per launch before this was noticed.
+// The members are therefore first pinned in scalar registers and the select made between those.)
+template <class T>
+__device__ __forceinline__ T pinned_scalar(T v) {
+  asm volatile("" : "+s"(v));
+  return v;
+}
+// kPin = false: the plain member selects (the multi-role kernels, where the pattern does not arise and the extra scalar
+// registers would spill).
+template <int EB, bool kPin>
 __device__ __forceinline__ gbyte* seg_elem_ptr(const Seg3& s, int row, int k) {
-  const int i = k < s.e0 ? 0 : (k < s.e1 ? 1 : 2);
-  const int kk = k - (i == 0 ? 0 : (i == 1 ? s.e0 : s.e1));
-  gbyte* p = seg_row_ptr<EB>(s, row, i);
-  return p + (s.mpad > 0 ? (long)(kk >> 5) * s.mpad * kChunkBytes + (long)(kk & 31) * EB : (long)kk * EB);
+  if constexpr (!kPin) {
+    const int i = k < s.e0 ? 0 : (k < s.e1 ? 1 : 2);
+    const int kk = k - (i == 0 ? 0 : (i == 1 ? s.e0 : s.e1));
+    gbyte* p = seg_row_ptr<EB>(s, row, i);
+    return p + (s.mpad > 0 ? (long)(kk >> 5) * s.mpad * kChunkBytes + (long)(kk & 31) * EB : (long)kk * EB);
+  }
+  const int e0 = pinned_scalar(s.e0), e1 = pinned_scalar(s.e1), mpad = s.mpad;
+  const unsigned long long p0 = pinned_scalar((unsigned long long)s.p0), p1 = pinned_scalar((unsigned long long)s.p1),
+                           p2 = pinned_scalar((unsigned long long)s.p2);
+  const int ld0 = pinned_scalar(s.ld0), ld1 = pinned_scalar(s.ld1), ld2 = pinned_scalar(s.ld2);
+  const int i = k < e0 ? 0 : (k < e1 ? 1 : 2);
+  const int kk = k - (i == 0 ? 0 : (i == 1 ? e0 : e1));
+  const unsigned long long base = i == 0 ? p0 : (i == 1 ? p1 : p2);
+  const int ld = i == 0 ? ld0 : (i == 1 ? ld1 : ld2);
+  gbyte* p = (gbyte*)base + (mpad > 0 ? (long)row * kChunkBytes : (long)row * ld * EB);
+  return p + (mpad > 0 ? (long)(kk >> 5) * mpad * kChunkBytes + (long)(kk & 31) * EB : (long)kk * EB);
 }
 
 constexpr int kProjLdsFloats = 8 * 32 * 33;
 // red: kProjLdsFloats floats of LDS (the caller's ONE shared array); id: index of the workgroup within the kernel or role
-template <int PREC>
+// kPin: seg_elem_ptr above (true in the stand-alone projection kernel)
+template <int PREC, bool kPin = false>
 __device__ __forceinline__ void proj_body(ProjArgs g, float* red, int id) {
   constexpr bool F16 = PREC == PREC_F16S;
   constexpr int EB = F16 ? 2 : 4, RS = 33;
@@ -574,7 +598,7 @@ __device__ __forceinline__ void proj_body(ProjArgs g, float* red, int id) {
 #pragma unroll
       for (int j = 0; j < kProjNS; ++j)
         if (j < spw) {
-          const int oh = (int)(seg_elem_ptr<2>(g.a, m, kbeg + 8 * j) - base_h), ol = (int)(seg_elem_ptr<2>(g.a_lo, m, kbeg + 8 * j) - base_l);
+          const int oh = (int)(seg_elem_ptr<2, kPin>(g.a, m, kbeg + 8 * j) - base_h), ol = (int)(seg_elem_ptr<2, kPin>(g.a_lo, m, kbeg + 8 * j) - base_l);
           ah[j] = __builtin_bit_cast(f16x8, (u32x4)__builtin_amdgcn_raw_buffer_load_b128(rh, oh, 0, 16));
           al[j] = __builtin_bit_cast(f16x8, (u32x4)__builtin_amdgcn_raw_buffer_load_b128(rl, ol, 0, 16));
         }
@@ -582,7 +606,7 @@ __device__ __forceinline__ void proj_body(ProjArgs g, float* red, int id) {
 #pragma unroll
       for (int j = 0; j < 2 * kProjNS; ++j)
         if (j < 2 * spw) {
-          const int oa = (int)(seg_elem_ptr<4>(g.a, m, kbeg + 4 * j) - base_h);
+          const int oa = (int)(seg_elem_ptr<4, kPin>(g.a, m, kbeg + 4 * j) - base_h);
           af[j] = __builtin_bit_cast(f32x4, (u32x4)__builtin_amdgcn_raw_buffer_load_b128(rh, oa, 0, 16));
         }
     }
@@ -592,13 +616,13 @@ __device__ __forceinline__ void proj_body(ProjArgs g, float* red, int id) {
 #pragma unroll
       for (int j = 0; j < kProjNS; ++j)
         if (j < spw) {
-          ah[j] = *(gf16x8*)seg_elem_ptr<2>(g.a, m, kbeg + 8 * j);
-          al[j] = *(gf16x8*)seg_elem_ptr<2>(g.a_lo, m, kbeg + 8 * j);
+          ah[j] = *(gf16x8*)seg_elem_ptr<2, kPin>(g.a, m, kbeg + 8 * j);
+          al[j] = *(gf16x8*)seg_elem_ptr<2, kPin>(g.a_lo, m, kbeg + 8 * j);
         }
     } else {
 #pragma unroll
       for (int j = 0; j < 2 * kProjNS; ++j)
-        if (j < 2 * spw) af[j] = *(gf32x4*)seg_elem_ptr<4>(g.a, m, kbeg + 4 * j);
+        if (j < 2 * spw) af[j] = *(gf32x4*)seg_elem_ptr<4, kPin>(g.a, m, kbeg + 4 * j);
     }
   }
   bool signal = false;

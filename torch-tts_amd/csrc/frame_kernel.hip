@@ -29,7 +29,7 @@ template <int PREC>
 __global__ __launch_bounds__(kFrameThreads) void proj_kernel(ProjArgs g) {
   loop_stamp(g.ctrl, g.slot, g.node);
   __shared__ __attribute__((aligned(16))) float red[kProjLdsFloats];
-  proj_body<PREC>(g, red, blockIdx.x);
+  proj_body<PREC, true>(g, red, blockIdx.x);
 }
 
 int proj_split(int K) {
