@@ -758,13 +758,15 @@ int overlap_level(const ttsdec_handle* h, int B) {
   const ttsdec_dims& d = h->d;
   if (is_taco2(d) || !fused_supported(d.d_mel, d.r, pre_hidden(d), d.d_pre, d.d_ctx)) return 0;
   if (h->overlap >= 0) return h->overlap;
-  if (lstm_prec(h)) return B <= 320 ? 2 : 1;  // (above that the two differ by +-1.5 %: B = 384 110.6 / 112.5, B = 512 133.4 / 130.0, B = 2048 494.5 / 502.3)
+  // Round 3 (after the sc1 hand-offs and the per-row-block counters; profiles/r03_t_levels_sweep.txt, us per step, levels 0 / 1 / 2):
+  // split-fp16 B = 96 78.3 / 62.4 / 48.8, 192 80.1 / 64.8 / 59.3, 320 128.5 / 102.5 / 88.8, 384 131.1 / 110.0 / 98.3, 512 147.7 / 131.6 /
+  // 117.8, 1024 - / 262.6 / 235.0, 2048 - / 504.1 / 455.8: level 2 at every batch size (round 2 had level 1 above 320, +-1.5 % then).
+  if (lstm_prec(h)) return 2;
   // exact fp32: the matrix pipe is the LSTMs' bound there, and the 64x8 lean tile of the middle batch sizes keeps only
   // two of a CU's four matrix pipes busy - so small batches (stand-alone tile) and chip-filling ones only.  us per step for
-  // levels 0 / 1 / 2: B = 32 75.3 / 67.4 / 56.4, B = 64 76.2 / 87.1 / 109.8, B = 96 100.8 / 103.9 / 114.3, B = 128 102.2 /
-  // 105.2 / 115.1, B = 192 141.9 / 129.7 / 119.2, B = 256 143.2 / 138.1 / 127.3 (profiles/r02_h_levels.txt)
-  // (above 320 utterances nothing was measured for level 2: level 1 there, as in split-fp16 mode)
-  return B <= 32 ? 2 : (B < 192 ? 0 : (B <= 320 ? 2 : 1));
+  // levels 0 / 1 / 2: B = 32 76.1 / 66.6 / 56.1, B = 64 77.1 / 87.2 / 111.4, B = 128 104.3 / 106.1 / 117.2, B = 192 143.7 / 130.0 /
+  // 119.4, B = 384 254.0 / 228.7 / 209.3, B = 512 - / 245.6 / 226.3, 1024 - / 473.8 / 435.2, 2048 - / 915.3 / 838.1
+  return B <= 32 ? 2 : (B < 192 ? 0 : 2);
 }
 // The projection as the head role of the next step's frame launch, wherever the register-weight kernel applies (split-fp16).
 // us per step without / with it, same box: B = 1 43.0 / 39.8, B = 64 51.8 / 50.1, B = 128 54.2 / 53.5, B = 256 73.4 / 73.3 (there
