@@ -182,7 +182,7 @@ enum {
   TTSDEC_OPT_PROJ_REGW,        /* "proj_regw": 0 = mel/stop projection on the LDS-staged split-K GEMM                          */
   TTSDEC_OPT_HEAD_PROJ,        /* "head_proj": 1 / 0 = that projection as a role at the head of the next step's first launch   */
   TTSDEC_OPT_QUERY_ROLE,       /* "query_role": 1 / 0 = the attention query GEMM as a job of the attention role's workgroups
-                                * (overlap 2, at most 256 utterances) instead of a launch of its own                          */
+                                * (overlap 2, at most 512 utterances) instead of a launch of its own                          */
   TTSDEC_OPT_MERGED_TUNE,      /* "merged_tune": measurement knobs of the one-launch step (overlap = 3): bit 0 = the decoder LSTM waits for
                                 * h_att before its first tile, bit 1 = wave priority 2 / 0 for the attention / decoder LSTM roles,
                                 * bits 8-15 = extra sleeps between the query role's polls for h_att                              */

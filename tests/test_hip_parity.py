@@ -345,12 +345,12 @@ def test_large_single_gpu_batch_runs_and_is_finite(H):
         y, s, w = dec(mem, None, None, T - 1)
     assert y.shape == (B, T, 80) and torch.isfinite(y).all()
     assert float((w.sum(-1) - 1).abs().max()) < 1e-4
-    # rows are independent: the first 384 utterances decoded alone give the same bits (same launch sequence - above 320
-    # utterances the decoder LSTM runs as a launch of its own - hence the same summation order)
+    # rows are independent: the first 512 utterances decoded alone give the same bits (same launch sequence - above 384
+    # utterances the attention query is a launch of its own - hence the same summation order)
     with torch.no_grad():
-        y2, _, w2 = dec(mem[:384].contiguous(), None, None, T - 1)
-    assert torch.equal(y[:384], y2) and torch.equal(w[:384], w2)
-    # ... and under the other launch sequence (192 utterances: attention || lstm_dec) the same values within the parity bar
+        y2, _, w2 = dec(mem[:512].contiguous(), None, None, T - 1)
+    assert torch.equal(y[:512], y2) and torch.equal(w[:512], w2)
+    # ... and under the other launch sequence (192 utterances: the query a job of the attention role) the same values within the parity bar
     with torch.no_grad():
         y3, _, w3 = dec(mem[:192].contiguous(), None, None, T - 1)
     H.assert_close(y3.cpu(), y[:192].cpu(), RTOL, ATOL, "y, 192 of 2048")
@@ -659,11 +659,11 @@ def test_full_size_properties(H, prec):
 def test_shard_equivalence_bitwise(H):
     """Utterances never interact inside the step (decoder_cell.py:180-195 is row-wise), so
     decoding a batch in two shards must equal decoding it whole, bit for bit.
-    Whole batch and shards must lie in one regime of the launch schedule (the same GEMM tiling and K order): 65 .. 256
-    utterances (two launches per step), or more than 320 (both modes)."""
+    Whole batch and shards must lie in one regime of the launch schedule (the same GEMM tiling and K order): 65 .. 384
+    utterances (two launches per step: the query a job of the attention role), or more than 384 (both modes)."""
     dims = O.DecoderDims()
     wts = O.random_decoder_weights(dims, seed=1)
-    for prec, B in (("split_f16", 256), ("split_f16", 768), ("f32", 768)):
+    for prec, B in (("split_f16", 256), ("split_f16", 1024), ("f32", 768)):
         L, T = 64, 12
         mem = O.synthetic_memory(B, L, dims.d_ctx, seed=5).cuda()
         masks = O.synthetic_masks(T, B, dims.d_pre, seed=6)

@@ -776,22 +776,23 @@ bool head_proj(const ttsdec_handle* h, int B) {
   return h->head_proj != 0;  // (-1 = default = on)
 }
 // The query as a job of the attention role (fused_kernels.hip attn_lstm_kernel): needs every attention-role workgroup resident
-// at once - one per utterance, at most the chip's 256 CUs x 2 workgroups minus the LSTM role's - and whole K slices for the
-// register-weight GEMM body.
-// Measured, us per step with / without it (same box, profiles/r03_f_*): split-fp16 B = 256 60.4 / 61.6, 128 49.4 / 50.0, 64 46.6 /
-// 47.0; B = 32 44.1 / 42.5 (the roles do not share CUs there: the hop costs more than the launch), B = 1 175 / 38 (one
-// workgroup would run all 32 tiles); exact fp32 B = 256 125.0 / 125.0, B = 32 58.6 / 55.3.  So: split-fp16, 64 utterances or
-// more, at most one tile per workgroup (option query_role = 1 forces it wherever it is possible at all).
+// at once - one per utterance; they have the launch's lowest block ids, so that is at most the chip's 512 slots - and whole K
+// slices for the register-weight GEMM body.
+// Measured, us per step with / without it (same box, profiles/r03_f_*, r03_t_query_role_large_batches.txt): split-fp16 B = 256 60.4 /
+// 61.6, 128 49.4 / 50.0, 64 46.6 / 47.0, 320 83.9 / 89.7, 384 98.5 / 99.0, 448 108.5 / 106.9, 512 121.5 / 118.7; B = 32 44.1 / 42.5 (the
+// roles do not share CUs there: the hop costs more than the launch), B = 1 175 / 38 (one workgroup would run all 32 tiles); exact
+// fp32 B = 256 125.0 / 125.0, B = 32 58.6 / 55.3.  So: split-fp16, 64..384 utterances, at most one tile per workgroup (option
+// query_role = 1 forces it wherever it is possible at all).
 bool query_role(const ttsdec_handle* h, int B) {
   const ttsdec_dims& d = h->d;
-  if (overlap_level(h, B) < 2 || h->query_role == 0 || B > 256) return false;
+  if (overlap_level(h, B) < 2 || h->query_role == 0 || B > 512) return false;
   const int ps = proj_split(query_k(d));
   if (!(ps > 0 && ps <= kQuerySplit && !(d.h_att & 7))) return false;
   if (h->query_role > 0) return true;
-  return lstm_prec(h) && B >= 64 && proj_grid_size(B, d.d_ctx, ps) <= B;
+  return lstm_prec(h) && B >= 64 && B <= 384 && proj_grid_size(B, d.d_ctx, ps) <= B;
 }
-// The one-launch step (option overlap = 3): the configuration in which both two-role launches carry their extra roles - split-fp16
-// Prod cell, projection head role, query role - at batches the lean tiles take.
+// The one-launch step (option overlap = 3): split-fp16 Prod cell with the projection as a head role and the query on the
+// register-weight body, at batches whose attention workgroups fit the chip at once.
 bool step_merged(const ttsdec_handle* h, int B) {
   const ttsdec_dims& d = h->d;
   if (overlap_level(h, B) < 3 || !lstm_prec(h) || !head_proj(h, B)) return false;
