@@ -35,6 +35,7 @@ inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 struct BlobLayout {  // offsets in floats
   size_t pre0_w, pre0_b, pre1_w, pre1_b, wq;
   size_t pre0_h, pre0_l, pre1_h, pre1_l;  // split-fp16 planes of the PreNet weights
+  size_t pre0_ph, pre0_pl, pre1_ph, pre1_pl;  // the same in the frame kernel's lane order (launch_split_frame_order; layer 1 padded to 64 rows)
   size_t wq_h, wq_l, proj_h, proj_l;      // ... of the query and mel/stop projection weights
   size_t att_ih, att_hh, att_b, dec_ih, dec_hh, dec_b;
   size_t att_ih_h, att_ih_l, att_hh_h, att_hh_l, dec_ih_h, dec_ih_l, dec_hh_h, dec_hh_l;  // split-fp16 planes
@@ -176,6 +177,9 @@ BlobLayout make_blob_layout(const ttsdec_dims& d) {
   // fp16 planes occupy half a float per element
   L.pre0_h = take((Ph * Mel + 1) / 2); L.pre0_l = take((Ph * Mel + 1) / 2);
   L.pre1_h = take((P * Ph + 1) / 2); L.pre1_l = take((P * Ph + 1) / 2);
+  L.pre0_ph = take((Ph * Mel + 1) / 2); L.pre0_pl = take((Ph * Mel + 1) / 2);
+  const size_t p64 = (P + 63) / 64 * 64;
+  L.pre1_ph = take((p64 * Ph + 1) / 2); L.pre1_pl = take((p64 * Ph + 1) / 2);
   L.att_ih_h = take(2 * Ha * (P + D)); L.att_ih_l = take(2 * Ha * (P + D));
   L.att_hh_h = take(2 * Ha * Ha);      L.att_hh_l = take(2 * Ha * Ha);
   L.dec_ih_h = take(2 * Hd * (Ha + D)); L.dec_ih_l = take(2 * Hd * (Ha + D));
@@ -431,7 +435,7 @@ void launch_node(const ttsdec_handle* h, const StepBufs& sb, const StepIo& io, N
     if (io.dbg & 1) f.finalize = 0;       // measurement ablations (profile_step only)
     if (io.dbg & 8) f.only_finalize = 1;
     f.W0 = blob + bl.pre0_w; f.b0 = blob + bl.pre0_b; f.W1 = blob + bl.pre1_w; f.b1 = blob + bl.pre1_b;
-    f.W0h = plane(bl.pre0_h); f.W0l = plane(bl.pre0_l); f.W1h = plane(bl.pre1_h); f.W1l = plane(bl.pre1_l);
+    f.W0h = plane(bl.pre0_ph); f.W0l = plane(bl.pre0_pl); f.W1h = plane(bl.pre1_ph); f.W1l = plane(bl.pre1_pl);  // (lane order)
     f.prec = prec ? PREC_F16S : PREC_F32;
     f.Ph = Ph; f.P = P;
     f.dropout_mode = io.dropout_mode; f.masks = io.masks; f.mask_step_stride = (size_t)B * (Ph + P);
@@ -1046,6 +1050,10 @@ int ttsdec_pack_weights(ttsdec_handle* h, const float* const* src, int n_src, vo
   auto hp = [&](size_t float_off) { return reinterpret_cast<f16*>(b + float_off); };
   launch_split(src[TTSDEC_W_PRE0_W], hp(L.pre0_h), hp(L.pre0_l), Ph * Mel, st);
   launch_split(src[TTSDEC_W_PRE1_W], hp(L.pre1_h), hp(L.pre1_l), P * Ph, st);
+  if (use_frame(d)) {  // (the frame kernel's shapes: frame_supported - d_mel = 80, Ph = 128 or 256)
+    launch_split_frame_order(src[TTSDEC_W_PRE0_W], hp(L.pre0_ph), hp(L.pre0_pl), (int)Ph, (int)Mel, 0, st);
+    launch_split_frame_order(src[TTSDEC_W_PRE1_W], hp(L.pre1_ph), hp(L.pre1_pl), (int)P, (int)Ph, 1, st);
+  }
   launch_split(src[TTSDEC_W_ATT_IH], hp(L.att_ih_h), hp(L.att_ih_l), 4 * Ha * (P + D), st);
   launch_split(src[TTSDEC_W_ATT_HH], hp(L.att_hh_h), hp(L.att_hh_l), 4 * Ha * Ha, st);
   launch_split(src[TTSDEC_W_DEC_IH], hp(L.dec_ih_h), hp(L.dec_ih_l), 4 * Hd * (Ha + D), st);

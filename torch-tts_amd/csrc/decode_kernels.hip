@@ -615,6 +615,36 @@ void launch_split(const float* src, f16* hi, f16* lo, size_t n, hipStream_t st) 
   hipLaunchKernelGGL(split_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, src, hi, lo, n);
 }
 
+// The PreNet weights in the order the frame kernel's lanes take them (frame_body.h: lane (l32, half) of wave w holds a K run of
+// weight row n): piece (w, j) = the 64 lanes' 16 bytes back to back, so every weight load of the kernel is one coalesced KiB.
+// Row-per-lane loads touched 32-40 cache lines per instruction; beside an LSTM workgroup on the same CU that cost the LSTM's tile
+// stream ~2 us per step at B = 256 (profiles/r03_u_*).
+//   layer 0 (W [PH, K0], K0H = K0 / 2):  n = 32 w + l32, k = half K0H + 8 j + e       -> ((w NW0 + j) 64 + 32 half + l32) 8 + e
+//   layer 1 (W [P, PH], KQ = PH / 4):    n = 64 bx + 32 (w & 1) + l32, k = (w >> 1) KQ + half KQ/2 + 8 j + e
+//                                                                         -> (((8 bx + w) NW1 + j) 64 + 32 half + l32) 8 + e
+// (rows past P of the last 64-column block stay zero: the destination is cleared first)
+__global__ void split_frame_order_kernel(const float* src, f16* hi, f16* lo, int N, int K, int layer) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= (size_t)N * K) return;
+  const int n = (int)(i / K), k = (int)(i % K);
+  size_t o;
+  if (layer == 0) {
+    const int K0H = K / 2, NW0 = K0H / 8;
+    const int w = n >> 5, l32 = n & 31, half = k / K0H, j = (k % K0H) >> 3, e = k & 7;
+    o = ((size_t)((w * NW0 + j) * 64 + 32 * half + l32)) * 8 + e;
+  } else {
+    const int KQ = K / 4, K1H = KQ / 2, NW1 = K1H / 8;
+    const int bx = n >> 6, wl = (n >> 5) & 1, l32 = n & 31, wh = k / KQ, half = (k % KQ) / K1H, j = (k % K1H) >> 3, e = k & 7;
+    o = ((size_t)(((8 * bx + 2 * wh + wl) * NW1 + j) * 64 + 32 * half + l32)) * 8 + e;
+  }
+  split_f16(src[i], hi[o], lo[o]);
+}
+void launch_split_frame_order(const float* src, f16* hi, f16* lo, int N, int K, int layer, hipStream_t st) {
+  const size_t n = (size_t)N * K;
+  if (n == 0 || src == nullptr) return;
+  hipLaunchKernelGGL(split_frame_order_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, src, hi, lo, N, K, layer);
+}
+
 __global__ void split_chunked_kernel(const float* src, f16* hi, f16* lo, int M, int K, int mpad) {
   const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= (size_t)M * K) return;

@@ -79,9 +79,10 @@ __device__ __forceinline__ void frame_body(FrameArgs g, float* lds, int bx, int 
     if (p0_wave) {
       const size_t o = (size_t)(wave * 32 + l32) * K0 + half * K0H;
       if constexpr (F16) {
-        gf16x8 *sh = (gf16x8*)(g.W0h + o), *sl = (gf16x8*)(g.W0l + o);
+        // (planes in lane order, decode_kernels.hip split_frame_order_kernel: piece (wave, j) = 64 x 16 bytes, one coalesced KiB)
+        gf16x8 *sh = (gf16x8*)g.W0h + (size_t)wave * NW0 * 64 + lane, *sl = (gf16x8*)g.W0l + (size_t)wave * NW0 * 64 + lane;
 #pragma unroll
-        for (int j = 0; j < NW0; ++j) { w0h[j] = sh[j]; w0l[j] = sl[j]; }
+        for (int j = 0; j < NW0; ++j) { w0h[j] = sh[j * 64]; w0l[j] = sl[j * 64]; }
       } else {
         gf32x4* src = (gf32x4*)(g.W0 + o);
 #pragma unroll
@@ -93,9 +94,10 @@ __device__ __forceinline__ void frame_body(FrameArgs g, float* lds, int bx, int 
   auto load_w1 = [&]() {
     const size_t o1 = (size_t)(n1 < g.P ? n1 : 0) * PH + (wave >> 1) * KQ + half * K1H;
     if constexpr (F16) {
-      gf16x8 *sh = (gf16x8*)(g.W1h + o1), *sl = (gf16x8*)(g.W1l + o1);
+      const size_t op = ((size_t)(bx * 8 + wave) * NW1) * 64 + lane;  // (lane order, as layer 0; columns past P are zero there)
+      gf16x8 *sh = (gf16x8*)g.W1h + op, *sl = (gf16x8*)g.W1l + op;
 #pragma unroll
-      for (int j = 0; j < NW1; ++j) { w1h[j] = sh[j]; w1l[j] = sl[j]; }
+      for (int j = 0; j < NW1; ++j) { w1h[j] = sh[j * 64]; w1l[j] = sl[j * 64]; }
     } else {
       gf32x4* src = (gf32x4*)(g.W1 + o1);
 #pragma unroll

@@ -290,6 +290,7 @@ void launch_add_vec(const float* a, const float* b, float* out, int n, hipStream
 void launch_copy(const float* src, float* dst, size_t n, hipStream_t st);
 void launch_split(const float* src, f16* hi, f16* lo, size_t n, hipStream_t st);
 // src [M, K] row-major -> split-fp16 planes in the chunked layout [K / 32][mpad][32] (common.h Seg3)
+void launch_split_frame_order(const float* src, f16* hi, f16* lo, int N, int K, int layer, hipStream_t st);  // PreNet planes, frame kernel's lane order
 void launch_split_chunked(const float* src, f16* hi, f16* lo, int M, int K, int mpad, hipStream_t st);
 // LSTM weight matrix src [4H, K] (PyTorch gate blocks i,f,g,o) -> chunked split-fp16 planes
 // [H / 16][K / 32][gate * 16 + unit % 16][32]  (step_bodies.h LoaderWLstm); needs H % 16 == 0, K % 32 == 0
