@@ -51,8 +51,16 @@ for kind, name in ((0, "frame || lstm_att"), (1, "attention || lstm_dec")):
             gi, go = us(3)[m], us(4)[m]
             ok = s[:, 3][m] > 0
             print(f"           gate reached {gi[ok].min():6.2f}..{gi[ok].max():6.2f} (mean {gi[ok].mean():6.2f})  passed {go[ok].min():6.2f}..{go[ok].max():6.2f} (mean {go[ok].mean():6.2f})")
+            if not merged and (s[:, 6][m] > 0).any() and (s[:, 7][m] > 0).any():  # K-loop progress marks
+                t16, t32 = us(6)[m], us(7)[m]
+                st_ = us(2)[m]
+                print(f"           K tile 16 at {t16.min():6.2f}..{t16.max():6.2f} (mean {t16.mean():6.2f}), tile 32 at {t32.min():6.2f}..{t32.max():6.2f} (mean {t32.mean():6.2f})")
+                slow = np.argsort(-gi)[:32]
+                fast = np.argsort(gi)[:32]
+                for nm, idx in (("32 slowest", slow), ("32 fastest", fast)):
+                    print(f"             {nm}: start {st_[idx].mean():5.2f}  ->t16 {(t16[idx]-st_[idx]).mean():5.2f}  ->t32 {(t32[idx]-t16[idx]).mean():5.2f}  ->gate {(gi[idx]-t32[idx]).mean():5.2f} us")
             ok2 = s[:, 6][m] > 0
-            if kind == 1 and ok2.any():  # (one-launch step: the decoder LSTM's h_att segment)
+            if merged and kind == 1 and ok2.any():  # (one-launch step: the decoder LSTM's h_att segment)
                 g2i, g2o = us(6)[m], us(7)[m]
                 print(f"           h_att gate reached {g2i[ok2].min():6.2f}..{g2i[ok2].max():6.2f} (mean {g2i[ok2].mean():6.2f})  passed {g2o[ok2].min():6.2f}..{g2o[ok2].max():6.2f} (mean {g2o[ok2].mean():6.2f})")
     per_cu = Counter()

@@ -147,6 +147,7 @@ struct NoGate {
   static constexpr int kAuxA = 0;
   int seg = -1, seg2 = -1;
   __device__ __forceinline__ void wait(int) const {}
+  __device__ __forceinline__ void mark(int) const {}
 };
 
 template <class Cfg, class LoaderA, class LoaderB, class Gate = NoGate>
@@ -320,6 +321,7 @@ __device__ __forceinline__ void gemm_tile(const LoaderA& la, const LoaderB& lb, 
       // big tiles: tile t has landed (fragments are read right after this barrier)
       wait_vmcnt<Cfg::kWaitCnt>();
       __builtin_amdgcn_s_barrier();       // the MFMA waves are done reading the stage tile t-1 occupied
+      if (wave8 == 4) gate.mark(t);       // (measurement only: time stamps of the K loop's progress, TTSDEC_STAMPS)
       gate_at(t + S - 1);
       if (dbg != 3) issue_tile();         // tile t+S-1 into that stage (dbg 3: measurement ablation)
     }

@@ -74,6 +74,13 @@ struct RoleGateT {
   Ctrl* ctrl;
   int kind;
   stamp_ptr st;  // (loaded by the caller, once: see common.h stamp)
+  // K-loop progress (measurement only): the time at K tiles 16 and 32, stamps 6 and 7 (the second gate's slots: not both at once)
+  __device__ __forceinline__ void mark(int t) const {
+    if (st != nullptr && seg2 < 0) {
+      if (t == 16) stamp(st, kind, 6, now_rt());
+      if (t == 32) stamp(st, kind, 7, now_rt());
+    }
+  }
   __device__ __forceinline__ void wait(int which) const {
     if (which == 1) {
       stamp(st, kind, 6, now_rt());
@@ -264,9 +271,16 @@ __device__ __forceinline__ void lstm_body(LstmArgs g, float* smem, int bx, int b
 // part: kAttnThreads / 64 * NJ * 256 floats of LDS (the caller's ONE shared array); b: the utterance.
 template <int NJ>
 __device__ __forceinline__ void attn_body(AttnArgs g, float* part, int b) {
+  // Rows that can carry weight at this step: the stepwise-monotonic update (attention.py:119-123) moves weight by at most one
+  // row per step from the one-hot start, so after t steps w_prev is EXACTLY zero beyond row t, w_new beyond row t + 1 - rows
+  // past that add exact zeros to the context and need neither their energies nor their memory (245 KB per utterance and step
+  // otherwise, all of it Infinity-Cache traffic beside the decoder LSTM's weight stream).  Known only with a control block
+  // (t counts from the utterance's first step); the wave ranges stay as they are, so every sum keeps its order.
+  int row_lim = g.L;
   if (g.ctrl != nullptr) {
     const Ctrl* c = g.ctrl;
     StepNow now = step_now(c, g.slot);
+    if (now.t + 2 < row_lim) row_lim = now.t + 2;
     if (g.live_lag) now.live = now.t < c->t_end && now.t - 1 <= c->stop_t;  // (a role of the one-launch step: see lstm_body)
     if (!now.live) return;
     g.memory = c->memory;
@@ -346,7 +360,7 @@ __device__ __forceinline__ void attn_body(AttnArgs g, float* part, int b) {
 
   const int chunk = (L + NW - 1) / NW;
   const int l0 = wv * chunk;
-  const int l1 = (l0 + chunk < L) ? l0 + chunk : L;
+  const int l1_all = (l0 + chunk < L) ? l0 + chunk : L;  // this wave's rows [l0, l1_all): all get their (possibly zero) weight stored
 
   float4 acc[NJ];
 #pragma unroll
@@ -355,8 +369,10 @@ __device__ __forceinline__ void attn_body(AttnArgs g, float* part, int b) {
   // The previous weights of this wave's rows, l0-1 .. l1-1, in ONE coalesced load (lane i holds w_prev[l0 - 1 + i]); the new
   // ones are gathered the same way and stored after the loop: a store inside the loop sits in the same in-order queue as the
   // next group's row loads, whose wait then also waits for the store.
-  const int nrows = l1 > l0 ? l1 - l0 : 0;
+  const int nrows = l1_all > l0 ? l1_all - l0 : 0;
   const bool lanes_hold_w = chunk < 64;  // (rows per wave + 1 <= 64 lanes; longer memories take the per-row accesses)
+  // ... of which [l0, l1) can be non-zero (the per-row store path of long memories walks all rows)
+  const int l1 = (lanes_hold_w && row_lim < l1_all) ? (row_lim > l0 ? row_lim : l0) : l1_all;
   float wp_lane = 0.f, wn_lane = 0.f;
   if (lanes_hold_w && lane <= nrows && l0 - 1 + lane >= 0 && l0 - 1 + lane < L) wp_lane = wprev[l0 - 1 + lane];
   auto w_prev_of = [&](int l) {  // l in [l0 - 1, l1): uniform
@@ -409,10 +425,10 @@ __device__ __forceinline__ void attn_body(AttnArgs g, float* part, int b) {
         }
       }
     }
-    if (lanes_hold_w && !g.ctx_only && lane < nrows) {
-      wnew[l0 + lane] = wn_lane;
-      if (wout) wout[l0 + lane] = wn_lane;
-    }
+  }
+  if (lanes_hold_w && !g.ctx_only && lane < nrows) {  // (all of the wave's rows: the ones past row_lim get their zero)
+    wnew[l0 + lane] = wn_lane;
+    if (wout) wout[l0 + lane] = wn_lane;
   }
   // cross-wave sum of the context partials in a fixed order (deterministic)
 #pragma unroll
