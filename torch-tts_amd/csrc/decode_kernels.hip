@@ -329,7 +329,7 @@ static void launch_gemm_cfg(const GemmArgs& a, hipStream_t st) {
     // (256x128 tiles for bf16 - TileCfg<2, 2, 1, 4, PREC_BF16, 0, 4, 2, 1> - were measured: 1.58 ms against 1.35 ms for
     // the Postnet at 256 x 600 frames.  Their 132-KiB output tile leaves one workgroup per CU where the 128x128 tile
     // fits two, and the second workgroup hides more latency than the bigger tile saves in staged bytes.)
-    // large 16-bit GEMMs (Postnet convs): 128x128 tiles, half-depth stages (see TileCfg)
+    // large 16-bit GEMMs (Postnet convs): 128x128 tiles
     if constexpr (PREC == PREC_F16S && AK == A_PLAIN && EK == EPI_GENERIC) {
       // short-K row GEMMs (the VITS2 1x1 convs, K = 192: six k32 tiles): the lean 64x64 tile, two workgroups per CU, so
       // that one workgroup's loads and stores run beside the other's MFMAs - on the 128x128 tile these launches were
@@ -343,7 +343,10 @@ static void launch_gemm_cfg(const GemmArgs& a, hipStream_t st) {
       }
     }
     if (a.N >= 128 && a.M >= 2048) {
-      using Cfg = TileCfg<2, 2, 1, 4, PREC, 0, 2, 2, 1>;
+      // 128x128 tiles, full-depth stages (64 k), double buffered: half the per-stage barriers of the four half-depth stages
+      // this ran on until round 3 for the same bytes in flight (Postnet 256 x 600: split-fp16 3.44 -> 3.32 ms, bf16 1.26 ->
+      // 1.19 ms, VITS2 flow 6.18 -> 6.13 ms, same box, bit-identical; profiles/r03_x_big_tile_full_depth.txt)
+      using Cfg = TileCfg<2, 2, 1, 2, PREC, 0, 2, 2, 0>;
       dim3 grid((a.N + Cfg::BN - 1) / Cfg::BN, (a.M + Cfg::BM - 1) / Cfg::BM);
       hipLaunchKernelGGL((gemm_rows_kernel<Cfg, AK, EK>), grid, dim3(kGemmThreads), 0, st, a);
       return;
