@@ -198,6 +198,7 @@ struct MhaArgs {
   float* out;            // [B*T, C]
   f16* out_p;            // optional split-fp16 planes of out (hi, then lo n_out halfs later)
   size_t n_out;          // B*T*C
+  int planes_only;       // flash kernel: 1 = write the planes only (their consumer, the output GEMM in split-fp16 mode, reads nothing else)
   int T, C, dk, window;
   float qscale;  // sqrt(dk): q is DIVIDED by it, as the reference does
 };
@@ -886,7 +887,7 @@ __global__ __launch_bounds__(kFaThreads, 2) void mha_flash_kernel(MhaArgs g) {
           f32x4 o;
 #pragma unroll
           for (int e = 0; e < 4; ++e) o[e] = fmaf(y2[dt][4 * gq + e], 1.0f / kSplitScale, y[dt][4 * gq + e]) * inv;
-          *reinterpret_cast<f32x4*>(orow + d0) = o;
+          if (!g.planes_only) *reinterpret_cast<f32x4*>(orow + d0) = o;  // (the output GEMM of split-fp16 mode reads the planes)
           if (g.out_p) {
             union { f16 h[4]; uint2 u; } hi, lo;
 #pragma unroll
@@ -919,7 +920,7 @@ __global__ void wn_gate_kernel(const float* xin, float* acts, f16* acts_p, int M
   float a = xin[m * 2 * H + c], s = xin[m * 2 * H + H + c];
   if (gl != nullptr) { a = add_rn(a, gl[(m / T) * ldg + c]); s = add_rn(s, gl[(m / T) * ldg + H + c]); }
   const float v = mul_rn(tanhf(a), sigmoid_f(s));
-  acts[i] = v;
+  if (acts != nullptr) acts[i] = v;  // (nullptr: the consumer - the res/skip GEMM in split-fp16 mode - reads the planes only)
   if (acts_p) split_f16(v, acts_p[i], acts_p[(size_t)M * H + i]);
 }
 // modules.WN.forward:201-208: not last: x = (x + rs[:, :H]) * mask; output += rs[:, H:]
@@ -979,7 +980,7 @@ __global__ void wn_gate4_kernel(const float* xin, float* acts, f16* acts_p, uint
   f32x4 v;
 #pragma unroll
   for (int e = 0; e < 4; ++e) v[e] = kFast ? mul_rn(tanh_fast(a[e]), sigmoid_fast(s[e])) : mul_rn(tanhf(a[e]), sigmoid_f(s[e]));
-  reinterpret_cast<f32x4*>(acts)[i] = v;
+  if (acts != nullptr) reinterpret_cast<f32x4*>(acts)[i] = v;  // (nullptr: see wn_gate_kernel)
   if (acts_p) split4_store(v, acts_p, (size_t)M * H4 * 4, i);
 }
 __global__ void wn_update4_kernel(float* x, float* output, const float* rs, const float* mask, f16* x_p, f16* out_p, uint32_t M, uint32_t H4,
@@ -1184,6 +1185,7 @@ int run_stack(ttsvits_handle* h, const StackBlob& sb, const StackDims& sd, const
                  nullptr, 1, T, st);
     MhaArgs a;
     a.qkv = sw.qkv; a.mask = mask; a.out = sw.att; a.out_p = sw.att_p; a.n_out = (size_t)M * C;
+    a.planes_only = (use_flash && sw.cx.split && sw.att_p != nullptr && !(C & 7)) ? 1 : 0;
     a.T = T; a.C = C; a.dk = dk; a.window = sd.window;
     a.ek = sd.window >= 0 ? blob + sb.ek[i] : nullptr; a.ev = sd.window >= 0 ? blob + sb.ev[i] : nullptr;
     a.qscale = sqrtf((float)dk);
@@ -1497,7 +1499,7 @@ int ttsvits_flow_reverse(ttsvits_handle* h, const float* z, const int32_t* lengt
       gemm_generic(fcx, hx, hx_p, Fh, Fh, blob + fb.in_w[j], (size_t)2 * Fh * d.flow_kernel * Fh, blob + fb.in_b[j], M, 2 * Fh, xin, nullptr, 2 * Fh, 0,
                    nullptr, nullptr, d.flow_kernel, T, st);
       const bool vec4 = Fh % 4 == 0 && (size_t)M * Fh < ((size_t)1 << 32);
-      if (vec4 && fcx.split) hipLaunchKernelGGL(wn_gate4_kernel<true>, grid1((size_t)M * Fh / 4), dim3(256), 0, st, xin, acts, acts_p, (uint32_t)M, (uint32_t)Fh / 4, gl, (uint32_t)T, (uint32_t)ncond);
+      if (vec4 && fcx.split) hipLaunchKernelGGL(wn_gate4_kernel<true>, grid1((size_t)M * Fh / 4), dim3(256), 0, st, xin, (Fh & 7) ? acts : (float*)nullptr, acts_p, (uint32_t)M, (uint32_t)Fh / 4, gl, (uint32_t)T, (uint32_t)ncond);
       else if (vec4) hipLaunchKernelGGL(wn_gate4_kernel<false>, grid1((size_t)M * Fh / 4), dim3(256), 0, st, xin, acts, acts_p, (uint32_t)M, (uint32_t)Fh / 4, gl, (uint32_t)T, (uint32_t)ncond);
       else hipLaunchKernelGGL(wn_gate_kernel, grid1((size_t)M * Fh), dim3(256), 0, st, xin, acts, acts_p, M, Fh, gl, T, ncond);
       const int cr = last ? Fh : 2 * Fh;
