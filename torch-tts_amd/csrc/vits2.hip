@@ -146,15 +146,18 @@ __global__ void frame_mask_kernel(const int* lengths, int T, float* mask, int M)
 
 // modules.LayerNorm (modules.py:24-27) over the channels of one frame; one wave per row.
 // out = LN(in) ; out_m = LN(in) * mask  (either may be nullptr)
+// NJ: 64-channel groups a lane walks (C <= 64 NJ; the 96- and 192-channel stacks of the VITS2 path take 2 and 4 instead of 16
+// predicated rounds per pass)
+template <int NJ>
 __global__ __launch_bounds__(256) void layernorm_rows_kernel(const float* in, const float* gamma, const float* beta, const float* mask,
                                                              float* out, float* out_m, f16* out_p, f16* outm_p, int M, int C, float eps) {
   const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
   if (row >= M) return;
   const float* x = in + (size_t)row * C;
-  float v[16];  // C <= 1024
+  float v[NJ];  // C <= 64 NJ
   float s = 0.f;
 #pragma unroll
-  for (int j = 0; j < 16; ++j) {
+  for (int j = 0; j < NJ; ++j) {
     const int c = lane + 64 * j;
     v[j] = c < C ? x[c] : 0.f;
     s += v[j];
@@ -163,7 +166,7 @@ __global__ __launch_bounds__(256) void layernorm_rows_kernel(const float* in, co
   const float mean = s / (float)C;
   float q = 0.f;
 #pragma unroll
-  for (int j = 0; j < 16; ++j) {
+  for (int j = 0; j < NJ; ++j) {
     const int c = lane + 64 * j;
     const float dlt = c < C ? v[j] - mean : 0.f;
     q += dlt * dlt;
@@ -172,7 +175,7 @@ __global__ __launch_bounds__(256) void layernorm_rows_kernel(const float* in, co
   const float rstd = 1.0f / sqrt_rn(add_rn(q / (float)C, eps));
   const float mk = mask ? mask[row] : 1.0f;
 #pragma unroll
-  for (int j = 0; j < 16; ++j) {
+  for (int j = 0; j < NJ; ++j) {
     const int c = lane + 64 * j;
     if (c < C) {
       const float y = add_rn(mul_rn(mul_rn(v[j] - mean, rstd), gamma[c]), beta[c]);
@@ -1153,6 +1156,14 @@ size_t mha_lds_bytes(int T, int dk, int window) {
 }
 constexpr size_t kMhaMaxLds = 150 * 1024;
 
+void launch_layernorm(const float* in, const float* gamma, const float* beta, const float* mask, float* out, float* out_m, f16* out_p,
+                      f16* outm_p, int M, int C, hipStream_t st) {
+  const dim3 grid((M + 3) / 4), block(256);
+  if (C <= 128) hipLaunchKernelGGL(layernorm_rows_kernel<2>, grid, block, 0, st, in, gamma, beta, mask, out, out_m, out_p, outm_p, M, C, 1e-5f);
+  else if (C <= 256) hipLaunchKernelGGL(layernorm_rows_kernel<4>, grid, block, 0, st, in, gamma, beta, mask, out, out_m, out_p, outm_p, M, C, 1e-5f);
+  else hipLaunchKernelGGL(layernorm_rows_kernel<16>, grid, block, 0, st, in, gamma, beta, mask, out, out_m, out_p, outm_p, M, C, 1e-5f);
+}
+
 // attentions.Encoder.forward (attentions.py:76-93), eval mode.  Input: sw.x = sw.xm = x * mask.
 // Result: sw.xm (= x * mask of the last layer).
 // gvec / cond_idx: the text encoder's speaker conditioning (add_spk_kernel), nullptr / -1 without.
@@ -1206,15 +1217,21 @@ int run_stack(ttsvits_handle* h, const StackBlob& sb, const StackDims& sd, const
     }
     // x = LayerNorm(x + conv_o(att))
     gemm_generic(sw.cx, sw.att, sw.att_p, C, C, blob + sb.wo[i], (size_t)C * C, blob + sb.bo[i], M, C, sw.t, nullptr, C, 0, nullptr, xa, 1, T, st);
-    hipLaunchKernelGGL(layernorm_rows_kernel, dim3((M + 3) / 4), dim3(256), 0, st, sw.t, blob + sb.g1[i], blob + sb.b1[i], mask, sw.x,
-                       sw.xm, sw.x_p, sw.xm_p, M, C, 1e-5f);
+    // (only the outputs somebody reads: x for the FFN's residual; x * mask as the FFN's input - its planes where conv_1 runs on
+    // planes (gemm_generic: split mode and C % 8 == 0), the fp32 form otherwise)
+    const bool pl = sw.cx.split && !(C & 7) && sw.xm_p != nullptr;
+    launch_layernorm(sw.t, blob + sb.g1[i], blob + sb.b1[i], mask, sw.x, pl ? (float*)nullptr : sw.xm, (f16*)nullptr,
+                     pl ? sw.xm_p : (f16*)nullptr, M, C, st);
     // FFN (attentions.py:411-419): conv_2(relu(conv_1(x * mask)) * mask) * mask, then x = LayerNorm(x + y)
     gemm_generic(sw.cx, sw.xm, sw.xm_p, C, C, blob + sb.w1[i], (size_t)sd.F * sd.kernel * C, blob + sb.c1[i], M, sd.F, sw.f, sw.f_p, sd.F, 1, mask,
                  nullptr, sd.kernel, T, st);
     gemm_generic(sw.cx, sw.f, sw.f_p, sd.F, sd.F, blob + sb.w2[i], (size_t)C * sd.kernel * sd.F, blob + sb.c2[i], M, C, sw.t, nullptr, C, 0, mask,
                  sw.x, sd.kernel, T, st);
-    hipLaunchKernelGGL(layernorm_rows_kernel, dim3((M + 3) / 4), dim3(256), 0, st, sw.t, blob + sb.g2[i], blob + sb.b2[i], mask, sw.x,
-                       sw.xm, sw.x_p, sw.xm_p, M, C, 1e-5f);
+    // (a layer in the middle hands the next one x and, where its QKV GEMM runs on planes, x's planes; the last layer hands the
+    // caller x * mask in both forms)
+    const bool last_layer = i == sd.layers - 1;
+    launch_layernorm(sw.t, blob + sb.g2[i], blob + sb.b2[i], mask, last_layer ? (float*)nullptr : sw.x, last_layer ? sw.xm : (float*)nullptr,
+                     (!last_layer && pl) ? sw.x_p : (f16*)nullptr, last_layer ? sw.xm_p : (f16*)nullptr, M, C, st);
   }
   (void)xin;
   return TTSDEC_OK;
