@@ -1176,6 +1176,22 @@ def test_two_role_launches_with_more_producers_than_the_chip_holds(H, prec, monk
         H.assert_argmax(w, ow, f"argmax overlap={lv} {prec}")
         outs[lv] = (y, s, w)
     # (no bitwise comparison between the levels: a gated LSTM walks its K segments in another order than the whole cell)
+    # 330 utterances on the defaults: level 2 with the query as a job of the attention role's 330 workgroups (all resident, lowest
+    # block ids), the decoder LSTM's workgroups arriving in two waves behind them
+    B2 = 330
+    mem2 = O.synthetic_memory(B2, 7, dims.d_ctx, lengths=[7] * (B2 - 2) + [3, 1], seed=12)
+    masks2 = O.synthetic_masks(T_, B2, dims.d_pre, seed=18)
+    oy2, os2, ow2 = O.decode(wts, dims, mem2, max_steps=T_ - 1, masks=masks2)
+    dec = H.make_decoder(dims, wts)
+    dec.precision = prec
+    y, s, w, fired = H.run_decoder_with_masks(dec, mem2, masks2, max_steps=T_ - 1)
+    assert not fired
+    if prec == "split_f16":
+        names = set(dec.engine(torch.device("cuda:0")).profile_step(mem2.cuda(), 1, 0, None, 0))
+        assert "query+attention+lstm_dec" in names, names
+    H.assert_close(y, oy2, RTOL, ATOL, f"y B=330 {prec}")
+    H.assert_close(s, os2, RTOL, ATOL, f"s B=330 {prec}")
+    H.assert_argmax(w, ow2, f"argmax B=330 {prec}")
 
 
 def test_set_option_on_a_live_handle_switches_the_launch_sequence(H):
