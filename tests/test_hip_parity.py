@@ -1235,8 +1235,8 @@ def test_role_timeout_flags_the_call_and_the_module_falls_back(H):
     memd = mem.cuda()
     for prec in ("f32", "split_f16"):
         for bit in (1, 2, 4, 8):  # the frame role / the attention role / the projection head role / the attention LSTM's tiles stay silent
-            if bit >= 4 and prec == "f32":
-                continue  # (the head role and the one-launch step exist in split-fp16 mode only)
+            if bit == 8 and prec == "f32":
+                continue  # (the one-launch step exists in split-fp16 mode only)
             dec = H.make_decoder(dims, wts)
             dec.precision = prec
             eng = dec.engine(torch.device("cuda:0"))

@@ -144,12 +144,17 @@ inline int query_split(const ttsdec_dims& d) { return split_of(query_k(d), query
 // covers the shape: whole 8-element groups in every K segment, K slices of whole 128-element blocks; else the LDS-staged
 // split-K GEMM.  Measured, proj launch / step in the loop: B = 256 5.0 / 83.6 us against 6.7 / 84.1, B = 1 4.3 / 46.9
 // against 5.5 / 47.9; exact fp32 (64-cycle MFMAs, 8 per k16 step) 7.0 against 6.4 - so split-fp16 only.
-inline bool proj_regw(const ttsdec_handle* h, int prec) {
+// (Exact fp32 takes it where the projection then becomes the head role of the next step's first launch - batches with the
+// two-role launches: the role's 7 us hide under the fp32 attention LSTM's 48-us stream and the step loses the projection's own
+// launch: 128.6 -> 121.4 us per step at B = 256, 56.2 -> 54.4 at B = 32, 54.0 -> 50.2 at B = 1; profiles/r03_w_fp32_head_proj.txt.)
+int overlap_level(const ttsdec_handle* h, int B);
+inline bool proj_regw(const ttsdec_handle* h, int prec, int B) {
   const ttsdec_dims& d = h->d;
-  return prec && h->proj_regw && use_frame(d) && !((d.h_att | d.h_dec | d.d_ctx) & 7) && proj_split(proj_k(d)) > 0 && proj_n(d) <= 192;
+  if (!(h->proj_regw && use_frame(d) && !((d.h_att | d.h_dec | d.d_ctx) & 7) && proj_split(proj_k(d)) > 0 && proj_n(d) <= 192)) return false;
+  return prec || (overlap_level(h, B) >= 1 && h->head_proj != 0);
 }
-inline int proj_parts(const ttsdec_handle* h, int prec) {
-  return proj_regw(h, prec) ? proj_split(proj_k(h->d)) : split_of(proj_k(h->d), kProjSplit);
+inline int proj_parts(const ttsdec_handle* h, int prec, int B) {
+  return proj_regw(h, prec, B) ? proj_split(proj_k(h->d)) : split_of(proj_k(h->d), kProjSplit);
 }
 
 BlobLayout make_blob_layout(const ttsdec_dims& d) {
@@ -425,7 +430,7 @@ void launch_node(const ttsdec_handle* h, const StepBufs& sb, const StepIo& io, N
     FrameArgs f;
     memset(&f, 0, sizeof(f));
     const int Ph = pre_hidden(d);
-    f.parts = sb.jparts; f.n_parts = proj_parts(h, prec); f.ldp = proj_ldp(d);
+    f.parts = sb.jparts; f.n_parts = proj_parts(h, prec, B); f.ldp = proj_ldp(d);
     f.part_stride = (size_t)B * proj_ldp(d);
     f.proj_bias = blob + bl.proj_b;
     f.y_out = io.y; f.s_out = io.s; f.ynext = sb.ynext;
@@ -568,7 +573,7 @@ void launch_node(const ttsdec_handle* h, const StepBufs& sb, const StepIo& io, N
     pa.a = act(make_seg2(sb.h_dec_h[1 - pp], Hd, Hd, sb.ctx_h, D, D));
     pa.a_lo = act(make_seg2(sb.h_dec_l[1 - pp], Hd, Hd, sb.ctx_l, D, D));
     pa.W = plane(bl.proj_h); pa.W_lo = plane(bl.proj_l); pa.ldw = proj_ld(d); pa.prec = PREC_F16S;
-    pa.M = B; pa.N = proj_n(d); pa.K = proj_k(d); pa.ksplit = proj_parts(h, prec); pa.split_stride = (size_t)B * proj_ldp(d);
+    pa.M = B; pa.N = proj_n(d); pa.K = proj_k(d); pa.ksplit = proj_parts(h, prec, B); pa.split_stride = (size_t)B * proj_ldp(d);
     pa.out = sb.jparts; pa.ldo = proj_ldp(d); pa.ctrl = ctrl; pa.slot = io.slot; pa.node = io.node_pos;
     pa.mode = mode;
     return pa;
@@ -707,11 +712,11 @@ void launch_node(const ttsdec_handle* h, const StepBufs& sb, const StepIo& io, N
           g.a_lo = act(make_seg2(sb.h_dec_l[1 - p], Hd, Hd, sb.ctx_l, D, D));
         }
       }
-      if (proj_regw(h, prec)) {  // (same slabs, from the kernel that keeps its weight fragments in registers)
+      if (proj_regw(h, prec, B)) {  // (same slabs, from the kernel that keeps its weight fragments in registers)
         ProjArgs pa;
         memset(&pa, 0, sizeof(pa));
         pa.a = g.a; pa.a_lo = g.a_lo; pa.W = g.W; pa.W_lo = g.W_lo; pa.ldw = g.ldw; pa.prec = g.prec;
-        pa.M = B; pa.N = g.N; pa.K = g.K; pa.ksplit = proj_parts(h, prec); pa.split_stride = (size_t)B * proj_ldp(d);
+        pa.M = B; pa.N = g.N; pa.K = g.K; pa.ksplit = proj_parts(h, prec, B); pa.split_stride = (size_t)B * proj_ldp(d);
         pa.out = sb.jparts; pa.ldo = proj_ldp(d); pa.ctrl = ctrl; pa.slot = io.slot; pa.node = io.node_pos;
         pa.mode = node == N_JFA ? PROJ_HEAD : (node == N_JFIN ? PROJ_FINAL : PROJ_STEP);
         if (node == N_JFA) {
@@ -776,7 +781,7 @@ int overlap_level(const ttsdec_handle* h, int B) {
 // us per step without / with it, same box: B = 1 43.0 / 39.8, B = 64 51.8 / 50.1, B = 128 54.2 / 53.5, B = 256 73.4 / 73.3 (there
 // the frame role's chain is what the launch waits for, and it grows by what the projection's own launch cost).
 bool head_proj(const ttsdec_handle* h, int B) {
-  if (!overlap_level(h, B) || !proj_regw(h, lstm_prec(h))) return false;
+  if (!overlap_level(h, B) || !proj_regw(h, lstm_prec(h), B)) return false;
   return h->head_proj != 0;  // (-1 = default = on)
 }
 // The query as a job of the attention role (fused_kernels.hip attn_lstm_kernel): needs every attention-role workgroup resident
