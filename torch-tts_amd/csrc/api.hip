@@ -753,6 +753,8 @@ const StepOrder kOrderTaco2 = {7, {N_P0, N_P1, N_A, N_D, N_Q, N_T, N_J},  // dec
 const StepOrder kOrderProdF = {6, {N_F, N_A, N_Q, N_T, N_D, N_J}, {"prenet", "lstm_att", "query", "attention", "lstm_dec", "proj"}};
 const StepOrder kOrderTaco2F = {6, {N_F, N_A, N_D, N_Q, N_T, N_J}, {"prenet", "lstm_att", "lstm_dec", "query", "attention", "proj"}};
 const StepOrder kOrderProdO = {5, {N_FA, N_Q, N_T, N_D, N_J}, {"prenet+lstm_att", "query", "attention", "lstm_dec", "proj"}};
+const StepOrder kOrderTaco2O = {5, {N_FA, N_D, N_Q, N_T, N_J}, {"prenet+lstm_att", "lstm_dec", "query", "attention", "proj"}};
+const StepOrder kOrderTaco2H = {4, {N_JFA, N_D, N_Q, N_T}, {"proj+prenet+lstm_att", "lstm_dec", "query", "attention"}};
 const StepOrder kOrderProdO2 = {4, {N_FA, N_Q, N_TD, N_J}, {"prenet+lstm_att", "query", "attention+lstm_dec", "proj"}};
 // ... with step t-1's projection at the head of step t's first launch
 const StepOrder kOrderProdH = {4, {N_JFA, N_Q, N_T, N_D}, {"proj+prenet+lstm_att", "query", "attention", "lstm_dec"}};
@@ -765,7 +767,17 @@ const StepOrder kOrderProdS = {1, {N_STEP}, {"step"}};
 // the two-role step: LJSpeech-type cell, either arithmetic mode
 int overlap_level(const ttsdec_handle* h, int B) {
   const ttsdec_dims& d = h->d;
-  if (is_taco2(d) || !fused_supported(d.d_mel, d.r, pre_hidden(d), d.d_pre, d.d_ctx)) return 0;
+  if (!fused_supported(d.d_mel, d.r, pre_hidden(d), d.d_pre, d.d_ctx)) return 0;
+  if (is_taco2(d)) {
+    // Taco2DecoderCell (decoder_cell.py:116-136): its attention pass FOLLOWS both LSTMs, so only the first two-role launch
+    // applies - frame || lstm_att, with the projection (which reads the two LSTM states there, not the context) as its head
+    // role.  rdh config, us per step without / with (profiles/r03_w_taco2_level1.txt): split-fp16 B = 256 92.3 / 80.7, B = 64
+    // 60.5 / 52.8, B = 1 54.6 / 46.9; exact fp32 B = 256 147.2 / 137.1, B = 64 73.0 / 80.6, B = 1 69.3 / 59.3 - the fp32 rule of the
+    // other cell: not in the middle batch range.
+    if (h->overlap >= 0) return h->overlap > 1 ? 1 : h->overlap;
+    if (lstm_prec(h)) return 1;
+    return (B <= 32 || B >= 192) ? 1 : 0;
+  }
   if (h->overlap >= 0) return h->overlap;
   // Round 3 (after the sc1 hand-offs and the per-row-block counters; profiles/r03_t_levels_sweep.txt, us per step, levels 0 / 1 / 2):
   // split-fp16 B = 96 78.3 / 62.4 / 48.8, 192 80.1 / 64.8 / 59.3, 320 128.5 / 102.5 / 88.8, 384 131.1 / 110.0 / 98.3, 512 147.7 / 131.6 /
@@ -812,6 +824,7 @@ bool step_merged(const ttsdec_handle* h, int B) {
 const StepOrder& step_order(const ttsdec_handle* h, int B) {
   const ttsdec_dims& d = h->d;
   if (const int lv = overlap_level(h, B)) {
+    if (is_taco2(d)) return head_proj(h, B) ? kOrderTaco2H : kOrderTaco2O;
     if (step_merged(h, B)) return kOrderProdS;
     if (lv >= 2 && query_role(h, B)) return head_proj(h, B) ? kOrderProdH2Q : kOrderProdO2Q;
     if (head_proj(h, B)) return lv >= 2 ? kOrderProdH2 : kOrderProdH;
