@@ -1253,13 +1253,14 @@ def test_role_timeout_flags_the_call_and_the_module_falls_back(H):
             dec.dropout_source = "off"
             with pytest.warns(RuntimeWarning, match="producer role"), torch.no_grad():
                 y2, s2, w2 = dec(memd, None, None, max_steps=T_ - 1)
-            assert eng.get_option("overlap") == 0
+            assert eng.get_option("overlap") == 0 and eng.get_option("head_proj") == 0
             H.assert_close(y2.cpu(), ny, RTOL, ATOL, f"y after the fallback ({prec}, bit {bit})")
             H.assert_argmax(w2.cpu(), nw, "argmax after the fallback")
             # the hook off again, two-role launches back on: the same handle decodes correctly
             eng.set_option("debug_flags", 0)
             eng.set_option("spin_limit", -1)
             eng.set_option("overlap", 2)
+            eng.set_option("head_proj", -1)
             y3, s3, w3, fired = H.run_decoder_with_masks(dec, mem, masks, max_steps=T_ - 1)
             H.assert_close(y3, oy, RTOL, ATOL, "y after a timed-out call")
             H.assert_argmax(w3, ow, "argmax after a timed-out call")

@@ -147,11 +147,13 @@ inline int query_split(const ttsdec_dims& d) { return split_of(query_k(d), query
 // (Exact fp32 takes it where the projection then becomes the head role of the next step's first launch - batches with the
 // two-role launches: the role's 7 us hide under the fp32 attention LSTM's 48-us stream and the step loses the projection's own
 // launch: 128.6 -> 121.4 us per step at B = 256, 56.2 -> 54.4 at B = 32, 54.0 -> 50.2 at B = 1; profiles/r03_w_fp32_head_proj.txt.)
-int overlap_level(const ttsdec_handle* h, int B);
-inline bool proj_regw(const ttsdec_handle* h, int prec, int B) {
+inline bool proj_regw_shapes(const ttsdec_handle* h) {
   const ttsdec_dims& d = h->d;
-  if (!(h->proj_regw && use_frame(d) && !((d.h_att | d.h_dec | d.d_ctx) & 7) && proj_split(proj_k(d)) > 0 && proj_n(d) <= 192)) return false;
-  return prec || (overlap_level(h, B) >= 1 && h->head_proj != 0);
+  return h->proj_regw && use_frame(d) && !((d.h_att | d.h_dec | d.d_ctx) & 7) && proj_split(proj_k(d)) > 0 && proj_n(d) <= 192;
+}
+inline bool proj_regw(const ttsdec_handle* h, int prec, int B) {
+  (void)B;
+  return proj_regw_shapes(h) && (prec || h->head_proj != 0);  // (exact fp32: as a head role - head_proj() - only)
 }
 inline int proj_parts(const ttsdec_handle* h, int prec, int B) {
   return proj_regw(h, prec, B) ? proj_split(proj_k(h->d)) : split_of(proj_k(h->d), kProjSplit);
@@ -374,7 +376,8 @@ struct StepIo {
 // role at its head (then no N_J in the step), N_JFIN = the projection of a call's last step.
 // N_QTD = N_TD whose attention-role workgroups first compute the query GEMM between them (then no N_Q in the step).
 // N_STEP = N_JFA + N_QTD as one launch.
-enum Node { N_F, N_FIN, N_P0, N_P1, N_A, N_Q, N_T, N_D, N_J, N_FA, N_TD, N_AG, N_DG, N_JFA, N_JFIN, N_QTD, N_STEP };
+// N_JF = [proj(t-1) | frame] as one launch (no LSTM role).
+enum Node { N_F, N_FIN, N_P0, N_P1, N_A, N_Q, N_T, N_D, N_J, N_FA, N_TD, N_AG, N_DG, N_JFA, N_JFIN, N_QTD, N_STEP, N_JF };
 // PART_GATED: the whole cell with the segment that waits for the other role of the launch LAST
 enum LstmPart { PART_WHOLE = 0, PART_EARLY = 1, PART_LATE = 2, PART_GATED = 3 };
 
@@ -689,11 +692,13 @@ void launch_node(const ttsdec_handle* h, const StepBufs& sb, const StepIo& io, N
       break;
     }
     case N_JFA:
+    case N_JF:
     case N_JFIN:
     case N_J: {
       // N_J: at the end of step t (buffer parity p).  N_JFA: the same GEMM for step t-1, at the head of step t's launch -
       // step t-1's outputs are this step's "previous" buffers.  N_JFIN: io.slot carries the last step's parity.
-      const int p = node == N_JFA ? 1 - ((io.use_ctrl ? io.slot : io.t) & 1) : ((io.use_ctrl ? io.slot : io.t) & 1);
+      const bool head = node == N_JFA || node == N_JF;
+      const int p = head ? 1 - ((io.use_ctrl ? io.slot : io.t) & 1) : ((io.use_ctrl ? io.slot : io.t) & 1);
       GemmArgs g;
       memset(&g, 0, sizeof(g));
       // projection input: cat[h_dec, ctx] (Prod, decoder_cell.py:192) or cat[h0, h1, zeros] (Taco2, :136)
@@ -718,12 +723,17 @@ void launch_node(const ttsdec_handle* h, const StepBufs& sb, const StepIo& io, N
         pa.a = g.a; pa.a_lo = g.a_lo; pa.W = g.W; pa.W_lo = g.W_lo; pa.ldw = g.ldw; pa.prec = g.prec;
         pa.M = B; pa.N = g.N; pa.K = g.K; pa.ksplit = proj_parts(h, prec, B); pa.split_stride = (size_t)B * proj_ldp(d);
         pa.out = sb.jparts; pa.ldo = proj_ldp(d); pa.ctrl = ctrl; pa.slot = io.slot; pa.node = io.node_pos;
-        pa.mode = node == N_JFA ? PROJ_HEAD : (node == N_JFIN ? PROJ_FINAL : PROJ_STEP);
-        if (node == N_JFA) {
+        pa.mode = head ? PROJ_HEAD : (node == N_JFIN ? PROJ_FINAL : PROJ_STEP);
+        if (head) {
           FrameArgs f = frame_args(false);
           f.dep_signal = 1; f.dep_cnt = dep(DEP_FRAME);
           pa.dep_cnt = f.wait_cnt = dep(DEP_PROJ);
           f.wait_n = proj_grid_size(32, pa.N, pa.ksplit);  // (the projection workgroups of one 32-row block)
+          if (node == N_JF) {  // no LSTM role behind the frame role: nobody to signal
+            f.dep_signal = 0;
+            launch_proj_frame(pa, f, st);
+            break;
+          }
           launch_proj_frame_lstm(pa, f, lstm_args(0, PART_GATED), st);
         } else {
           launch_proj(pa, st);
@@ -753,6 +763,9 @@ const StepOrder kOrderTaco2 = {7, {N_P0, N_P1, N_A, N_D, N_Q, N_T, N_J},  // dec
 const StepOrder kOrderProdF = {6, {N_F, N_A, N_Q, N_T, N_D, N_J}, {"prenet", "lstm_att", "query", "attention", "lstm_dec", "proj"}};
 const StepOrder kOrderTaco2F = {6, {N_F, N_A, N_D, N_Q, N_T, N_J}, {"prenet", "lstm_att", "lstm_dec", "query", "attention", "proj"}};
 const StepOrder kOrderProdO = {5, {N_FA, N_Q, N_T, N_D, N_J}, {"prenet+lstm_att", "query", "attention", "lstm_dec", "proj"}};
+// ... and where one role per launch stays the rule: the projection at the head of the frame kernel's launch
+const StepOrder kOrderProdHF = {5, {N_JF, N_A, N_Q, N_T, N_D}, {"proj+prenet", "lstm_att", "query", "attention", "lstm_dec"}};
+const StepOrder kOrderTaco2HF = {5, {N_JF, N_A, N_D, N_Q, N_T}, {"proj+prenet", "lstm_att", "lstm_dec", "query", "attention"}};
 const StepOrder kOrderTaco2O = {5, {N_FA, N_D, N_Q, N_T, N_J}, {"prenet+lstm_att", "lstm_dec", "query", "attention", "proj"}};
 const StepOrder kOrderTaco2H = {4, {N_JFA, N_D, N_Q, N_T}, {"proj+prenet+lstm_att", "lstm_dec", "query", "attention"}};
 const StepOrder kOrderProdO2 = {4, {N_FA, N_Q, N_TD, N_J}, {"prenet+lstm_att", "query", "attention+lstm_dec", "proj"}};
@@ -792,9 +805,12 @@ int overlap_level(const ttsdec_handle* h, int B) {
 // The projection as the head role of the next step's frame launch, wherever the register-weight kernel applies (split-fp16).
 // us per step without / with it, same box: B = 1 43.0 / 39.8, B = 64 51.8 / 50.1, B = 128 54.2 / 53.5, B = 256 73.4 / 73.3 (there
 // the frame role's chain is what the launch waits for, and it grows by what the projection's own launch cost).
+// Round 3: also where the step runs one role per launch (N_JF: [proj | frame]) - us per step without / with it
+// (profiles/r03_w_head_proj_level0.txt): exact fp32 B = 64 76.5 / 74.7, B = 128 103.0 / 100.9; sandra config (two frames per
+// step) 63.4 / 63.3, B = 1 44.3 / 44.1 - the hop costs there what the launch did.
 bool head_proj(const ttsdec_handle* h, int B) {
-  if (!overlap_level(h, B) || !proj_regw(h, lstm_prec(h), B)) return false;
-  return h->head_proj != 0;  // (-1 = default = on)
+  (void)B;
+  return proj_regw_shapes(h) && h->head_proj != 0;  // (-1 = default = on)
 }
 // The query as a job of the attention role (fused_kernels.hip attn_lstm_kernel): needs every attention-role workgroup resident
 // at once - one per utterance; they have the launch's lowest block ids, so that is at most the chip's 512 slots - and whole K
@@ -830,6 +846,7 @@ const StepOrder& step_order(const ttsdec_handle* h, int B) {
     if (head_proj(h, B)) return lv >= 2 ? kOrderProdH2 : kOrderProdH;
     return lv >= 2 ? kOrderProdO2 : kOrderProdO;
   }
+  if (use_frame(d) && head_proj(h, B)) return is_taco2(d) ? kOrderTaco2HF : kOrderProdHF;
   if (use_frame(d)) return is_taco2(d) ? kOrderTaco2F : kOrderProdF;
   return is_taco2(d) ? kOrderTaco2 : kOrderProd;
 }

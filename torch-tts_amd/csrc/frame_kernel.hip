@@ -45,6 +45,44 @@ void launch_proj(const ProjArgs& a, hipStream_t st) {
   else hipLaunchKernelGGL(proj_kernel<PREC_F32>, grid, block, 0, st, a);
 }
 
+// [proj(t-1) | frame(t)]: the projection as a head role of the FRAME kernel's own launch - the form of fused_kernels.hip's
+// three-role launch for configurations that run one role per launch otherwise (exact fp32 in the middle batch range, two frames
+// per step): the step still loses the projection's launch.  Projection workgroups have the lowest block ids and wait for
+// nothing; a frame workgroup waits for the projection workgroups of its 32-row block (frame_body kHead).
+template <int K0H, int PH, int PREC, int NI>
+__global__ __launch_bounds__(kFrameThreads) void proj_frame_kernel(ProjArgs pj, FrameArgs g, int n_proj, int frame_cols) {
+  loop_stamp(g.ctrl, g.slot, g.node);
+  constexpr int kF = FrameLds<K0H, PH, PREC>::kFloats;
+  __shared__ __attribute__((aligned(16))) float lds[kF > kProjLdsFloats ? kF : kProjLdsFloats];
+  int id = blockIdx.x;
+  if (id < n_proj) {
+    proj_body<PREC>(pj, lds, id);
+    return;
+  }
+  id -= n_proj;
+  frame_body<K0H, PH, PREC, NI, false, true>(g, lds, id % frame_cols, id / frame_cols);
+}
+
+void launch_proj_frame(const ProjArgs& pj, const FrameArgs& a, hipStream_t st) {
+  if (a.M <= 0) return;
+  const int cols = (a.P + kFrameCols - 1) / kFrameCols, n_frame = cols * ((a.M + kFrameRows - 1) / kFrameRows);
+  const int n_proj = proj_grid_size(pj.M, pj.N, pj.ksplit);
+  dim3 grid(n_proj + n_frame), block(kFrameThreads);
+  const bool few = a.r * a.d_mel + a.r <= 16 * 6;
+  auto go = [&](auto ni) {
+    constexpr int NI = decltype(ni)::value;
+    if (a.prec == PREC_F16S) {
+      if (a.Ph == 256) hipLaunchKernelGGL((proj_frame_kernel<40, 256, PREC_F16S, NI>), grid, block, 0, st, pj, a, n_proj, cols);
+      else hipLaunchKernelGGL((proj_frame_kernel<40, 128, PREC_F16S, NI>), grid, block, 0, st, pj, a, n_proj, cols);
+    } else {
+      if (a.Ph == 256) hipLaunchKernelGGL((proj_frame_kernel<40, 256, PREC_F32, NI>), grid, block, 0, st, pj, a, n_proj, cols);
+      else hipLaunchKernelGGL((proj_frame_kernel<40, 128, PREC_F32, NI>), grid, block, 0, st, pj, a, n_proj, cols);
+    }
+  };
+  if (few) go(std::integral_constant<int, 6>{});
+  else go(std::integral_constant<int, kFrameMaxNI>{});
+}
+
 bool frame_supported(int d_mel, int r, int Ph, int P) {
   return d_mel == 80 && (Ph == 256 || Ph == 128) && P % 4 == 0 && r * d_mel + r <= 16 * kFrameMaxNI;
 }

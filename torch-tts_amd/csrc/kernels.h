@@ -236,6 +236,7 @@ struct ProjArgs {
 enum ProjMode { PROJ_STEP = 0, PROJ_HEAD = 1, PROJ_FINAL = 2, PROJ_QUERY = 3 };
 int proj_split(int K);  // the ksplit of this kernel for K, or 0 when it does not cover K
 void launch_proj(const ProjArgs& a, hipStream_t st);
+void launch_proj_frame(const ProjArgs& pj, const FrameArgs& f, hipStream_t st);  // [proj(t-1) | frame(t)] as one launch (frame_kernel.hip)
 
 // ---- two-role launches (fused_kernels.hip): a latency-bound kernel and the early part of the next LSTM ----
 // The LstmArgs must be a split-fp16 cell with M >= 192 whose gated K segment (dep_seg) comes last; its gate GEMM

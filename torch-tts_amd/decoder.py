@@ -156,9 +156,10 @@ class Decoder(PackedWeightsMixin, nn.Module):
             # call restarts from its inputs: switch this engine to one role per launch and run the call again.
             import warnings
 
-            warnings.warn("decode step: a two-role launch timed out waiting for its producer role; "
-                          "this engine now runs one role per launch (option overlap = 0) and the call is repeated", RuntimeWarning)
+            warnings.warn("decode step: a multi-role launch timed out waiting for its producer role; "
+                          "this engine now runs one role per launch (options overlap = 0, head_proj = 0) and the call is repeated", RuntimeWarning)
             eng.set_option("overlap", 0)
+            eng.set_option("head_proj", 0)  # (the projection would otherwise stay a role at the head of the frame kernel's launch)
             if stream is not None:
                 stream.restart()
             out = run()
