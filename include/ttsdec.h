@@ -15,8 +15,10 @@
  *   - the caller owns every buffer (weights blob, workspace, inputs, outputs); the
  *     library allocates nothing on the device and keeps only the pointers bound with
  *     ttsdec_bind_weights().
- *   - all work is enqueued on the hipStream_t passed in (as void*); no hidden
- *     synchronisation.  Calls on one handle must be serialised by the caller.
+ *   - all work is enqueued on the hipStream_t passed in (as void*); nothing on the decode / postnet / encoder / VITS2 paths
+ *     synchronises.  The two exceptions are set-up calls and say so below: ttsdec_pack_weights (one stream synchronisation +
+ *     an 8-byte read-back for the range guard) and ttsdec_bind_weights (a synchronous 8-byte copy of the same header).
+ *     Calls on one handle must be serialised by the caller.
  *   - return value: 0 = TTSDEC_OK, negative = error (ttsdec_strerror()).  Nothing
  *     throws or aborts across this boundary.
  *   - the handle is bound to the HIP device that was current at ttsdec_create();
@@ -32,7 +34,10 @@
 extern "C" {
 #endif
 
-#define TTSDEC_VERSION 1
+/* ABI version: bumped whenever an entry point's argument list or a struct layout changes.  2 (round 4): ttsenc_forward /
+ * ttsvits_text_encoder / ttsvits_flow_reverse carry `g` and a status word, ttsvits_dims two more fields (round 3, unversioned
+ * then).  The Python binding refuses a library whose ttsdec_version() differs from the version it was written for. */
+#define TTSDEC_VERSION 2
 
 enum {
   TTSDEC_OK = 0,
@@ -190,7 +195,7 @@ enum {
   TTSDEC_OPT_DEBUG_FLAGS,      /* "debug_flags": TEST HOOK. bit 0 / 1 / 2 / 3: the frame / attention / projection-head role of a
                                 * two-role launch / the attention LSTM's tiles of the one-launch step do not signal their
                                 * consumers, which then run into the bounded-spin time-out (T_out[1] bit 2)                   */
-  TTSDEC_OPT_SPIN_LIMIT,       /* "spin_limit": TEST HOOK. polls before a consumer role gives up (default 65536, ~30 ms)       */
+  TTSDEC_OPT_SPIN_LIMIT,       /* "spin_limit": TEST HOOK. polls before a consumer role gives up (default 4096, ~1-4 ms)         */
   TTSDEC_OPT_COUNT
 };
 int ttsdec_set_option(ttsdec_handle* h, int option, int value);

@@ -1219,6 +1219,44 @@ def test_set_option_on_a_live_handle_switches_the_launch_sequence(H):
         eng.set_option("no_such_option", 1)
 
 
+def test_role_timeout_at_the_default_spin_limit_is_bounded_in_time(H):
+    """A call whose producer role never signals costs about ONE spin limit, not steps x gates of them (common.h role_poll: once
+    Ctrl::range_err bit 1 is set every later gate of the call returns at once).  Default spin limit (~1-4 ms), a 256-step chunk
+    (Decoder.forward's chunk_steps): the whole call, flag read-back included, stays far below a second.  Round 3's limit
+    (2^17 polls per gate, no short-circuit) would have spun for tens of seconds here."""
+    import time
+    from torch_tts_amd import _lib
+    dims = O.DecoderDims(d_mel=80, d_pre=128, d_ctx=64, h_att=128, h_dec=192)
+    wts = O.random_decoder_weights(dims, seed=4, nonzero_init_state=True)
+    B, T_ = 70, 256
+    memd = O.synthetic_memory(B, 9, dims.d_ctx, seed=3).cuda()
+    for prec in ("f32", "split_f16"):
+        dec = H.make_decoder(dims, wts)
+        dec.precision = prec
+        eng = dec.engine(torch.device("cuda:0"))
+        eng.set_option("overlap", 2)
+        y = torch.empty(B, T_, 80, device="cuda"); s = torch.empty(B, T_, device="cuda"); w = torch.empty(B, T_, 9, device="cuda")
+        t_out = torch.zeros(2, dtype=torch.int32, device="cuda")
+
+        def call():
+            eng.decode(memd, t_begin=0, n_steps=T_, stop_threshold=-2.0, check_stop=True, dropout_mode=_lib.DROPOUT_OFF, masks=None,
+                       seed=0, teacher=None, teacher_flags=None, y=y, s=s, w=w, t_out=t_out)
+            torch.cuda.synchronize()
+
+        call()  # (graph capture, code load)
+        assert t_out.tolist()[1] & 4 == 0
+        eng.set_option("debug_flags", 1)  # the frame role stays silent: every attention-LSTM workgroup runs into its gate
+        call()  # (the option dropped the graph: capture again outside the timed call)
+        t0 = time.perf_counter()
+        call()
+        dt = time.perf_counter() - t0
+        assert t_out.tolist()[1] & 4, (prec, t_out.tolist())
+        assert dt < 0.5, f"a timed-out {T_}-step call took {dt:.2f} s ({prec})"
+        eng.set_option("debug_flags", 0)
+        call()
+        assert t_out.tolist() == [T_, 0]
+
+
 def test_role_timeout_flags_the_call_and_the_module_falls_back(H):
     """The bounded spin of the two-role launches (common.h role_wait): a producer role that never signals (test hook
     TTSDEC_OPT_DEBUG_FLAGS) makes the consumers give up - T_out[1] bit 2, the grid drains - and Decoder.forward does

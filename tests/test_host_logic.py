@@ -23,7 +23,7 @@ def test_library_exports_every_declared_symbol():
     lib = _lib.load()
     for sym in declared:
         assert hasattr(lib, sym), sym
-    assert lib.ttsdec_version() == 1
+    assert lib.ttsdec_version() == _lib.ABI_VERSION == 2
     assert lib.ttsdec_strerror(0) == b"ok"
     assert b"multiples of 4" in lib.ttsdec_strerror(_lib.ERR_DIMS)
 

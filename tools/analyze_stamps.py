@@ -55,6 +55,13 @@ for kind, name in ((0, "frame || lstm_att"), (1, "attention || lstm_dec")):
                 t16, t32 = us(6)[m], us(7)[m]
                 st_ = us(2)[m]
                 print(f"           K tile 16 at {t16.min():6.2f}..{t16.max():6.2f} (mean {t16.mean():6.2f}), tile 32 at {t32.min():6.2f}..{t32.max():6.2f} (mean {t32.mean():6.2f})")
+                if a.shape[0] > kind + 3:  # shader-clock readings at the same two points
+                    c = a[kind + 3][used][m]
+                    okc = (c[:, 0] > 0) & (c[:, 1] > c[:, 0])
+                    if okc.any():
+                        ghz = (c[okc, 1] - c[okc, 0]).astype(np.float64) / ((t32[okc] - t16[okc]) * 100.0) * 0.1
+                        print(f"           in-kernel clock over K tiles 16..32: median {np.median(ghz):5.3f} GHz (min {ghz.min():5.3f}, max {ghz.max():5.3f}); "
+                              f"{(t32[okc] - t16[okc]).mean() / 16 * 1e3:6.1f} ns = {np.median((c[okc, 1] - c[okc, 0]) / 16.0):7.1f} cycles per K tile")
                 slow = np.argsort(-gi)[:32]
                 fast = np.argsort(gi)[:32]
                 for nm, idx in (("32 slowest", slow), ("32 fastest", fast)):

@@ -1,0 +1,64 @@
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#include <vector>
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+// Where inside a K tile do the two waves of a SIMD spend their time when a workgroup barrier couples them?  (round 4)
+// per-tile stamps: MFMA wave 0: [after barrier, before next barrier]; partner wave 4: same
+template <int PARTNER>
+__global__ __launch_bounds__(512, 2) void k(unsigned long long* out, float* sink) {
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
+  unsigned long long st[32];
+  if (wave < 4) {
+    f32x16 acc;
+    for (int i = 0; i < 16; ++i) acc[i] = 0.f;
+    float a = lane * 0.001f, b = 1.0f - lane * 0.002f;
+    __builtin_amdgcn_s_barrier();
+#pragma unroll
+    for (int t = 0; t < 16; ++t) {
+      __builtin_amdgcn_s_barrier();
+      __builtin_amdgcn_sched_barrier(0); st[2 * t] = __builtin_amdgcn_s_memtime(); __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int i = 0; i < 16; ++i) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc, 0, 0, 0);
+      __builtin_amdgcn_sched_barrier(0); st[2 * t + 1] = __builtin_amdgcn_s_memtime(); __builtin_amdgcn_sched_barrier(0);
+    }
+    float s = 0.f;
+    for (int i = 0; i < 16; ++i) s += acc[i];
+    if (s == 123.456f) sink[threadIdx.x] = s;
+  } else {
+    unsigned a0 = lane, a1 = lane * 3, a2 = lane * 5, a3 = lane * 7;
+    __builtin_amdgcn_s_barrier();
+#pragma unroll
+    for (int t = 0; t < 16; ++t) {
+      __builtin_amdgcn_s_barrier();
+      __builtin_amdgcn_sched_barrier(0); st[2 * t] = __builtin_amdgcn_s_memtime(); __builtin_amdgcn_sched_barrier(0);
+      if (PARTNER == 1) {
+#pragma unroll
+        for (int i = 0; i < 16; ++i)
+          asm volatile("v_add_u32 %0, %0, %4\n\tv_add_u32 %1, %1, %4\n\tv_add_u32 %2, %2, %4\n\tv_add_u32 %3, %3, %4" : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3) : "v"(lane));
+      } else if (PARTNER == 2) {
+        __builtin_amdgcn_s_sleep(8);
+      }
+      __builtin_amdgcn_sched_barrier(0); st[2 * t + 1] = __builtin_amdgcn_s_memtime(); __builtin_amdgcn_sched_barrier(0);
+    }
+    if ((a0 ^ a1 ^ a2 ^ a3) == 0x12345u) sink[threadIdx.x] = 1.f;
+  }
+  if (blockIdx.x == 0 && lane == 0 && (wave == 0 || wave == 4))
+    for (int i = 0; i < 32; ++i) out[(wave / 4) * 32 + i] = st[i];
+}
+template <int P> void run(unsigned long long* out, float* sink) {
+  hipLaunchKernelGGL((k<P>), dim3(256), dim3(512), 0, 0, out, sink);
+  hipLaunchKernelGGL((k<P>), dim3(256), dim3(512), 0, 0, out, sink);
+  hipDeviceSynchronize();
+  std::vector<unsigned long long> h(64);
+  hipMemcpy(h.data(), out, 64 * 8, hipMemcpyDeviceToHost);
+  unsigned long long t0 = h[0];
+  printf("partner %d\n tile: MFMA wave [after barrier .. chain issued]   partner [after barrier .. work done]\n", P);
+  for (int t = 4; t < 10; ++t)
+    printf("  %2d: %6lld .. %6lld     %6lld .. %6lld\n", t, (long long)(h[2 * t] - t0), (long long)(h[2 * t + 1] - t0), (long long)(h[32 + 2 * t] - t0), (long long)(h[32 + 2 * t + 1] - t0));
+}
+int main() {
+  unsigned long long* out; float* sink;
+  hipMalloc(&out, 64 * 8); hipMalloc(&sink, 4096);
+  run<0>(out, sink); run<1>(out, sink); run<2>(out, sink);
+  return 0;
+}

@@ -16,6 +16,7 @@ ERR_INVALID_ARG, ERR_DIMS, ERR_HIP, ERR_NOT_BOUND, ERR_WORKSPACE, ERR_DEVICE = -
 DROPOUT_OFF, DROPOUT_MASKS, DROPOUT_PHILOX = 0, 1, 2
 POSTNET_F32, POSTNET_BF16, POSTNET_SPLIT_F16 = 0, 1, 2
 PREC_F32, PREC_SPLIT_F16 = 0, 1
+ABI_VERSION = 2  # include/ttsdec.h TTSDEC_VERSION these bindings were written for
 CELL_TACO2PROD, CELL_TACO2 = 0, 1
 POSTNET_TYPE_MEL, POSTNET_TYPE_MEL2 = 0, 1
 W_DECODER_COUNT = 21
@@ -156,6 +157,10 @@ def load() -> C.CDLL:
         vp, i32, u64, sz, f32 = C.c_void_p, C.c_int, C.c_uint64, C.c_size_t, C.c_float
         lib.ttsdec_version.restype = i32
         lib.ttsdec_version.argtypes = []
+        got = lib.ttsdec_version()
+        if got != ABI_VERSION:  # (an older or newer build, e.g. through TTSDEC_LIB: its entry points take other argument lists)
+            raise RuntimeError(f"{LIB_PATH} has ABI version {got}, these bindings are for version {ABI_VERSION}: rebuild it "
+                               "(python torch-tts_amd/build.py --force)")
         lib.ttsdec_strerror.restype = C.c_char_p
         lib.ttsdec_strerror.argtypes = [i32]
         lib.ttsdec_last_hip_error.restype = C.c_char_p

@@ -813,8 +813,10 @@ bool head_proj(const ttsdec_handle* h, int B) {
   return proj_regw_shapes(h) && h->head_proj != 0;  // (-1 = default = on)
 }
 // The query as a job of the attention role (fused_kernels.hip attn_lstm_kernel): needs every attention-role workgroup resident
-// at once - one per utterance; they have the launch's lowest block ids, so that is at most the chip's 512 slots - and whole K
-// slices for the register-weight GEMM body.
+// at once - one per utterance, and they wait for each other's query tiles; they have the launch's lowest block ids, so that is
+// at most what the device holds of that kernel at once (attn_lstm_resident_slots: CUs x the runtime's occupancy answer, 512 on
+// an MI355X; a partitioned or smaller part answers for itself; a GPU shared with another process is what the bounded spin and
+// Decoder.forward's fallback are for) - and whole K slices for the register-weight GEMM body.
 // Measured, us per step with / without it (same box, profiles/r03_f_*, r03_t_query_role_large_batches.txt): split-fp16 B = 256 60.4 /
 // 61.6, 128 49.4 / 50.0, 64 46.6 / 47.0, 320 83.9 / 89.7, 384 98.5 / 99.0, 448 108.5 / 106.9, 512 121.5 / 118.7; B = 32 44.1 / 42.5 (the
 // roles do not share CUs there: the hop costs more than the launch), B = 1 175 / 38 (one workgroup would run all 32 tiles); exact
@@ -822,7 +824,8 @@ bool head_proj(const ttsdec_handle* h, int B) {
 // query_role = 1 forces it wherever it is possible at all).
 bool query_role(const ttsdec_handle* h, int B) {
   const ttsdec_dims& d = h->d;
-  if (overlap_level(h, B) < 2 || h->query_role == 0 || B > 512) return false;
+  if (overlap_level(h, B) < 2 || h->query_role == 0) return false;
+  if (B > attn_lstm_resident_slots(B, d.h_dec, d.d_ctx, lstm_prec(h) != 0)) return false;
   const int ps = proj_split(query_k(d));
   if (!(ps > 0 && ps <= kQuerySplit && !(d.h_att & 7))) return false;
   if (h->query_role > 0) return true;
@@ -835,7 +838,7 @@ bool step_merged(const ttsdec_handle* h, int B) {
   if (overlap_level(h, B) < 3 || !lstm_prec(h) || !head_proj(h, B)) return false;
   const int ps = proj_split(query_k(d));  // (the query on the register-weight body: whole K slices)
   if (!(ps > 0 && ps <= kQuerySplit && !(d.h_att & 7))) return false;
-  return step_merged_supported(B, d.h_att, d.h_dec);
+  return step_merged_supported(B, d.h_att, d.h_dec, pre_hidden(d), d.d_pre, d.d_ctx, proj_n(d), proj_parts(h, lstm_prec(h), B));
 }
 const StepOrder& step_order(const ttsdec_handle* h, int B) {
   const ttsdec_dims& d = h->d;

@@ -62,7 +62,7 @@ __device__ __forceinline__ void loop_stamp(const Ctrl* c, int slot, int node) {
     if (p != nullptr && slot < kLoopStampSlots) p[slot * kLoopStampNodes + node] = __builtin_amdgcn_s_memrealtime();
   }
 }
-constexpr int kStampKinds = 3;
+constexpr int kStampKinds = 5;  // 3, 4: shader-clock readings (s_memtime) of kinds 0 / 1 at K tiles 16 and 32, for the in-kernel clock
 // stamps[(kind * 1024 + block) * 8 + k]; kind 0 = frame || lstm_att, 1 = attention || lstm_dec, 2 = the projection role at the head of
 // kind 0's launch (k: 2 = entry, 3 = control block and operands arrived, 4 = partial tile reduced, 5 = signalled);
 // k: 0 = role << 32 | HW_ID, 1 = XCC_ID, 2 = start, 3 = gate reached, 4 = gate passed, 5 = end (s_memrealtime, 10 ns units)
@@ -331,7 +331,12 @@ __device__ __forceinline__ void role_signal2(unsigned int* c0, unsigned int* c1)
   if (threadIdx.x == 0) __hip_atomic_fetch_add(c0, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   if (threadIdx.x == 64 && c1 != nullptr) __hip_atomic_fetch_add(c1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
-constexpr int kRoleSpinLimit = 1 << 17;  // x ~0.25 us of s_sleep + the poll's round trip: > 30 ms, far beyond any producer's run time
+// Polls before a consumer role gives up: x (~0.25 us of s_sleep + the poll's round trip) ~ 1-4 ms - three orders of magnitude
+// beyond any producer role's run time (they end within tens of microseconds of the launch's start), and short enough that a
+// call that does time out (an over-subscribed or partitioned GPU on which the producers are not resident) costs ONE such wait:
+// once the flag is set every later gate of the call returns at once (role_poll), and Decoder.forward repeats the call on the
+// one-role-per-launch schedule.  (Round 3 had 2^17 polls and no short-circuit: hundreds of gates x > 30 ms each.)
+constexpr int kRoleSpinLimit = 1 << 12;
 // Arrival counters of the two-role launches (in the workspace, zeroed by every ttsdec_decode call): one per 32-ROW BLOCK of the
 // batch and hand-off kind, each on a 128-byte line of its own.  A consumer waits for the producers of ITS rows only - 8 frame
 // workgroups instead of all 32, 12 projection workgroups instead of 96, 64 attention workgroups instead of 256 - so no
@@ -346,10 +351,14 @@ __device__ __forceinline__ void role_poll(const unsigned int* c0, unsigned int t
                                           unsigned int target1 = 0, int long_sleep = 0) {
   if (target0 == 0 && (c1 == nullptr || target1 == 0)) return;
   int spins = 0;
+  // Has a hand-off of this call already timed out (Ctrl::range_err bit 1)?  Then its arrival targets - cumulative over the
+  // call's steps - can never be met: do not wait again.  The load travels with the first poll (one round trip, not two).
+  const int gave_up = ctrl != nullptr ? (__hip_atomic_load(&ctrl->range_err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) & 2) : 0;
   for (;;) {
     const unsigned int v0 = __hip_atomic_load(c0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     const unsigned int v1 = c1 != nullptr ? __hip_atomic_load(c1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : target1;
     if (v0 >= target0 && v1 >= target1) break;
+    if (gave_up) break;
     __builtin_amdgcn_s_sleep(8);
     for (int i = 0; i < long_sleep; ++i) __builtin_amdgcn_s_sleep(8);  // (waits known to be long: fewer polls beside the tile streams)
     if (++spins > (ctrl != nullptr ? ctrl->spin_limit : kRoleSpinLimit)) {

@@ -22,6 +22,10 @@
 // a "late" launch (round 2: 86.4 vs 88.3 us per step - the extra launch costs what the overlap wins).
 #include <string.h>
 
+#include <map>
+#include <mutex>
+#include <utility>
+
 #include "frame_body.h"
 #include "step_bodies.h"
 
@@ -240,68 +244,101 @@ void launch_frame_lstm(const FrameArgs& f, const LstmArgs& l, hipStream_t st) {
 }
 void launch_proj_frame_lstm(const ProjArgs& pj, const FrameArgs& f, const LstmArgs& l, hipStream_t st) { launch_frame_lstm_any<true>(f, l, pj, st); }
 
+// Workgroups of a multi-role kernel the device holds AT ONCE, as its runtime says: CUs x hipOccupancyMaxActiveBlocksPerMultiprocessor
+// (registers, LDS and the wave limit of THIS kernel on THIS device - a partitioned or smaller part answers for itself).  The
+// schedules in which workgroups of one role wait for EACH OTHER (the query role, the one-launch step) are only taken when all
+// of them fit that number; they further assume the GPU is not shared with another process's kernels (what the number cannot
+// know - the bounded spin and Decoder.forward's fallback cover that case).  0 when the query fails: those schedules stay off.
+static int resident_slots(const void* fn) {
+  static std::mutex mu;
+  static std::map<std::pair<int, const void*>, int> cache;
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess) { (void)hipGetLastError(); return 0; }
+  std::lock_guard<std::mutex> lock(mu);
+  const auto key = std::make_pair(dev, fn);
+  const auto it = cache.find(key);
+  if (it != cache.end()) return it->second;
+  int cus = 0, per_cu = 0;
+  if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess ||
+      hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, fn, kGemmThreads, 0) != hipSuccess) {
+    (void)hipGetLastError();
+    cus = per_cu = 0;
+  }
+  return cache[key] = cus * per_cu;
+}
+
+typedef void (*attn_lstm_fn)(AttnArgs, LstmArgs, ProjArgs, int, int);
 template <int NJ, int PREC>
-static void launch_attn_lstm_nj(const AttnArgs& a, const LstmArgs& l, const ProjArgs& pq, hipStream_t st) {
+static attn_lstm_fn attn_lstm_kernel_of(LeanKind kind) {
   using TL = LeanTiles<PREC>;
+  if (kind == SMALL_FAT) return attn_lstm_kernel<NJ, typename TL::SmallFat, 2>;
+  if (kind == LEAN_64x8) return attn_lstm_kernel<NJ, typename TL::Lean64x8, 4>;
+  return attn_lstm_kernel<NJ, typename TL::Lean64x16, 4>;
+}
+static attn_lstm_fn attn_lstm_kernel_for(int D, bool f16, LeanKind kind) {
+  if (D / 4 <= 64) return f16 ? attn_lstm_kernel_of<1, PREC_F16S>(kind) : attn_lstm_kernel_of<1, PREC_F32>(kind);
+  return f16 ? attn_lstm_kernel_of<2, PREC_F16S>(kind) : attn_lstm_kernel_of<2, PREC_F32>(kind);
+}
+int attn_lstm_resident_slots(int B, int H, int D, bool f16) {
+  return resident_slots(reinterpret_cast<const void*>(attn_lstm_kernel_for(D, f16, lean_kind(B, B, H))));
+}
+void launch_attn_lstm(const AttnArgs& a, const LstmArgs& l, const ProjArgs* q, hipStream_t st) {
+  if (a.B <= 0) return;
+  ProjArgs pq;
+  if (q != nullptr) pq = *q;
+  else memset(&pq, 0, sizeof(pq));
   const LeanKind kind = lean_kind(l.M, a.B, l.H);
   const int lcols = kind == LEAN_64x16 ? (l.H + 15) / 16 : (l.H + 7) / 8;
   const int lrows = kind == SMALL_FAT ? (l.M + 31) / 32 : (l.M + 63) / 64;
   dim3 grid(a.B + lcols * lrows), block(kGemmThreads);
-  if (kind == SMALL_FAT) hipLaunchKernelGGL((attn_lstm_kernel<NJ, typename TL::SmallFat, 2>), grid, block, 0, st, a, l, pq, a.B, lcols);
-  else if (kind == LEAN_64x8) hipLaunchKernelGGL((attn_lstm_kernel<NJ, typename TL::Lean64x8, 4>), grid, block, 0, st, a, l, pq, a.B, lcols);
-  else hipLaunchKernelGGL((attn_lstm_kernel<NJ, typename TL::Lean64x16, 4>), grid, block, 0, st, a, l, pq, a.B, lcols);
-}
-void launch_attn_lstm(const AttnArgs& a, const LstmArgs& l, const ProjArgs* q, hipStream_t st) {
-  if (a.B <= 0) return;
-  const bool f16 = l.prec == 1;
-  ProjArgs pq;
-  if (q != nullptr) pq = *q;
-  else memset(&pq, 0, sizeof(pq));
-  if (a.D / 4 <= 64) { if (f16) launch_attn_lstm_nj<1, PREC_F16S>(a, l, pq, st); else launch_attn_lstm_nj<1, PREC_F32>(a, l, pq, st); }
-  else { if (f16) launch_attn_lstm_nj<2, PREC_F16S>(a, l, pq, st); else launch_attn_lstm_nj<2, PREC_F32>(a, l, pq, st); }
+  hipLaunchKernelGGL(attn_lstm_kernel_for(a.D, l.prec == 1, kind), grid, block, 0, st, a, l, pq, a.B, lcols);
 }
 
 // ---- one-launch step ----
-constexpr int kChipSlots = 512;  // 256 CUs x two 512-thread workgroups of <= 80 KiB LDS and <= 128 VGPRs
-template <int PH, int NJ, class Cfg, int WPE>
-static void launch_step_merged_cfg(const ProjArgs& pj, const FrameArgs& f, const LstmArgs& la, const ProjArgs& pq, const AttnArgs& a,
-                                   const LstmArgs& ld, hipStream_t st) {
-  constexpr int BU = Cfg::BN / 4;
+typedef void (*step_fn)(FrameArgs, LstmArgs, ProjArgs, AttnArgs, LstmArgs, ProjArgs, StepGrid);
+struct StepKernel {
+  step_fn fn;
+  int bm, bu;  // batch rows / hidden units of an LSTM tile
+};
+template <int PH, int NJ>
+static StepKernel step_kernel_of(LeanKind kind) {
+  using TL = LeanTiles<PREC_F16S>;
+  if (kind == SMALL_FAT) return {step_kernel<40, PH, TL::SmallFat, NJ, 2>, TL::SmallFat::BM, TL::SmallFat::BN / 4};
+  if (kind == LEAN_64x8) return {step_kernel<40, PH, TL::Lean64x8, NJ, 4>, TL::Lean64x8::BM, TL::Lean64x8::BN / 4};
+  return {step_kernel<40, PH, TL::Lean64x16, NJ, 4>, TL::Lean64x16::BM, TL::Lean64x16::BN / 4};
+}
+static StepKernel step_kernel_for(int Ph, int D, LeanKind kind) {
+  if (Ph == 256) return D / 4 <= 64 ? step_kernel_of<256, 1>(kind) : step_kernel_of<256, 2>(kind);
+  return D / 4 <= 64 ? step_kernel_of<128, 1>(kind) : step_kernel_of<128, 2>(kind);
+}
+static int step_roles_in_front(int B, int P, int n_out, int ksplit) {  // the workgroups in front of the attention LSTM's
+  return proj_grid_size(B, n_out, ksplit) + frame_grid_size(B, P);
+}
+bool step_merged_supported(int B, int Ha, int Hd, int Ph, int P, int D, int n_out, int ksplit) {
+  // The attention role's workgroups - one per utterance - wait for each other's query tiles: all of them resident at once,
+  // beside workgroups of the roles in front of them that have not ended yet - so at most HALF of what the device holds of this
+  // kernel (resident_slots: 2 x 256 on an MI355X).
+  if (B < 1) return false;
+  const LeanKind kind = lean_kind(B, step_roles_in_front(B, P, n_out, ksplit), Ha > Hd ? Ha : Hd);
+  return B <= resident_slots(reinterpret_cast<const void*>(step_kernel_for(Ph, D, kind).fn)) / 2;
+}
+void launch_step_merged(const ProjArgs& pj, const FrameArgs& f, const LstmArgs& la, const ProjArgs& pq, const AttnArgs& a, const LstmArgs& ld,
+                        hipStream_t st) {
+  if (f.M <= 0 || la.prec != 1) return;  // (split-fp16 only: the host never asks for it otherwise)
+  const LeanKind kind = lean_kind(la.M, step_roles_in_front(f.M, f.P, pj.N, pj.ksplit), la.H > ld.H ? la.H : ld.H);
+  const StepKernel k = step_kernel_for(f.Ph, a.D, kind);
   StepGrid n;
   n.tune = f.dbg >> 8;
   n.frame_cols = (f.P + kFrameCols - 1) / kFrameCols;
   n.n_frame = n.frame_cols * ((f.M + kFrameRows - 1) / kFrameRows);
   n.n_proj = proj_grid_size(pj.M, pj.N, pj.ksplit);
-  const int lrows = (la.M + Cfg::BM - 1) / Cfg::BM;
-  n.la_cols = (la.H + BU - 1) / BU; n.n_la = n.la_cols * lrows;
-  n.ld_cols = (ld.H + BU - 1) / BU;
+  const int lrows = (la.M + k.bm - 1) / k.bm;
+  n.la_cols = (la.H + k.bu - 1) / k.bu; n.n_la = n.la_cols * lrows;
+  n.ld_cols = (ld.H + k.bu - 1) / k.bu;
   n.n_attn = a.B;
   n.n_q = a.q_tiles > a.B ? a.q_tiles : 0;  // (fewer attention workgroups than query tiles: the tiles get workgroups of their own)
   dim3 grid(n.n_proj + n.n_frame + n.n_la + n.n_q + n.n_attn + n.ld_cols * lrows), block(kGemmThreads);
-  hipLaunchKernelGGL((step_kernel<40, PH, Cfg, NJ, WPE>), grid, block, 0, st, f, la, pj, a, ld, pq, n);
-}
-static int step_roles_in_front(int B, int P, int n_out, int ksplit) {  // the workgroups in front of the attention LSTM's
-  return proj_grid_size(B, n_out, ksplit) + frame_grid_size(B, P);
-}
-bool step_merged_supported(int B, int Ha, int Hd) {
-  (void)Ha; (void)Hd;
-  // (the attention role's workgroups - one per utterance - and, where they also run the query tiles, each other's: all
-  // resident at once)
-  return B >= 1 && B <= kChipSlots / 2;
-}
-void launch_step_merged(const ProjArgs& pj, const FrameArgs& f, const LstmArgs& la, const ProjArgs& pq, const AttnArgs& a, const LstmArgs& ld,
-                        hipStream_t st) {
-  if (f.M <= 0 || la.prec != 1) return;  // (split-fp16 only: the host never asks for it otherwise)
-  using TL = LeanTiles<PREC_F16S>;
-  const LeanKind kind = lean_kind(la.M, step_roles_in_front(f.M, f.P, pj.N, pj.ksplit), la.H > ld.H ? la.H : ld.H);
-  const bool nj1 = a.D / 4 <= 64, ph256 = f.Ph == 256;
-#define TTS_STEP(PH_, NJ_)                                                                                   \
-  (kind == SMALL_FAT ? launch_step_merged_cfg<PH_, NJ_, TL::SmallFat, 2>(pj, f, la, pq, a, ld, st)            \
-   : kind == LEAN_64x8 ? launch_step_merged_cfg<PH_, NJ_, TL::Lean64x8, 4>(pj, f, la, pq, a, ld, st)         \
-                       : launch_step_merged_cfg<PH_, NJ_, TL::Lean64x16, 4>(pj, f, la, pq, a, ld, st))
-  if (ph256) { if (nj1) TTS_STEP(256, 1); else TTS_STEP(256, 2); }
-  else { if (nj1) TTS_STEP(128, 1); else TTS_STEP(128, 2); }
-#undef TTS_STEP
+  hipLaunchKernelGGL(k.fn, grid, block, 0, st, f, la, pj, a, ld, pq, n);
 }
 
 void launch_lstm_lean(const LstmArgs& l, hipStream_t st) {

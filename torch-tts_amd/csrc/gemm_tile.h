@@ -150,7 +150,29 @@ struct NoGate {
   __device__ __forceinline__ void mark(int) const {}
 };
 
-template <class Cfg, class LoaderA, class LoaderB, class Gate = NoGate>
+// kBufDma (round 4): the loader waves issue their LDS-DMA as buffer_load_dwordx4 ... lds - a wave-uniform descriptor of the
+// K segment's base, a per-lane byte offset that is computed ONCE per segment (row offset + swizzled column) and a SCALAR K
+// offset that advances per tile - instead of global_load_lds with a 64-bit per-lane address that every instruction updates
+// (two 64-bit adds and a select in the vector ALU per DMA).  Why it matters: a loader wave shares its SIMD with an MFMA wave,
+// and beside a dense MFMA chain a partner wave's vector-ALU instructions issue at 8-21 cycles each (tools/
+// ubench_f32_partner.hip, ubench_f32_barrier_phase.hip: 64 v_add_u32 beside 16 dependent fp32 MFMAs take 1344 cycles, the chain
+// itself 968), so it was the LOADERS' per-tile instruction stream - ~40 VALU + 4 DMA - that set the pace of the fp32 K loop:
+// 1725 cycles per 32-k tile for 1024 cycles of MFMA, 640 for the loader waves alone.  With scalar bookkeeping only:
+// ~1100 in the micro-benchmark.  Out-of-range lanes (rows past the matrix, the zero padding of a segment's last tile, the
+// trailing dummy tiles) carry an offset beyond the descriptor's range: such a lane reads nothing and the DMA writes ZEROS to
+// its LDS slot (tools/ubench_buffer_lds_oob.hip; the scalar offset is part of the range check on gfx950, so a valid lane needs
+// offset + K advance < kBufRange: operands below 2 GiB - the callers that set kBufDma are the LSTM kernels).
+// Loaders used with kBufDma provide  seg_base(s, plane)  (uniform pointer) and  row_off(r, s)  (bytes from it).
+constexpr unsigned kBufRange = 0x7FFFF000u;  // num_records of every descriptor = the offset that marks a lane out of range
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const void* base) {
+  // (the pointer is wave-uniform by construction - kernel arguments - but say so: a descriptor the compiler believes to be
+  // lane-varying becomes a waterfall loop around every load)
+  const unsigned long long a = (unsigned long long)base;
+  const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)a), hi = __builtin_amdgcn_readfirstlane((unsigned)(a >> 32));
+  return __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<void*>(((unsigned long long)hi << 32) | lo), 0, (int)kBufRange, 0x00020000);
+}
+
+template <class Cfg, class LoaderA, class LoaderB, class Gate = NoGate, bool kBufDma = false>
 __device__ __forceinline__ void gemm_tile(const LoaderA& la, const LoaderB& lb, float* smem, bool live = true,
                                           int dbg = 0, const Gate gate = Gate()) {
   // `live` (does this launch have anything to do?) typically comes from a control-block load
@@ -200,7 +222,183 @@ __device__ __forceinline__ void gemm_tile(const LoaderA& la, const LoaderB& lb, 
   const int half = lane >> 5;
   const int l32 = lane & 31;
 
-  if (is_loader) {
+  if (is_loader && kBufDma) {
+    // ====================== loader waves, buffer-descriptor form ======================
+    if constexpr (kBufDma) {
+    static_assert(!LoaderA::kRange, "per-row k windows keep the per-lane address form");
+    // ONE descriptor per operand plane, based at the lowest of the operand's segment pointers; a segment's distance from it is
+    // folded into the per-lane offsets below.  (The segments of an LSTM operand are slices of one allocation - the decoder
+    // workspace, the packed weight blob - so the distances are far below the 2-GiB range; api.hip refuses larger ones.)  A
+    // descriptor per segment kept 3 x planes x 2 base pointers alive in scalar registers across the K loop: spills.
+    auto lowest = [&](const auto& ld_, int p) {
+      const char* b0 = static_cast<const char*>(ld_.seg_base(0, p));
+      const char* b1 = nseg > 1 ? static_cast<const char*>(ld_.seg_base(1, p)) : b0;
+      const char* b2 = nseg > 2 ? static_cast<const char*>(ld_.seg_base(2, p)) : b0;
+      const char* m = b1 < b0 ? b1 : b0;
+      return b2 < m ? b2 : m;
+    };
+    // distance of plane p's segment sg from that plane's base: uniform, added to the SCALAR offset (the planes of an operand
+    // need not be laid out alike, so it cannot ride in the per-lane offsets that the planes share)
+    auto seg_delta = [&](const auto& ld_, int sg, int p) {
+      const char* b = static_cast<const char*>(ld_.seg_base(sg < nseg ? sg : 0, p));
+      return (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(b - lowest(ld_, p)));
+    };
+    unsigned dla[NP][3], dlb[NP][3];
+#pragma unroll
+    for (int p = 0; p < NP; ++p)
+#pragma unroll
+      for (int sg = 0; sg < 3; ++sg) {
+        dla[p][sg] = seg_delta(la, sg, p);
+        dlb[p][sg] = seg_delta(lb, sg, p);
+      }
+    unsigned va[3][NA], vb[3][NB];  // per-lane byte offset inside a segment (row + swizzled column), per K segment; planes share it
+    int ca[NA], cb[NB];             // element offset of the lane's column inside a tile
+#pragma unroll
+    for (int i = 0; i < NA; ++i) {
+      const int row = (wave * NA + i) * RPI + lane / C16;
+      const bool ok = row < BM && la.row_ok(row) && dbg != 1;
+      const int c16 = (lane % C16) ^ Cfg::swz(row);
+      ca[i] = c16 * EPC;
+#pragma unroll
+      for (int sg = 0; sg < 3; ++sg) va[sg][i] = ok ? la.row_off(row, sg) + (unsigned)la.col_off(c16) : kBufRange;
+    }
+#pragma unroll
+    for (int i = 0; i < NB; ++i) {
+      const int row = (wave * NB + i) * RPI + lane / C16;
+      const bool ok = row < BN && lb.row_ok(row) && dbg != 1;
+      const int c16 = (lane % C16) ^ Cfg::swz(row);
+      cb[i] = c16 * EPC;
+#pragma unroll
+      for (int sg = 0; sg < 3; ++sg) vb[sg][i] = ok ? lb.row_off(row, sg) + (unsigned)lb.col_off(c16) : kBufRange;
+    }
+#ifdef TTSDEC_CHECK_DMA
+    // Debug build (tools/build_check_dma.sh): every lane's first address of every segment and plane against the per-lane
+    // pointer form; a lane that disagrees is taken out of range (reads nothing) and reported - never dereferenced.
+#pragma unroll
+    for (int sg = 0; sg < 3; ++sg) {
+      if (sg >= nseg) continue;
+#pragma unroll
+      for (int p = 0; p < NP; ++p) {
+#pragma unroll
+        for (int i = 0; i < NA; ++i) {
+          const int row = (wave * NA + i) * RPI + lane / C16;
+          const int c16 = (lane % C16) ^ Cfg::swz(row);
+          if (va[sg][i] != kBufRange && (gbyte*)lowest(la, p) + dla[p][sg] + va[sg][i] != la.row_ptr(row, sg, p) + la.col_off(c16)) {
+            printf("DMA address mismatch A seg %d plane %d row %d c16 %d\n", sg, p, row, c16);
+            va[sg][i] = kBufRange;
+          }
+        }
+#pragma unroll
+        for (int i = 0; i < NB; ++i) {
+          const int row = (wave * NB + i) * RPI + lane / C16;
+          const int c16 = (lane % C16) ^ Cfg::swz(row);
+          if (vb[sg][i] != kBufRange && (gbyte*)lowest(lb, p) + dlb[p][sg] + vb[sg][i] != lb.row_ptr(row, sg, p) + lb.col_off(c16)) {
+            printf("DMA address mismatch B seg %d plane %d row %d c16 %d\n", sg, p, row, c16);
+            vb[sg][i] = kBufRange;
+          }
+        }
+      }
+    }
+#endif
+    const unsigned inca = (unsigned)__builtin_amdgcn_readfirstlane((int)la.tile_inc(ROWB));
+    const unsigned incb = (unsigned)__builtin_amdgcn_readfirstlane((int)lb.tile_inc(ROWB));
+    __amdgpu_buffer_rsrc_t ra[NP], rb[NP];
+#pragma unroll
+    for (int p = 0; p < NP; ++p) {
+      ra[p] = make_rsrc(lowest(la, p));
+      rb[p] = make_rsrc(lowest(lb, p));
+    }
+    unsigned cva[NA], cvb[NB];
+    unsigned cda[NP], cdb[NP];  // the current segment's distance from the base, per plane (uniform)
+    auto enter_seg = [&](int sg) {  // uniform sg
+#pragma unroll
+      for (int i = 0; i < NA; ++i) cva[i] = sg == 0 ? va[0][i] : (sg == 1 ? va[1][i] : va[2][i]);
+#pragma unroll
+      for (int i = 0; i < NB; ++i) cvb[i] = sg == 0 ? vb[0][i] : (sg == 1 ? vb[1][i] : vb[2][i]);
+#pragma unroll
+      for (int p = 0; p < NP; ++p) {
+        cda[p] = sg == 0 ? dla[p][0] : (sg == 1 ? dla[p][1] : dla[p][2]);
+        cdb[p] = sg == 0 ? dlb[p][0] : (sg == 1 ? dlb[p][1] : dlb[p][2]);
+      }
+    };
+    enter_seg(0);
+    int seg = 0, left = nt0, seg_len = len0, kpos = 0, istage = 0;
+    unsigned soa = 0, sob = 0;  // scalar byte offsets of the current tile inside the segment
+
+    auto dma_a = [&](const __amdgpu_buffer_rsrc_t& r, char* dst, unsigned voff, unsigned soff) {
+      // (size, immediate offset and cache-policy arguments of the builtin must be literals)
+      if constexpr (Gate::kAuxA == 16) __builtin_amdgcn_raw_ptr_buffer_load_lds(r, (lds_void*)dst, 16, (int)voff, (int)soff, 0, 16);
+      else __builtin_amdgcn_raw_ptr_buffer_load_lds(r, (lds_void*)dst, 16, (int)voff, (int)soff, 0, 0);
+    };
+    auto dma_b = [&](const __amdgpu_buffer_rsrc_t& r, char* dst, unsigned voff, unsigned soff) {
+      if constexpr (Cfg::kAuxB == 2) __builtin_amdgcn_raw_ptr_buffer_load_lds(r, (lds_void*)dst, 16, (int)voff, (int)soff, 0, 2);
+      else __builtin_amdgcn_raw_ptr_buffer_load_lds(r, (lds_void*)dst, 16, (int)voff, (int)soff, 0, 0);
+    };
+    auto issue_tile = [&]() {
+      char* st = lds + istage * Cfg::kStageBytes;
+      const bool partial = (kpos + KT > seg_len);  // uniform: last, zero-padded tile of a segment (or past the end)
+      auto dst_a = [&](int p, int i) {
+        char* dst = st + p * Cfg::kPlaneABytes + (wave * NA + i) * 1024;
+        if (Cfg::kDummy && (wave * NA + i) * 1024 >= Cfg::kPlaneABytes) dst = lds + Cfg::kDummyOff + wave * 1024;
+        return dst;
+      };
+      auto dst_b = [&](int p, int i) {
+        char* dst = st + NP * Cfg::kPlaneABytes + p * Cfg::kPlaneBBytes + (wave * NB + i) * 1024;
+        if (Cfg::kDummy && (wave * NB + i) * 1024 >= Cfg::kPlaneBBytes) dst = lds + Cfg::kDummyOff + wave * 1024;
+        return dst;
+      };
+      if (partial) {
+        // (its own block, kept apart from the common one by the asm statement: merged into per-lane selects, the test would put
+        // three vector-ALU instructions in front of EVERY tile's DMAs)
+        asm volatile("; zero-padded tile" ::: "memory");
+#pragma unroll
+        for (int p = 0; p < NP; ++p)
+#pragma unroll
+          for (int i = 0; i < NA; ++i) dma_a(ra[p], dst_a(p, i), kpos + ca[i] >= seg_len ? kBufRange : cva[i], soa + cda[p]);
+#pragma unroll
+        for (int p = 0; p < NP; ++p)
+#pragma unroll
+          for (int i = 0; i < NB; ++i) dma_b(rb[p], dst_b(p, i), kpos + cb[i] >= seg_len ? kBufRange : cvb[i], sob + cdb[p]);
+      } else {
+#pragma unroll
+        for (int p = 0; p < NP; ++p)
+#pragma unroll
+          for (int i = 0; i < NA; ++i) dma_a(ra[p], dst_a(p, i), cva[i], soa + cda[p]);
+#pragma unroll
+        for (int p = 0; p < NP; ++p)
+#pragma unroll
+          for (int i = 0; i < NB; ++i) dma_b(rb[p], dst_b(p, i), cvb[i], sob + cdb[p]);
+      }
+      istage = (istage + 1 == S) ? 0 : istage + 1;
+      kpos += KT;
+      soa += inca;
+      sob += incb;
+      if (--left == 0) {  // next segment (or, past the last one, out-of-range loads that keep vmcnt uniform)
+        ++seg;
+        kpos = 0;
+        soa = sob = 0;
+        if (seg == 1 && nseg > 1) { left = nt1; seg_len = len1; enter_seg(1); }
+        else if (seg == 2 && nseg > 2) { left = nt2; seg_len = len2; enter_seg(2); }
+        else { left = 0x7fffffff; seg_len = 0; }  // every further tile is "partial" with nothing valid
+      }
+    };
+#pragma unroll
+    for (int t = 0; t < S - 1; ++t) issue_tile();
+    const int nk_run = live ? nk : 0;
+    if (live && !Cfg::kBig) {
+      wait_vmcnt<(S - 2) * Cfg::NLOADS>();  // tile 0 landed
+      __builtin_amdgcn_s_barrier();         // B0
+    }
+    for (int t = 0; t < nk_run; ++t) {
+      wait_vmcnt<Cfg::kWaitCnt>();
+      __builtin_amdgcn_s_barrier();
+      if (wave8 == 4) gate.mark(t);
+      gate_at(t + S - 1);
+      if (dbg != 3) issue_tile();
+    }
+    wait_vmcnt<0>();
+    }
+  } else if (is_loader) {
     // =========================== loader waves ===========================
     // loader w issues, per plane, instructions i = 0..NA-1 covering A-tile rows
     // (w*NA + i)*RPI + lane/C16; this lane's 16-byte column is (lane % C16) ^ swz(row).
@@ -451,15 +649,26 @@ __device__ __forceinline__ void gemm_tile(const LoaderA& la, const LoaderB& lb, 
         // tile t's fragments were requested a whole tile ago: retire them here (no stall), in a
         // form the compiler's wait-count model sees, so it does not later drain the next reads
         __builtin_amdgcn_s_waitcnt(0xC07F);  // lgkmcnt(0) only
+        if (dbg == 4) {  // measurement ablation: no MFMAs
+          read_frags(std::integral_constant<int, cur ^ 1>{});
+          return;
+        }
         read_frags(std::integral_constant<int, cur ^ 1>{});
-        __builtin_amdgcn_sched_barrier(0);
-        if (dbg != 4) {  // dbg 4: measurement ablation (no MFMAs)
+        // The next tile's eight fragment reads ride in the gaps of this tile's MFMA chain, one per two MFMAs (round 4).  In
+        // front of the chain they delayed its first MFMA by their issue time on every tile - the four MFMA waves leave the
+        // barrier together and 32 ds_read_b128 queue up at the LDS - which cost the fp32 K loop ~50-300 cycles per 1024-cycle
+        // tile (tools/ubench_f32_partner.hip: 1147 -> 1097 per tile beside an idle partner, more with a busy one).
+        // (No runtime branch between the reads and the MFMAs: they must sit in ONE basic block to be interleaved.)
 #pragma unroll
-          for (int q = 0; q < 4; ++q) {
+        for (int i = 0; i < 8; ++i) {
+          __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
+          __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+        }
 #pragma unroll
-            for (int e = 0; e < 4; ++e)
-              acc = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[cur][q][e], fb[cur][q][e], acc, 0, 0, 0);
-          }
+        for (int q = 0; q < 4; ++q) {
+#pragma unroll
+          for (int e = 0; e < 4; ++e)
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[cur][q][e], fb[cur][q][e], acc, 0, 0, 0);
         }
       };
       const int nk_run = live ? nk : 0;

@@ -251,7 +251,9 @@ void launch_attn_lstm(const AttnArgs& a, const LstmArgs& l, const ProjArgs* q, h
 void launch_lstm_lean(const LstmArgs& l, hipStream_t st);                       // an LSTM on the lean tile alone (profiling)
 // The whole step as ONE launch: [proj(t-1) | frame | lstm_att | query -> attention | lstm_dec] by block id, every role waiting
 // only for roles with lower ids (fused_kernels.hip step_kernel).  False: the configuration is not covered (nothing launched).
-bool step_merged_supported(int B, int Ha, int Hd);
+bool step_merged_supported(int B, int Ha, int Hd, int Ph, int P, int D, int n_out, int ksplit);
+// workgroups of the [query ->] attention || decoder-LSTM kernel the current device holds at once (0 = unknown): fused_kernels.hip
+int attn_lstm_resident_slots(int B, int H, int D, bool f16);
 void launch_step_merged(const ProjArgs& pj, const FrameArgs& f, const LstmArgs& la, const ProjArgs& pq, const AttnArgs& a, const LstmArgs& ld,
                         hipStream_t st);
 

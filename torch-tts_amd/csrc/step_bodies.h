@@ -25,6 +25,15 @@ struct LoaderPlain {
   __device__ __forceinline__ int k_hi(int) const { return 0; }
   __device__ __forceinline__ long col_off(int c16) const { return seg_col_off(s, c16); }
   __device__ __forceinline__ long tile_inc(int rowb) const { return seg_tile_inc(s, rowb); }
+  // buffer-descriptor form (gemm_tile kBufDma): the segment's base (uniform) and a row's byte offset from it
+  __device__ __forceinline__ const void* seg_base(int i, int plane) const {
+    const Seg3& q = plane == 0 ? s : s_lo;
+    return i == 0 ? q.p0 : (i == 1 ? q.p1 : q.p2);
+  }
+  __device__ __forceinline__ unsigned row_off(int r, int i) const {
+    const int ld = i == 0 ? s.ld0 : (i == 1 ? s.ld1 : s.ld2);
+    return s.mpad > 0 ? (unsigned)(m0 + r) * kChunkBytes : (unsigned)(m0 + r) * (unsigned)ld * EB;
+  }
 };
 
 // ===========================================================================
@@ -55,6 +64,17 @@ struct LoaderWLstm {
   }
   __device__ __forceinline__ long col_off(int c16) const { return w.mpad != 0 ? (long)(c16 >> 2) * 64 * kChunkBytes + (c16 & 3) * 16 : (long)c16 * 16; }
   __device__ __forceinline__ long tile_inc(int rowb) const { return w.mpad != 0 ? (long)(rowb / kChunkBytes) * 64 * kChunkBytes : (long)rowb; }
+  // buffer-descriptor form (gemm_tile kBufDma)
+  __device__ __forceinline__ const void* seg_base(int i, int plane) const {
+    const Seg3& s = plane == 0 ? w : w_lo;
+    return i == 0 ? s.p0 : (i == 1 ? s.p1 : s.p2);
+  }
+  __device__ __forceinline__ unsigned row_off(int r, int i) const {
+    const int ld = i == 0 ? w.ld0 : (i == 1 ? w.ld1 : w.ld2);  // row-major: leading dimension; chunked: chunks per 16-unit block
+    const int u = u0 + (r % BU);
+    if (w.mpad != 0) return ((unsigned)(u >> 4) * (unsigned)ld * 64u + (unsigned)((r / BU) * 16 + (u & 15))) * kChunkBytes;
+    return ((unsigned)(r / BU) * (unsigned)H + (unsigned)u) * (unsigned)ld * EB;
+  }
 };
 
 // smem: Cfg::kLdsFloats floats of LDS (the caller's ONE shared array); (bx, by): unit block / row block.
@@ -77,8 +97,9 @@ struct RoleGateT {
   // K-loop progress (measurement only): the time at K tiles 16 and 32, stamps 6 and 7 (the second gate's slots: not both at once)
   __device__ __forceinline__ void mark(int t) const {
     if (st != nullptr && seg2 < 0) {
-      if (t == 16) stamp(st, kind, 6, now_rt());
-      if (t == 32) stamp(st, kind, 7, now_rt());
+      // (with the shader clock beside the 100-MHz one: in-kernel clock = d s_memtime / d s_memrealtime x 100 MHz, MI355X_MICROARCH.md DVFS (6))
+      if (t == 16) { stamp(st, kind, 6, now_rt()); stamp(st, kind + 3, 0, __builtin_amdgcn_s_memtime()); }
+      if (t == 32) { stamp(st, kind, 7, now_rt()); stamp(st, kind + 3, 1, __builtin_amdgcn_s_memtime()); }
     }
   }
   __device__ __forceinline__ void wait(int which) const {
@@ -186,7 +207,7 @@ __device__ __forceinline__ void lstm_body(LstmArgs g, float* smem, int bx, int b
       }
     }
   }
-  gemm_tile<Cfg>(la, lb, smem, live, g.dbg, gate);
+  gemm_tile<Cfg, LoaderPlain<EB>, LoaderWLstm<BU, EB>, RoleGateT<kWhole>, true>(la, lb, smem, live, g.dbg, gate);
   if (!live) return;
   if constexpr (!kEarlyEpi) load_epi();
 
