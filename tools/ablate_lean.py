@@ -26,7 +26,7 @@ dec.precision = args.precision
 eng = dec.engine(dev)
 mem = torch.tanh(torch.randn(args.batch, 120, 512, device=dev) * 0.5)
 out = {}
-for abl in (0, 1, 3, 4):
+for abl in (0, 1, 3, 4, 5, 6):
     eng.set_option("profile_ablation", abl)
     ms = eng.profile_step(mem, iters=50, dropout_mode=_lib.DROPOUT_PHILOX, masks=None, seed=1)
     out[abl] = {k: round(v * 1e3, 2) for k, v in ms.items()}

@@ -34,8 +34,12 @@ namespace ttsdec {
 // The LSTM role's tiles, per arithmetic mode (PREC_F16S / PREC_F32):
 //   Lean64x16: 64 rows x 16 units, 16-KiB stages x 5 = 80 KiB (split-fp16: 32 k per stage on chunked planes; exact fp32:
 //              32 k per stage, 128-byte rows).  Two workgroups per CU.
-//   Lean64x8:  batches of <= 64 utterances: 64 rows x 8 units on two MFMA waves (12-KiB stages x 5), so the weight
-//              stream is spread over 128 workgroups instead of 64.  Rows past the batch read the 16-byte zero block.
+//   Lean64x8:  batches of <= 64 utterances.  Split-fp16: 64 rows x 8 units on two MFMA waves (12-KiB stages x 5), so the weight
+//              stream is spread over 128 workgroups instead of 64; rows past the batch read nothing (zeros).  Exact fp32
+//              (round 4): 32 rows x 8 units, the tile's K split over all FOUR MFMA waves (64-byte slices, 16-KiB stages of
+//              64 k x 5) - 2 x 128 = 256 workgroups at 64 utterances, every matrix pipe of the chip busy.  The 64-row fp32 form
+//              (two MFMA waves on 128 workgroups: a quarter of the chip's fp32 matrix rate) is why round 3 had to switch the
+//              two-role launches off for exact fp32 between 32 and 192 utterances.
 //   SmallFat:  batches of <= 32 utterances: both roles together are fewer workgroups than the chip has CUs, so nothing
 //              has to share a CU and the LSTM keeps the stand-alone small-batch tile (128 KiB of LDS, three tiles in
 //              flight - a batch-1 LSTM is a pure weight stream and lives on bytes in flight; the lean tiles' 48 KiB
@@ -51,7 +55,7 @@ struct LeanTiles<PREC_F16S> {
 template <>
 struct LeanTiles<PREC_F32> {
   using Lean64x16 = TileCfg<2, 2, 1, 5, PREC_F32>;
-  using Lean64x8 = TileCfg<2, 1, 1, 5, PREC_F32>;
+  using Lean64x8 = TileCfg<1, 1, 4, 5, PREC_F32, 0, 1, 1, 1>;
   using SmallFat = TileCfg<1, 1, 4, 4, PREC_F32>;
 };
 constexpr int kLean8MaxRows = 64;  // (measured with 128: B = 128 56.6 against 49.3 us per step, B = 96 53.6 / 48.1 - profiles/r03_w)
@@ -209,6 +213,11 @@ int frame_grid_size(int M, int P) { return ((P + kFrameCols - 1) / kFrameCols) *
 
 // which tile the LSTM role runs on, by batch size (see the three configurations above)
 enum LeanKind { LEAN_64x16, LEAN_64x8, SMALL_FAT };
+template <int PREC>
+static int lean_bm(LeanKind kind) {  // batch rows of the kind's tile
+  using TL = LeanTiles<PREC>;
+  return kind == SMALL_FAT ? TL::SmallFat::BM : (kind == LEAN_64x8 ? TL::Lean64x8::BM : TL::Lean64x16::BM);
+}
 static LeanKind lean_kind(int M, int n_producer, int H) {
   if (M <= kSmallFatMaxRows && n_producer + (H + 7) / 8 <= 224) return SMALL_FAT;
   return M <= kLean8MaxRows ? LEAN_64x8 : LEAN_64x16;
@@ -221,7 +230,8 @@ static void launch_frame_lstm_ph(const FrameArgs& f, const LstmArgs& l, const Pr
   const int n_frame = fcols * frows, n_proj = kHead ? proj_grid_size(pj.M, pj.N, pj.ksplit) : 0;
   const LeanKind kind = lean_kind(l.M, n_proj + n_frame, l.H);
   const int lcols = kind == LEAN_64x16 ? (l.H + 15) / 16 : (l.H + 7) / 8;
-  const int lrows = kind == SMALL_FAT ? (l.M + 31) / 32 : (l.M + 63) / 64;
+  const int bm = lean_bm<PREC>(kind);
+  const int lrows = (l.M + bm - 1) / bm;
   dim3 grid(n_proj + n_frame + lcols * lrows), block(kGemmThreads);
   if (kind == SMALL_FAT)
     hipLaunchKernelGGL((frame_lstm_kernel<K0H, PH, typename TL::SmallFat, 2, kHead>), grid, block, 0, st, f, l, pj, n_proj, n_frame, fcols, lcols);
@@ -289,7 +299,8 @@ void launch_attn_lstm(const AttnArgs& a, const LstmArgs& l, const ProjArgs* q, h
   else memset(&pq, 0, sizeof(pq));
   const LeanKind kind = lean_kind(l.M, a.B, l.H);
   const int lcols = kind == LEAN_64x16 ? (l.H + 15) / 16 : (l.H + 7) / 8;
-  const int lrows = kind == SMALL_FAT ? (l.M + 31) / 32 : (l.M + 63) / 64;
+  const int bm = l.prec == 1 ? lean_bm<PREC_F16S>(kind) : lean_bm<PREC_F32>(kind);
+  const int lrows = (l.M + bm - 1) / bm;
   dim3 grid(a.B + lcols * lrows), block(kGemmThreads);
   hipLaunchKernelGGL(attn_lstm_kernel_for(a.D, l.prec == 1, kind), grid, block, 0, st, a, l, pq, a.B, lcols);
 }
@@ -344,7 +355,9 @@ void launch_step_merged(const ProjArgs& pj, const FrameArgs& f, const LstmArgs& 
 void launch_lstm_lean(const LstmArgs& l, hipStream_t st) {
   if (l.M <= 0) return;
   const bool small = l.M <= kLean8MaxRows;
-  dim3 grid(small ? (l.H + 7) / 8 : (l.H + 15) / 16, (l.M + 63) / 64), block(kGemmThreads);
+  const LeanKind kind = small ? LEAN_64x8 : LEAN_64x16;
+  const int bm = l.prec == 1 ? lean_bm<PREC_F16S>(kind) : lean_bm<PREC_F32>(kind);
+  dim3 grid(small ? (l.H + 7) / 8 : (l.H + 15) / 16, (l.M + bm - 1) / bm), block(kGemmThreads);
   if (l.prec == 1) {
     if (small) hipLaunchKernelGGL((lstm_lean_kernel<LeanTiles<PREC_F16S>::Lean64x8>), grid, block, 0, st, l);
     else hipLaunchKernelGGL((lstm_lean_kernel<LeanTiles<PREC_F16S>::Lean64x16>), grid, block, 0, st, l);

@@ -35,7 +35,7 @@
 // instruction stream - hence the vmcnt arithmetic - is the same for every tile.
 //
 // K order inside a 128-byte slice.  fp32: lane half h = lane>>5 supplies k = 16h + 4q + e
-// for MFMA (q, e).  fp16: k16-step s uses the 16-byte column 2s + h, i.e. k = 16s + 8h + j.
+// for MFMA (q, e) (64-byte slices of the lean fp32 tile: k = 8h + 4q + e, q < 2).  fp16: k16-step s uses the 16-byte column 2s + h, i.e. k = 16s + 8h + j.
 // A and B use the same map, so every k is consumed exactly once.
 #pragma once
 #include "common.h"
@@ -62,15 +62,18 @@ struct TileCfg {
   static_assert(NMW == 4 || NMW == 2, "2 or 4 active MFMA waves per workgroup");
   static_assert(kBig || S >= 3, "ring needs at least 3 stages (fragment reads run one tile ahead of the MFMAs)");
   static_assert(!kBig || (PREC != PREC_F32 && WK == 1 && NMW == 4 && S >= 2), "big tiles: 16-bit modes, no intra-workgroup split-K");
-  static_assert(!HK || PREC != PREC_F32, "half-depth stages: 16-bit modes");
-  static_assert(!HK || WK == 1, "half-depth stages have no K slices");
+  // HK = 1: a wave's K slice of a tile is 64 bytes instead of 128.  16-bit modes: no K slices (WK = 1), 32 k per stage.  Exact
+  // fp32 (round 4): 16 k per wave and stage, so that FOUR MFMA waves (WK = 4) share a 32 x 32 output block inside 16-KiB stages -
+  // the lean fp32 tile of batches that have too few 64-row blocks to give every CU a workgroup (fused_kernels.hip).
+  static_assert(!HK || PREC == PREC_F32 || WK == 1, "half-depth stages of the 16-bit modes have no K slices");
   static constexpr int kPrec = PREC;
   static constexpr int EB = (PREC == PREC_F32) ? 4 : 2;      // element bytes
   static constexpr int NP = (PREC == PREC_F16S) ? 2 : 1;     // planes per operand
   static constexpr int BM = 32 * WM * TM;
   static constexpr int BN = 32 * WN * TN;
-  static constexpr int ROWB = HK ? 64 : 128 * WK;            // bytes per tile row per plane
+  static constexpr int ROWB = HK ? 64 * WK : 128 * WK;       // bytes per tile row per plane
   static constexpr int NS16 = HK ? 2 : 4;                    // k16 steps of a 16-bit tile (per K slice)
+  static constexpr int NQ32 = HK ? 2 : 4;                    // 16-byte columns of an fp32 tile per lane half (per K slice): 4 k each
   static constexpr int KT = ROWB / EB;                       // K elements per tile
   static constexpr int C16 = ROWB / 16;                      // 16-byte columns per tile row
   static constexpr int ROWS_PER_INST = 64 / C16;             // tile rows one wave instruction covers
@@ -256,7 +259,7 @@ __device__ __forceinline__ void gemm_tile(const LoaderA& la, const LoaderB& lb, 
 #pragma unroll
     for (int i = 0; i < NA; ++i) {
       const int row = (wave * NA + i) * RPI + lane / C16;
-      const bool ok = row < BM && la.row_ok(row) && dbg != 1;
+      const bool ok = row < BM && la.row_ok(row) && dbg != 1 && dbg != 5;  // (dbg 1 / 5 / 6: measurement ablations - all / A / B loads read nothing)
       const int c16 = (lane % C16) ^ Cfg::swz(row);
       ca[i] = c16 * EPC;
 #pragma unroll
@@ -265,7 +268,7 @@ __device__ __forceinline__ void gemm_tile(const LoaderA& la, const LoaderB& lb, 
 #pragma unroll
     for (int i = 0; i < NB; ++i) {
       const int row = (wave * NB + i) * RPI + lane / C16;
-      const bool ok = row < BN && lb.row_ok(row) && dbg != 1;
+      const bool ok = row < BN && lb.row_ok(row) && dbg != 1 && dbg != 6;
       const int c16 = (lane % C16) ^ Cfg::swz(row);
       cb[i] = c16 * EPC;
 #pragma unroll
@@ -622,22 +625,23 @@ __device__ __forceinline__ void gemm_tile(const LoaderA& la, const LoaderB& lb, 
             smem[row * LDO + (wn * TN + j) * 32 + l32] = v;
           }
     } else if constexpr (Cfg::kPrec == PREC_F32) {
-      int aoff[4], boff[4];  // byte offsets inside a stage
+      constexpr int NQ = Cfg::NQ32;
+      int aoff[NQ], boff[NQ];  // byte offsets inside a stage
 #pragma unroll
-      for (int q = 0; q < 4; ++q) {
-        const int c16 = wk * 8 + half * 4 + q;
+      for (int q = 0; q < NQ; ++q) {
+        const int c16 = wk * (2 * NQ) + half * NQ + q;
         aoff[q] = arow * ROWB + ((c16 ^ Cfg::swz(arow)) << 4);
         boff[q] = Cfg::kPlaneABytes + brow * ROWB + ((c16 ^ Cfg::swz(brow)) << 4);
       }
       // Fragment registers are double-buffered: the reads of tile t+1 are issued right after
       // the barrier that makes it visible and complete underneath tile t's MFMA chain.
-      f32x4 fa[2][4], fb[2][4];
+      f32x4 fa[2][NQ], fb[2][NQ];
       auto read_frags = [&](auto buf_c) {
         constexpr int buf = decltype(buf_c)::value;
         const char* st = lds + rstage * Cfg::kStageBytes;
         rstage = (rstage + 1 == S) ? 0 : rstage + 1;
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {
+        for (int q = 0; q < NQ; ++q) {
           fa[buf][q] = *reinterpret_cast<const f32x4*>(st + aoff[q]);
           fb[buf][q] = *reinterpret_cast<const f32x4*>(st + boff[q]);
         }
@@ -649,23 +653,21 @@ __device__ __forceinline__ void gemm_tile(const LoaderA& la, const LoaderB& lb, 
         // tile t's fragments were requested a whole tile ago: retire them here (no stall), in a
         // form the compiler's wait-count model sees, so it does not later drain the next reads
         __builtin_amdgcn_s_waitcnt(0xC07F);  // lgkmcnt(0) only
-        if (dbg == 4) {  // measurement ablation: no MFMAs
-          read_frags(std::integral_constant<int, cur ^ 1>{});
-          return;
-        }
         read_frags(std::integral_constant<int, cur ^ 1>{});
-        // The next tile's eight fragment reads ride in the gaps of this tile's MFMA chain, one per two MFMAs (round 4).  In
+        // The next tile's fragment reads ride in the gaps of this tile's MFMA chain, one per two MFMAs (round 4).  In
         // front of the chain they delayed its first MFMA by their issue time on every tile - the four MFMA waves leave the
         // barrier together and 32 ds_read_b128 queue up at the LDS - which cost the fp32 K loop ~50-300 cycles per 1024-cycle
-        // tile (tools/ubench_f32_partner.hip: 1147 -> 1097 per tile beside an idle partner, more with a busy one).
-        // (No runtime branch between the reads and the MFMAs: they must sit in ONE basic block to be interleaved.)
+        // tile (tools/ubench_f32_partner.hip: 1147 -> 1097 per tile beside an idle partner, more with a busy one; in the
+        // library, together with the loaders' scalar bookkeeping: 1725 -> 1270 cycles per tile of the decoder LSTM).
+        // (No runtime branch between the reads and the MFMAs - they must sit in ONE basic block to be interleaved - so the
+        // "no MFMAs" measurement ablation, dbg 4, no longer exists for this arithmetic mode.)
 #pragma unroll
-        for (int i = 0; i < 8; ++i) {
+        for (int i = 0; i < 2 * NQ; ++i) {
           __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
           __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
         }
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {
+        for (int q = 0; q < NQ; ++q) {
 #pragma unroll
           for (int e = 0; e < 4; ++e)
             acc = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[cur][q][e], fb[cur][q][e], acc, 0, 0, 0);
