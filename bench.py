@@ -14,14 +14,16 @@ With --gpus N > 1 and no torchrun environment the script starts its own N ranks 
 `python -m torch.distributed.run` child, before this process has made any GPU call) and
 exits with the child's code; under torchrun it is one of the ranks.
 
-One invocation times three legs, each with the same K steps / W warm-up steps, barrier +
+One invocation times these legs, each with the same K steps / W warm-up steps, barrier +
 synchronize on both sides and the maximum over ranks:
-  * the headline leg (value / dtype / roofline of the line): --precision / --postnet, default
-    split-fp16 arithmetic (include/ttsdec.h TTSDEC_PREC_SPLIT_F16);
-  * "f32_exact": the same workload on the reference's own arithmetic (exact fp32 MFMA everywhere);
-  * "b64_f32": BASELINE.json configs[1] (batch 64 per GPU, fp32).
-The injected-mask parity of the timed configuration against the CPU oracle (all 600 frames
-when the CPU sample covers them) is reported under "parity".
+  * the headline leg (value / dtype / roofline of the line): the reference's own arithmetic - exact fp32 on the
+    fp32-input matrix instruction for every GEMM, Postnet fp32 (--precision / --postnet change it);
+  * "split_f16": the same workload in the library's opt-in split-fp16 mode (include/ttsdec.h TTSDEC_PREC_SPLIT_F16:
+    two fp16 planes per operand, narrower than fp32 - a named sub-record, never the headline);
+  * "b64_f32": BASELINE.json configs[1] (batch 64 per GPU, fp32);
+  * "vits2": BASELINE.json configs[4] (TextEncoder + reverse flow, --workload vits2's step on a short run).
+The injected-mask parity of the timed configurations against the CPU oracle (all 600 frames when the CPU sample
+covers them), including the bf16 Postnet of configs[2], is reported under "parity".
 """
 import argparse
 import hashlib
@@ -72,28 +74,51 @@ DTYPE_TEXT = {
 POSTNET_TEXT = {"f32": "; Postnet f32", "split_f16": "; Postnet split-fp16", "bf16": "; Postnet bf16"}
 
 
+def cell_model(cfg):
+    """The decoder cell's sizes as the byte / FLOP model needs them, from the SELECTED config (reference: tacotron.py:165-214,
+    decoder_cell.py:66-140 Taco2DecoderCell, :143-195 Taco2ProdDecoderCell)."""
+    dd = cfg["model"]["decoder"]
+    taco2 = dd["type"] == "tacotron2"
+    r, M = dd["r"], cfg["audio"].get("num_mels", 80)
+    D, Ha, Hd, P = cfg["model"]["encoder"]["dim_out"], dd["dim_rnn"][0], dd["dim_rnn"][1], dd["dim_pre"]
+    return {
+        "taco2": taco2, "r": r, "M": M, "D": D, "Ha": Ha, "Hd": Hd, "P": P,
+        "P0": 128 if taco2 else P,                      # PreNet hidden width (decoder_cell.py:74-76 / :152)
+        "Kq": Ha + Hd if taco2 else Ha,                 # query input: cat[h0, h1, zeros] (the zero block is not read) / h_att
+        "Kproj": Ha + Hd if taco2 else Hd + D,          # projection input: cat[h0, h1, zeros] / cat[h_dec, ctx]
+        "Nproj": r * M + r,                             # fc_mel + fc_stop rows
+    }
+
+
 # Algorithmic bytes per decode step (SURVEY.md 8d / BASELINE.md 4), split by kernel.
-# weights (fp32 params incl. biases) + per-utterance reads/writes, L = memory length.
-def step_bytes(B, L, d):
-    P, D, Ha, Hd, M = d["dim_pre"], 512, d["dim_rnn"][0], d["dim_rnn"][1], 80
+# weights (fp32 params incl. biases) + per-utterance reads/writes, L = memory length; m = cell_model(config).
+def step_bytes(B, L, m):
+    P, P0, D, Ha, Hd, M, r = m["P"], m["P0"], m["D"], m["Ha"], m["Hd"], m["M"], m["r"]
     w = {
-        "prenet": (P * M + P + P * P + P) * 4,
+        "prenet": (P0 * M + P0 + P * P0 + P) * 4,
         "lstm_att": (4 * Ha * (P + D + Ha) + 8 * Ha) * 4,
-        "query": D * Ha * 4,
+        "query": D * m["Kq"] * 4,
         "lstm_dec": (4 * Hd * (Ha + D + Hd) + 8 * Hd) * 4,
-        "proj": ((M + 1) * (Hd + D) + M + 1) * 4,
+        "proj": (m["Nproj"] * m["Kproj"] + m["Nproj"]) * 4,
     }
     per_utt = {
-        "prenet": M * 4 + 2 * P,                       # y_prev + 2 uint8 masks
+        "prenet": M * 4 + P0 + P,                      # y_prev (the last frame of the previous step) + the two uint8 masks
         "lstm_att": 4 * Ha * 4 + D * 4,                # h,c read+write + ctx read
         "query": 0,
         "attention": L * D * 4 + 2 * L * 4 + L * 4 + D * 4,  # memory pass + w r/w + w_out + ctx write
         "lstm_dec": 4 * Hd * 4,
-        "proj": M * 4 + 4,                             # y + s out
+        "proj": r * M * 4 + r * 4,                     # y + s out
     }
     out = {k: w.get(k, 0) + B * per_utt.get(k, 0) for k in set(w) | set(per_utt)}
     out["step"] = sum(out.values())
     return out
+
+
+def step_flops(B, L, m):
+    """2 per weight of the five GEMM groups (biases excluded) + the two passes over `memory`."""
+    P, P0, D, Ha, Hd, M = m["P"], m["P0"], m["D"], m["Ha"], m["Hd"], m["M"]
+    n_w = P0 * M + P * P0 + 4 * Ha * (P + D + Ha) + D * m["Kq"] + 4 * Hd * (Ha + D + Hd) + m["Nproj"] * m["Kproj"]
+    return B * (2 * n_w + 4 * L * D)
 
 
 F16_MFMA_PEAK_TFLOPS = 2500.0  # MI355X_MICROARCH.md: dense bf16/f16 matrix peak
@@ -138,13 +163,15 @@ def vits2_flops(Tx, Ty, d):
     return te, d["n_flows"] * per_flow
 
 
-def bench_vits2(args, T, torch, dist, dev, world, rank):
+def bench_vits2(args, T, torch, dist, dev, world, rank, cpu_baseline=True):
     """Second hot path: one step = TextEncoder over [B, 120] tokens + the reverse
-    flow over [B, 192, 600] latent frames.  Utterances are independent: ranks take equal shares, no collective."""
+    flow over [B, 192, 600] latent frames.  Utterances are independent: ranks take equal shares, no collective.
+    Returns the record (rank 0 prints it when this is the invocation's workload; the tacotron workload carries it as
+    its "vits2" sub-record)."""
     import warnings
 
     warnings.filterwarnings("ignore", category=FutureWarning)
-    B = args.batch if args.batch != 256 else 64
+    B = args.batch if (args.workload == "vits2" and args.batch != 256) else 64
     Tx, Ty = args.mem_len, args.frames
     D = dict(n_vocab=178, inter_channels=192, hidden_channels=192, filter_channels=768, n_heads=2, n_layers=6, kernel_size=3, window_size=4,
              flow_hidden=192, flow_kernel=5, flow_wn_layers=4, n_flows=4)
@@ -213,7 +240,7 @@ def bench_vits2(args, T, torch, dist, dev, world, rank):
                      "peak_note": "dense f16 MFMA peak (2500 TFLOP/s) / 3 products per fp32 product",
                      "traffic": None, "alg_flops_per_utterance": {"text_encoder": f_te, "flow_reverse": f_fl}},
     }
-    if rank == 0 and not args.no_cpu_baseline:
+    if rank == 0 and cpu_baseline and not args.no_cpu_baseline:
         from oracle import vits2_oracle as V
 
         d = V.Vits2Dims()
@@ -229,10 +256,7 @@ def bench_vits2(args, T, torch, dist, dev, world, rank):
         ct = time.perf_counter() - t1
         res["cpu_baseline"] = {"value": round(bc * Ty / ct, 1), "unit": "mel-frames/s", "cores": cores, "cpu": cpu_model(), "kind": "port",
                                "sample": f"oracle (torch-CPU restatement of the reference blocks) on B={bc}: TextEncoder {Tx} tokens + reverse flow {Ty} frames, {cores} threads"}
-    if rank == 0:
-        print(json.dumps(res), flush=True)
-    if world > 1:
-        dist.destroy_process_group()
+    return res
 
 
 class Workload:
@@ -355,8 +379,8 @@ class Workload:
         args, _lib = self.args, self._lib
         io = self.inputs(B)
         self.eng.set_precision(precision)
-        dd = LJSPEECH["model"]["decoder"]  # (byte / FLOP model of the LJSpeech cell)
-        bytes_k = step_bytes(B, args.mem_len, dd)
+        cm = cell_model(self.cfg)  # (byte / FLOP model of the SELECTED config's cell)
+        bytes_k = step_bytes(B, args.mem_len, cm)
         alg = dict(bytes_k)
         alg.update({"prenet0": 0, "prenet1": 0})
 
@@ -369,9 +393,12 @@ class Workload:
         # separate passes), so the figures come from the committed capture - and only when that capture was taken on exactly
         # these kernel sources (digest match), else null
         traffic, traffic_src = {}, None
-        for fn in ("r03_traffic.json",):
+        pdir = os.path.join(ROOT, "profiles")
+        for fn in sorted(f for f in os.listdir(pdir) if f.startswith("r04_traffic") and f.endswith(".json")):
             try:
-                tj = json.load(open(os.path.join(ROOT, "profiles", fn)))
+                tj = json.load(open(os.path.join(pdir, fn)))
+                if tj.get("config", "ljspeech") != args.config:
+                    continue
                 if tj.get("sources_digest") == sources_digest() and tj.get("precision") == precision and tj.get("batch") == B:
                     traffic = {k: v.get("hbm_bytes") for k, v in tj["per_launch"].items()}
                     traffic_src = {"file": "profiles/" + fn, "sources_digest": tj["sources_digest"], "commit": tj.get("captured_at_commit")}
@@ -389,10 +416,7 @@ class Workload:
             ent["traffic"] = traffic.get(key)
             ent["traffic_over_alg"] = round(traffic[key] / ent["alg_bytes"], 3) if traffic.get(key) and ent["alg_bytes"] else None
             ent["ms_in_loop"], ent["ms_alone"] = round(ent["ms_in_loop"], 5), round(ent["ms_alone"], 5)
-        # FLOPs of one step: 2 per weight of the five GEMM groups + the two passes over `memory`
-        P, D, Ha, Hd, M = dd["dim_pre"], 512, dd["dim_rnn"][0], dd["dim_rnn"][1], 80
-        n_w = P * M + P * P + 4 * Ha * (P + D + Ha) + D * Ha + 4 * Hd * (Ha + D + Hd) + (M + 1) * (Hd + D)
-        flops = B * (2 * n_w + 4 * args.mem_len * D)
+        flops = step_flops(B, args.mem_len, cm)
         step_s = decode_step_ms * 1e-3
         hbm_gbs = bytes_k["step"] / step_s / 1e9
         if precision == "f32":
@@ -463,7 +487,8 @@ class Workload:
         def rel(a, b):
             return float(((a - b).abs() / (1e-5 / 1e-4 + b.abs())).max())
 
-        parity = {"frames_compared": tc, "batch": B, "tolerance": "max |hip - oracle| / (0.1 + |oracle|) <= 1e-4 (rtol 1e-4, atol 1e-5); argmax(w) exact"}
+        parity = {"frames_compared": tc, "batch": B, "tolerance": "max |hip - oracle| / (0.1 + |oracle|) <= 1e-4 (rtol 1e-4, atol 1e-5); argmax(w) exact; "
+                  "the bf16 Postnet (BASELINE.json configs[2]: 8 significand bits per operand) is REPORTED, not held to that bar"}
         for precision, postnet in zip(precisions, postnets):
             self.eng.set_precision(precision)
             self.decode(io, _lib.DROPOUT_MASKS, full)
@@ -492,9 +517,10 @@ def main():
     ap.add_argument("--batch", type=int, default=256, help="utterances per GPU")
     ap.add_argument("--mem-len", type=int, default=120)
     ap.add_argument("--frames", type=int, default=600)
-    ap.add_argument("--postnet", choices=["f32", "bf16", "split_f16"], default="split_f16")
-    ap.add_argument("--precision", choices=["f32", "split_f16"], default="split_f16",
-                    help="arithmetic of the headline leg's LSTM / PreNet / query / projection GEMMs (include/ttsdec.h TTSDEC_PREC_*)")
+    ap.add_argument("--postnet", choices=["f32", "bf16", "split_f16"], default="f32")
+    ap.add_argument("--precision", choices=["f32", "split_f16"], default="f32",
+                    help="arithmetic of the headline leg's LSTM / PreNet / query / projection GEMMs (include/ttsdec.h TTSDEC_PREC_*): "
+                         "f32 = the reference's own (default), split_f16 = the library's opt-in fast mode")
     ap.add_argument("--config", choices=sorted(CONFIGS), default="ljspeech",
                     help="model dims: ljspeech = BASELINE.json's config (default); rdh / sandra = the other shipped configs")
     ap.add_argument("--workload", choices=["tacotron", "vits2"], default="tacotron",
@@ -504,7 +530,7 @@ def main():
                     help="PreNet dropout source: philox = drawn on the device (default, SURVEY 8d 'mode 2'); masks = injected keep-masks "
                          "resident in HBM ('mode 1': what the parity runs use)")
     ap.add_argument("--no-cpu-baseline", action="store_true", help="skip the CPU baseline and the parity record")
-    ap.add_argument("--no-extra-legs", action="store_true", help="time only the headline leg (no f32_exact / b64_f32 sub-records)")
+    ap.add_argument("--no-extra-legs", action="store_true", help="time only the headline leg (no split_f16 / b64_f32 / vits2 sub-records)")
     ap.add_argument("--cpu-frames", type=int, default=0, help="decode frames for the CPU baseline sample (0 = auto)")
     args = ap.parse_args()
 
@@ -540,8 +566,20 @@ def main():
     import torch_tts_amd as T
     from torch_tts_amd import distributed as D
 
+    dist_info = {"backend": dist.get_backend() if world > 1 else None, "world_size": dist.get_world_size() if world > 1 else 1,
+                 "collectives": "one broadcast of the packed weight blob per engine at start-up; none in the step loop"}
+
+    def finish(out):
+        if rank == 0:
+            print(json.dumps(out), flush=True)
+        if world > 1:
+            dist.barrier()  # (rank 0 may still be in its CPU-baseline leg: nobody tears the group down under it)
+            dist.destroy_process_group()
+
     if args.workload == "vits2":
-        return bench_vits2(args, T, torch, dist, dev, world, rank)
+        res = bench_vits2(args, T, torch, dist, dev, world, rank)
+        res["distributed"] = dict(dist_info, collectives="none (every rank builds the same weights from the seed)")
+        return finish(res)
 
     wk = Workload(args, T, torch, D, dev, world, rank)
     B, L, NF = args.batch, args.mem_len, args.frames
@@ -559,13 +597,17 @@ def main():
             "global_batch": B * world, "mem_len": L, "frames": NF, "dropout": args.dropout, "parallelism": f"utterance-shard x{world}",
             "lstm_precision": head["lstm_precision"],
         },
+        "distributed": dist_info,
         "rtf": head["rtf"], "audio_seconds_per_s": round(head["value"] * FRAME_SEC, 1),
         "decode_only_frames_per_s": head["decode_only_frames_per_s"],
         "roofline": wk.roofline(B, args.precision, head["decode_step_ms"]),
     }
     legs = []
     if lj and not args.no_extra_legs:
-        if not (args.precision == "f32" and args.postnet == "f32"):
+        if args.precision != "split_f16":
+            legs.append(("split_f16", B, "split_f16", "split_f16",
+                         "the headline workload in the library's opt-in split-fp16 mode: two fp16 planes per operand (narrower than fp32), Postnet split-fp16"))
+        else:
             legs.append(("f32_exact", B, "f32", "f32", "the headline workload on the reference's own arithmetic: exact fp32 for every GEMM, Postnet fp32"))
         if B != 64:
             legs.append(("b64_f32", 64, "f32", "f32", "BASELINE.json configs[1]: batch 64 per GPU, exact fp32"))
@@ -578,16 +620,24 @@ def main():
             "decode_only_frames_per_s": leg["decode_only_frames_per_s"], "global_batch": leg["global_batch"],
             "roofline": rf,
         }
+    if lj and not args.no_extra_legs:
+        # BASELINE.json configs[4] on the driver's clock too: the vits2 workload's own step, a short run (its CPU leg stays
+        # with `--workload vits2`)
+        va = argparse.Namespace(**vars(args))
+        va.steps, va.warmup = max(3, min(args.steps, 10)), max(1, min(args.warmup, 2))
+        v = bench_vits2(va, T, torch, dist, dev, world, rank, cpu_baseline=False)
+        out["vits2"] = {k: v[k] for k in ("value", "unit", "ms_per_step", "steps", "warmup", "dtype", "config", "rtf", "text_encoder_ms",
+                                           "flow_reverse_ms", "roofline")}
+        out["vits2"]["what"] = "BASELINE.json configs[4]: VITS2 TextEncoder + reverse flow, `bench.py --workload vits2`'s step"
 
     if rank == 0 and lj and not args.no_cpu_baseline:  # (rank 0's shard and host cores, whatever the world size)
-        precs, posts = [args.precision], [args.postnet]
-        if not args.no_extra_legs and not (args.precision == "f32" and args.postnet == "f32"):
-            precs.append("f32"); posts.append("f32")
-        out["cpu_baseline"], out["parity"] = wk.cpu_baseline_and_parity(B, precs, posts)
-    if rank == 0:
-        print(json.dumps(out), flush=True)
-    if world > 1:
-        dist.destroy_process_group()
+        pairs = [(args.precision, args.postnet)]
+        if not args.no_extra_legs:
+            for pr in (("f32", "f32"), ("split_f16", "split_f16"), ("f32", "bf16")):
+                if pr not in pairs:
+                    pairs.append(pr)
+        out["cpu_baseline"], out["parity"] = wk.cpu_baseline_and_parity(B, [a for a, _ in pairs], [b for _, b in pairs])
+    finish(out)
 
 
 if __name__ == "__main__":

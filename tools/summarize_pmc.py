@@ -42,8 +42,8 @@ def short(name):
             return label
     if "lstm_kernel" in name:
         return "lstm_dec" if name.rstrip().endswith("1>(ttsdec::LstmArgs)") else "lstm_att"
-    if "gemm_rows_kernel<ttsdec::TileCfg<1, 1, 2, 4, 1, 0, 1, 1, 0>, 0, 0>" in name:
-        return "query"  # (the split-K query projection is the only user of this instantiation in a decode step)
+    if "gemm_rows_kernel<ttsdec::TileCfg<1, 1, 2, 4, 1, 0, 1, 1, 0>, 0, 0>" in name or "gemm_rows_kernel<ttsdec::TileCfg<1, 1, 4, 4, 0, 0, 1, 1, 0>, 0, 0>" in name:
+        return "query"  # (the split-K query projection is the only user of these instantiations - split-fp16 / exact fp32 - in a decode step)
     if "gemm_rows_kernel" in name:
         return "gemm_rows:" + name.split("gemm_rows_kernel<")[1].split(">(")[0].replace("ttsdec::", "")
     return name.split("(")[0][:80]

@@ -788,19 +788,21 @@ int overlap_level(const ttsdec_handle* h, int B) {
     // 60.5 / 52.8, B = 1 54.6 / 46.9; exact fp32 B = 256 147.2 / 137.1, B = 64 73.0 / 80.6, B = 1 69.3 / 59.3 - the fp32 rule of the
     // other cell: not in the middle batch range.
     if (h->overlap >= 0) return h->overlap > 1 ? 1 : h->overlap;
-    if (lstm_prec(h)) return 1;
-    return (B <= 32 || B >= 192) ? 1 : 0;
+    // (round 4, with the 32-row fp32 lean tile: exact fp32 B = 64 69.9 / 62.9, B = 128 86.9 / 82.7 - level 1 at every batch size now)
+    return 1;
   }
   if (h->overlap >= 0) return h->overlap;
   // Round 3 (after the sc1 hand-offs and the per-row-block counters; profiles/r03_t_levels_sweep.txt, us per step, levels 0 / 1 / 2):
   // split-fp16 B = 96 78.3 / 62.4 / 48.8, 192 80.1 / 64.8 / 59.3, 320 128.5 / 102.5 / 88.8, 384 131.1 / 110.0 / 98.3, 512 147.7 / 131.6 /
   // 117.8, 1024 - / 262.6 / 235.0, 2048 - / 504.1 / 455.8: level 2 at every batch size (round 2 had level 1 above 320, +-1.5 % then).
   if (lstm_prec(h)) return 2;
-  // exact fp32: the matrix pipe is the LSTMs' bound there, and the 64x8 lean tile of the middle batch sizes keeps only
-  // two of a CU's four matrix pipes busy - so small batches (stand-alone tile) and chip-filling ones only.  us per step for
-  // levels 0 / 1 / 2: B = 32 76.1 / 66.6 / 56.1, B = 64 77.1 / 87.2 / 111.4, B = 128 104.3 / 106.1 / 117.2, B = 192 143.7 / 130.0 /
-  // 119.4, B = 384 254.0 / 228.7 / 209.3, B = 512 - / 245.6 / 226.3, 1024 - / 473.8 / 435.2, 2048 - / 915.3 / 838.1
-  return B <= 32 ? 2 : (B < 192 ? 0 : 2);
+  // exact fp32 (round 4, after the loaders' buffer-descriptor DMA, the interleaved fragment reads and the 32-row lean tile whose
+  // four MFMA waves share a block's K axis - fused_kernels.hip): us per step for levels 0 / 1 / 2: B = 32 68.7 / 60.4 / 50.5,
+  // 40 68.6 / 63.4 / 60.0, 64 68.5 / 62.8 / 61.2, 80 96.3 / 79.4 / 65.4, 96 84.8 / 74.4 / 66.5, 112 86.0 / 81.5 / 91.2, 128 84.8 / 79.4 /
+  // 88.0, 144 121.3 / 105.7 / 97.5, 176 121.6 / 106.7 / 98.3, 192 122.4 / 107.6 / 99.1, 256 - / - / 102.7 (round 3: level 0 between 32
+  // and 192 utterances - its 64-row lean tile kept two of a CU's four matrix pipes busy there: B = 64 77.1 / 87.2 / 111.4).
+  // Between 97 and 128 utterances the 64 x 16-unit tile has only two row blocks (128 workgroups): one two-role launch.
+  return B <= 96 ? 2 : (B <= 128 ? 1 : 2);
 }
 // The projection as the head role of the next step's frame launch, wherever the register-weight kernel applies (split-fp16).
 // us per step without / with it, same box: B = 1 43.0 / 39.8, B = 64 51.8 / 50.1, B = 128 54.2 / 53.5, B = 256 73.4 / 73.3 (there

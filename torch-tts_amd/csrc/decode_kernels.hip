@@ -107,7 +107,11 @@ __global__ __launch_bounds__(kGemmThreads, Cfg::kWavesPerSimd) void gemm_rows_ke
 
   // Epilogue operands are requested BEFORE the K loop (their latency hides under it) - for the
   // small tiles, where a thread owns <= 8 outputs; the 128x128 tiles fetch them in the epilogue.
-  constexpr bool kPre = EPT <= 8;
+  // (not the lean tile: it runs at 128 registers so that two workgroups share a CU, and 4 x 8 pre-loaded operands across the K
+  // loop made round 3's short-K row GEMM - gemm_rows_kernel<TileCfg<2,2,1,4,F16S,0,1,1,1>, A_PLAIN, EPI_GENERIC>, a quarter of a
+  // VITS2 pass - spill 14 registers to scratch; its per-column operand is loaded once and the per-element ones in one batch
+  // after the loop, like the 128 x 128 tiles')
+  constexpr bool kPre = EPT <= 8 && Cfg::kWavesPerSimd < 4;
   constexpr int NPRE = kPre ? EPT : 1;
   auto load_epi = [&](int m, int n, bool ok, float& pb, float& pr, float& prm, uint8_t& pm) {
     pb = (ok && g.bias != nullptr) ? g.bias[n] : 0.f;

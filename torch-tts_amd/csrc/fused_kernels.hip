@@ -20,6 +20,7 @@
 // Measured alternatives: the same overlap as two STREAMS (round 1: slower - cross-stream graph
 // edges, one 128-KiB workgroup per CU); the early segments as a separate partial-sum launch beside role A plus
 // a "late" launch (round 2: 86.4 vs 88.3 us per step - the extra launch costs what the overlap wins).
+#include <stdlib.h>
 #include <string.h>
 
 #include <map>
@@ -58,6 +59,11 @@ struct LeanTiles<PREC_F32> {
   using Lean64x8 = TileCfg<1, 1, 4, 5, PREC_F32, 0, 1, 1, 1>;
   using SmallFat = TileCfg<1, 1, 4, 4, PREC_F32>;
 };
+// exact fp32: the 32-row tile (every matrix pipe busy from 33 utterances up) while its workgroups - 128 per 32 rows - still fit the
+// chip beside the producer role's: us per step at levels 0 / 1 / 2 with it, B = 80 96.3 / 79.4 / 65.4, B = 96 84.8 / 74.4 / 66.5, B = 128
+// 86.2 / 84.7 / 88.2 - against the 64-row tile's B = 80 96.3 / 86.8 / 90.7, 96 85.5 / 81.3 / 90.7, 112 86.0 / 81.5 / 91.2, 128 84.8 / 79.4 / 88.0
+// (gpurun sessions r4k / r4l)
+constexpr int kLean8MaxRowsF32 = 96;
 constexpr int kLean8MaxRows = 64;  // (measured with 128: B = 128 56.6 against 49.3 us per step, B = 96 53.6 / 48.1 - profiles/r03_w)
 constexpr int kSmallFatMaxRows = 32;
 static_assert(LeanTiles<PREC_F16S>::Lean64x16::kLdsBytes <= 80 * 1024 && LeanTiles<PREC_F32>::Lean64x16::kLdsBytes <= 80 * 1024 &&
@@ -218,9 +224,14 @@ static int lean_bm(LeanKind kind) {  // batch rows of the kind's tile
   using TL = LeanTiles<PREC>;
   return kind == SMALL_FAT ? TL::SmallFat::BM : (kind == LEAN_64x8 ? TL::Lean64x8::BM : TL::Lean64x16::BM);
 }
-static LeanKind lean_kind(int M, int n_producer, int H) {
+static int lean8_max_rows(bool f16) {
+  if (f16) return kLean8MaxRows;
+  static const int f32_max = [] { const char* e = getenv("TTSDEC_LEAN8_F32_MAX"); return e ? atoi(e) : kLean8MaxRowsF32; }();  // (measurement)
+  return f32_max;
+}
+static LeanKind lean_kind(int M, int n_producer, int H, bool f16 = true) {
   if (M <= kSmallFatMaxRows && n_producer + (H + 7) / 8 <= 224) return SMALL_FAT;
-  return M <= kLean8MaxRows ? LEAN_64x8 : LEAN_64x16;
+  return M <= lean8_max_rows(f16) ? LEAN_64x8 : LEAN_64x16;
 }
 
 template <int K0H, int PH, int PREC, bool kHead>
@@ -228,7 +239,7 @@ static void launch_frame_lstm_ph(const FrameArgs& f, const LstmArgs& l, const Pr
   using TL = LeanTiles<PREC>;
   const int fcols = (f.P + kFrameCols - 1) / kFrameCols, frows = (f.M + kFrameRows - 1) / kFrameRows;
   const int n_frame = fcols * frows, n_proj = kHead ? proj_grid_size(pj.M, pj.N, pj.ksplit) : 0;
-  const LeanKind kind = lean_kind(l.M, n_proj + n_frame, l.H);
+  const LeanKind kind = lean_kind(l.M, n_proj + n_frame, l.H, PREC == PREC_F16S);
   const int lcols = kind == LEAN_64x16 ? (l.H + 15) / 16 : (l.H + 7) / 8;
   const int bm = lean_bm<PREC>(kind);
   const int lrows = (l.M + bm - 1) / bm;
@@ -290,14 +301,14 @@ static attn_lstm_fn attn_lstm_kernel_for(int D, bool f16, LeanKind kind) {
   return f16 ? attn_lstm_kernel_of<2, PREC_F16S>(kind) : attn_lstm_kernel_of<2, PREC_F32>(kind);
 }
 int attn_lstm_resident_slots(int B, int H, int D, bool f16) {
-  return resident_slots(reinterpret_cast<const void*>(attn_lstm_kernel_for(D, f16, lean_kind(B, B, H))));
+  return resident_slots(reinterpret_cast<const void*>(attn_lstm_kernel_for(D, f16, lean_kind(B, B, H, f16))));
 }
 void launch_attn_lstm(const AttnArgs& a, const LstmArgs& l, const ProjArgs* q, hipStream_t st) {
   if (a.B <= 0) return;
   ProjArgs pq;
   if (q != nullptr) pq = *q;
   else memset(&pq, 0, sizeof(pq));
-  const LeanKind kind = lean_kind(l.M, a.B, l.H);
+  const LeanKind kind = lean_kind(l.M, a.B, l.H, l.prec == 1);
   const int lcols = kind == LEAN_64x16 ? (l.H + 15) / 16 : (l.H + 7) / 8;
   const int bm = l.prec == 1 ? lean_bm<PREC_F16S>(kind) : lean_bm<PREC_F32>(kind);
   const int lrows = (l.M + bm - 1) / bm;
@@ -354,7 +365,7 @@ void launch_step_merged(const ProjArgs& pj, const FrameArgs& f, const LstmArgs& 
 
 void launch_lstm_lean(const LstmArgs& l, hipStream_t st) {
   if (l.M <= 0) return;
-  const bool small = l.M <= kLean8MaxRows;
+  const bool small = l.M <= lean8_max_rows(l.prec == 1);
   const LeanKind kind = small ? LEAN_64x8 : LEAN_64x16;
   const int bm = l.prec == 1 ? lean_bm<PREC_F16S>(kind) : lean_bm<PREC_F32>(kind);
   dim3 grid(small ? (l.H + 7) / 8 : (l.H + 15) / 16, (l.M + bm - 1) / bm), block(kGemmThreads);
