@@ -39,6 +39,13 @@ struct LoaderConv {
   }
   __device__ __forceinline__ long col_off(int c16) const { return (long)c16 * 16; }
   __device__ __forceinline__ long tile_inc(int rowb) const { return rowb; }
+  // buffer-descriptor form (gemm_tile kBufDma): based at THIS workgroup's first im2col row - so the per-lane offsets stay small
+  // whatever the size of x (Postnet at 2048 x 600 frames: 2.5 GB) - which for the batch's first frames lies `taps/2` frames
+  // in front of x: only lanes whose k is inside the row's window [k_lo, k_hi) are ever in range, and those address x itself
+  __device__ __forceinline__ const void* seg_base(int, int plane) const {
+    return static_cast<const char*>(plane == 0 ? x : x_lo) + ((long)m0 - (taps >> 1)) * Cin * EB;
+  }
+  __device__ __forceinline__ unsigned row_off(int r, int) const { return (unsigned)r * (unsigned)Cin * EB; }
 };
 
 // rows n0.. of a PyTorch-layout weight [N, K] cut into the same K segments as A
@@ -55,6 +62,16 @@ struct LoaderW {
   }
   __device__ __forceinline__ long col_off(int c16) const { return (long)c16 * 16; }
   __device__ __forceinline__ long tile_inc(int rowb) const { return rowb; }
+  // buffer-descriptor form (gemm_tile kBufDma; row-major weights): based at this workgroup's first weight row
+  __device__ __forceinline__ const void* seg_base(int i, int plane) const {
+    const Seg3& s = plane == 0 ? w : w_lo;
+    const int ld = i == 0 ? s.ld0 : (i == 1 ? s.ld1 : s.ld2);
+    return static_cast<const char*>(i == 0 ? s.p0 : (i == 1 ? s.p1 : s.p2)) + (long)n0 * ld * EB;
+  }
+  __device__ __forceinline__ unsigned row_off(int r, int i) const {
+    const int ld = i == 0 ? w.ld0 : (i == 1 ? w.ld1 : w.ld2);
+    return (unsigned)r * (unsigned)ld * EB;
+  }
 };
 
 template <class Cfg, int AK, int EK>
@@ -160,7 +177,9 @@ __global__ __launch_bounds__(kGemmThreads, Cfg::kWavesPerSimd) void gemm_rows_ke
   if (AK == A_CONV) {
     const LoaderConv<EB> la{g.a.p0, g.a_lo.p0, m0, g.M, g.T, g.Cin, g.taps, g.K};
     const LoaderW<EB> lb{make_seg1(g.W, g.ldw, g.K), make_seg1(g.W_lo, g.ldw, g.K), n0, g.N};
-    gemm_tile<Cfg>(la, lb, smem, live);
+    // (one K segment, both operands based at the workgroup's own first row: the buffer-descriptor loaders of gemm_tile.h apply
+    // whatever the operand sizes)
+    gemm_tile<Cfg, LoaderConv<EB>, LoaderW<EB>, NoGate, true>(la, lb, smem, live);
   } else {
     Seg3 s = g.a, s_lo = g.a_lo;
     if (g.teacher != nullptr && g.t > 0 && as_g(g.teacher_flags)[g.t - 1] != 0) {

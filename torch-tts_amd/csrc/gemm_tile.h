@@ -228,7 +228,6 @@ __device__ __forceinline__ void gemm_tile(const LoaderA& la, const LoaderB& lb, 
   if (is_loader && kBufDma) {
     // ====================== loader waves, buffer-descriptor form ======================
     if constexpr (kBufDma) {
-    static_assert(!LoaderA::kRange, "per-row k windows keep the per-lane address form");
     // ONE descriptor per operand plane, based at the lowest of the operand's segment pointers; a segment's distance from it is
     // folded into the per-lane offsets below.  (The segments of an LSTM operand are slices of one allocation - the decoder
     // workspace, the packed weight blob - so the distances are far below the 2-GiB range; api.hip refuses larger ones.)  A
@@ -256,6 +255,11 @@ __device__ __forceinline__ void gemm_tile(const LoaderA& la, const LoaderB& lb, 
       }
     unsigned va[3][NA], vb[3][NB];  // per-lane byte offset inside a segment (row + swizzled column), per K segment; planes share it
     int ca[NA], cb[NB];             // element offset of the lane's column inside a tile
+    // Per-row valid k windows (LoaderA::kRange: conv padding).  The per-lane test - two compares and a select in front of every
+    // DMA - is what the buffer form exists to avoid, so each instruction also gets the k range in which ALL its lanes are
+    // valid (wave-uniform, computed once): tiles inside it take the test-free path; only the tiles at an utterance's first
+    // and last frames take the per-lane one.
+    int aklo[NA], akhi[NA], alo_all[NA], ahi_all[NA];
 #pragma unroll
     for (int i = 0; i < NA; ++i) {
       const int row = (wave * NA + i) * RPI + lane / C16;
@@ -264,6 +268,16 @@ __device__ __forceinline__ void gemm_tile(const LoaderA& la, const LoaderB& lb, 
       ca[i] = c16 * EPC;
 #pragma unroll
       for (int sg = 0; sg < 3; ++sg) va[sg][i] = ok ? la.row_off(row, sg) + (unsigned)la.col_off(c16) : kBufRange;
+      if constexpr (LoaderA::kRange) {
+        aklo[i] = ok ? la.k_lo(row) : 0;
+        akhi[i] = ok ? la.k_hi(row) : 0x7fffff;
+        // (k < 2^24: exact in fp32, so the wave-wide maximum / minimum can use the DPP float reductions of common.h)
+        alo_all[i] = __builtin_amdgcn_readfirstlane((int)wave_max((float)aklo[i]));
+        ahi_all[i] = __builtin_amdgcn_readfirstlane((int)-wave_max(-(float)akhi[i]));
+        if (!ok) akhi[i] = 0;
+      } else {
+        aklo[i] = akhi[i] = alo_all[i] = ahi_all[i] = 0;
+      }
     }
 #pragma unroll
     for (int i = 0; i < NB; ++i) {
@@ -350,14 +364,23 @@ __device__ __forceinline__ void gemm_tile(const LoaderA& la, const LoaderB& lb, 
         if (Cfg::kDummy && (wave * NB + i) * 1024 >= Cfg::kPlaneBBytes) dst = lds + Cfg::kDummyOff + wave * 1024;
         return dst;
       };
-      if (partial) {
+      bool slow = partial;
+      if constexpr (LoaderA::kRange) {
+#pragma unroll
+        for (int i = 0; i < NA; ++i) slow = slow || kpos < alo_all[i] || kpos + KT > ahi_all[i];
+      }
+      if (slow) {
         // (its own block, kept apart from the common one by the asm statement: merged into per-lane selects, the test would put
         // three vector-ALU instructions in front of EVERY tile's DMAs)
         asm volatile("; zero-padded tile" ::: "memory");
 #pragma unroll
         for (int p = 0; p < NP; ++p)
 #pragma unroll
-          for (int i = 0; i < NA; ++i) dma_a(ra[p], dst_a(p, i), kpos + ca[i] >= seg_len ? kBufRange : cva[i], soa + cda[p]);
+          for (int i = 0; i < NA; ++i) {
+            bool in = kpos + ca[i] < seg_len;
+            if constexpr (LoaderA::kRange) in = in && kpos + ca[i] >= aklo[i] && kpos + ca[i] < akhi[i];
+            dma_a(ra[p], dst_a(p, i), in ? cva[i] : kBufRange, soa + cda[p]);
+          }
 #pragma unroll
         for (int p = 0; p < NP; ++p)
 #pragma unroll
