@@ -258,8 +258,14 @@ size_t ttsdec_workspace_bytes(const ttsdec_handle* h, int B, int L);
  *   T_out         device int32[2]: [0] = total number of steps produced so far
  *                 (= stop step + 1 if the rule fired, else t_begin+n_steps),
  *                 [1] = bit 0: the stop rule has fired; bit 2: a two-role launch of the step gave up waiting
- *                 for its producer role (bounded spin, only possible on a stalled or over-subscribed GPU):
- *                 the outputs of the call are invalid; bit 1 (split-fp16 mode only): an activation
+ *                 for its producer role (bounded spin of ~1-4 ms, once per call: later gates of the same call
+ *                 return at once; only possible when the producer role's workgroups are not resident - a GPU
+ *                 shared with another process's kernels, a stalled queue): the outputs of the call are INVALID.
+ *                 What a direct caller of this ABI must do then (torch-tts_amd/decoder.py does exactly this):
+ *                 ttsdec_set_option(h, TTSDEC_OPT_OVERLAP, 0) and ttsdec_set_option(h, TTSDEC_OPT_HEAD_PROJ, 0) -
+ *                 one role per launch, no hand-off inside a launch - and decode the utterance batch again from
+ *                 t_begin = 0 (the recurrent state left in the workspace is not a state of the sequence any more);
+ *                 bit 1 (split-fp16 mode only): an activation
  *                 entering a 16-bit GEMM (input / teacher frame, PreNet output, context) had
  *                 |x| > 65504, the fp16 range - it was SATURATED, never inf/NaN, so outputs stay
  *                 finite but those rows are not fp32-accurate: rerun with TTSDEC_PREC_F32.

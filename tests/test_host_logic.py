@@ -407,3 +407,24 @@ def test_workspace_and_blob_layouts_over_many_shapes_host_only():
                     assert e.postnet_workspace_bytes(B, 600) > e.postnet_workspace_bytes(B, 1) > 0
             assert e.workspace_bytes(0, 5) == 0 and e.workspace_bytes(5, 0) == 0 and e.workspace_bytes(-1, -1) == 0
             assert e.postnet_workspace_bytes(0, 1) == 0
+
+
+def test_bench_byte_and_flop_model_follows_the_selected_config():
+    """bench.py's algorithmic bytes / FLOPs per decode step: the LJSpeech cell reproduces SURVEY.md 8(d)'s figures; the other
+    shipped configs get their own widths (d_ctx 256, PreNet hidden 128, r = 2, the Taco2 cell's query / projection inputs)."""
+    import importlib.util
+
+    spec = importlib.util.spec_from_file_location("bench_mod", os.path.join(ROOT, "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    lj = bench.cell_model(bench.LJSPEECH)
+    for B in (1, 64, 256):
+        assert bench.step_bytes(B, 120, lj)["step"] == 74_309_956 + B * 285_220  # SURVEY 8(d)
+    assert bench.step_flops(1, 120, lj) == 2 * (18_577_489 - 16_977) + 4 * 120 * 512  # 37.37 MFLOP per frame
+    sd = bench.cell_model(bench.SANDRA)
+    assert (sd["D"], sd["P0"], sd["r"], sd["Ha"], sd["Kq"], sd["Kproj"], sd["Nproj"]) == (256, 128, 2, 512, 1024, 1024, 162)
+    b = bench.step_bytes(256, 120, sd)
+    assert b["attention"] == 256 * (120 * 256 * 4 + 3 * 120 * 4 + 256 * 4)  # one pass over a 256-wide memory
+    assert b["query"] == 256 * 1024 * 4 and b["proj"] == (162 * 1024 + 162) * 4 + 256 * (2 * 80 * 4 + 2 * 4)
+    rd = bench.cell_model(bench.RDH)
+    assert rd["taco2"] and rd["P0"] == 128 and rd["D"] == 512 and rd["Kq"] == 2048
