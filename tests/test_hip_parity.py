@@ -659,8 +659,9 @@ def test_full_size_properties(H, prec):
 def test_shard_equivalence_bitwise(H):
     """Utterances never interact inside the step (decoder_cell.py:180-195 is row-wise), so
     decoding a batch in two shards must equal decoding it whole, bit for bit.
-    Whole batch and shards must lie in one regime of the launch schedule (the same GEMM tiling and K order): 65 .. 384
-    utterances (two launches per step: the query a job of the attention role), or more than 384 (both modes)."""
+    Whole batch and shards must lie in one regime of the launch schedule (the same GEMM tiling and K order; the table in
+    DESIGN.md section 6): split-fp16 65 .. 384 utterances (two launches per step: the query a job of the attention role) or more
+    than 384; exact fp32 more than 128."""
     dims = O.DecoderDims()
     wts = O.random_decoder_weights(dims, seed=1)
     for prec, B in (("split_f16", 256), ("split_f16", 1024), ("f32", 768)):
