@@ -19,6 +19,7 @@ ap.add_argument("--batch", type=int, default=64)
 ap.add_argument("--tx", type=int, default=120)
 ap.add_argument("--ty", type=int, default=600)
 ap.add_argument("--iters", type=int, default=10)
+ap.add_argument("--precision", default="split_f16", choices=["split_f16", "f32"])
 args = ap.parse_args()
 dev = torch.device("cuda:0")
 torch.manual_seed(0)
@@ -27,6 +28,7 @@ fl = T.vits2.ResidualCouplingTransformersBlock(192, 192, 5, 1, 4, use_transforme
 for l in fl.flows:
     if hasattr(l, "post"):
         torch.nn.init.normal_(l.post.weight, 0, 0.05)
+te.precision = fl.precision = args.precision
 B = args.batch
 ids = torch.randint(0, 178, (B, args.tx), device=dev)
 xl = torch.full((B,), args.tx, device=dev)
@@ -40,4 +42,4 @@ with torch.no_grad():
         for _ in range(args.iters):
             fn()
         torch.cuda.synchronize()
-        print(f"{name}: {(time.perf_counter() - t0) / args.iters * 1e3:.3f} ms  (B={B})")
+        print(f"{name}: {(time.perf_counter() - t0) / args.iters * 1e3:.3f} ms  (B={B}, {args.precision})")

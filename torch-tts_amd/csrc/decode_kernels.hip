@@ -179,7 +179,7 @@ __global__ __launch_bounds__(kGemmThreads, Cfg::kWavesPerSimd) void gemm_rows_ke
     const LoaderW<EB> lb{make_seg1(g.W, g.ldw, g.K), make_seg1(g.W_lo, g.ldw, g.K), n0, g.N};
     // (one K segment, both operands based at the workgroup's own first row: the buffer-descriptor loaders of gemm_tile.h apply
     // whatever the operand sizes)
-    gemm_tile<Cfg, LoaderConv<EB>, LoaderW<EB>, NoGate, true>(la, lb, smem, live);
+    gemm_tile<Cfg, LoaderConv<EB>, LoaderW<EB>, NoGate, 2>(la, lb, smem, live);
   } else {
     Seg3 s = g.a, s_lo = g.a_lo;
     if (g.teacher != nullptr && g.t > 0 && as_g(g.teacher_flags)[g.t - 1] != 0) {
@@ -202,7 +202,7 @@ __global__ __launch_bounds__(kGemmThreads, Cfg::kWavesPerSimd) void gemm_rows_ke
     const Seg3 wsl = make_seg3(wl, g.ldw, k0, wl + (size_t)k0 * EB, g.ldw, k1, wl + (size_t)(k0 + k1) * EB, g.ldw, k2);
     const LoaderW<EB> lb{ws, wsl, n0, g.N};
     const LoaderPlain<EB> la{s, s_lo, m0, g.M};
-    gemm_tile<Cfg>(la, lb, smem, live);
+    gemm_tile<Cfg, LoaderPlain<EB>, LoaderW<EB>, NoGate, 2>(la, lb, smem, live);
   }
   if (!live) return;
 

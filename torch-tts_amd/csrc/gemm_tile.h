@@ -166,6 +166,9 @@ struct NoGate {
 // its LDS slot (tools/ubench_buffer_lds_oob.hip; the scalar offset is part of the range check on gfx950, so a valid lane needs
 // offset + K advance < kBufRange: operands below 2 GiB - the callers that set kBufDma are the LSTM kernels).
 // Loaders used with kBufDma provide  seg_base(s, plane)  (uniform pointer) and  row_off(r, s)  (bytes from it).
+// kBufDma = 1: ONE descriptor per operand plane for all K segments (the LSTM kernels: segments of one allocation, their distances
+// ride in the scalar offset); kBufDma = 2: a descriptor per K segment, rebuilt where the segment is entered (the generic row /
+// conv GEMMs: segments may come from different allocations; based at the workgroup's own first row, so any operand size).
 constexpr unsigned kBufRange = 0x7FFFF000u;  // num_records of every descriptor = the offset that marks a lane out of range
 __device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const void* base) {
   // (the pointer is wave-uniform by construction - kernel arguments - but say so: a descriptor the compiler believes to be
@@ -175,7 +178,7 @@ __device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const void* base) {
   return __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<void*>(((unsigned long long)hi << 32) | lo), 0, (int)kBufRange, 0x00020000);
 }
 
-template <class Cfg, class LoaderA, class LoaderB, class Gate = NoGate, bool kBufDma = false>
+template <class Cfg, class LoaderA, class LoaderB, class Gate = NoGate, int kBufDma = 0>
 __device__ __forceinline__ void gemm_tile(const LoaderA& la, const LoaderB& lb, float* smem, bool live = true,
                                           int dbg = 0, const Gate gate = Gate()) {
   // `live` (does this launch have anything to do?) typically comes from a control-block load
@@ -242,6 +245,7 @@ __device__ __forceinline__ void gemm_tile(const LoaderA& la, const LoaderB& lb, 
     // distance of plane p's segment sg from that plane's base: uniform, added to the SCALAR offset (the planes of an operand
     // need not be laid out alike, so it cannot ride in the per-lane offsets that the planes share)
     auto seg_delta = [&](const auto& ld_, int sg, int p) {
+      if constexpr (kBufDma == 2) return 0u;  // (a descriptor per segment: no distances)
       const char* b = static_cast<const char*>(ld_.seg_base(sg < nseg ? sg : 0, p));
       return (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(b - lowest(ld_, p)));
     };
@@ -300,7 +304,7 @@ __device__ __forceinline__ void gemm_tile(const LoaderA& la, const LoaderB& lb, 
         for (int i = 0; i < NA; ++i) {
           const int row = (wave * NA + i) * RPI + lane / C16;
           const int c16 = (lane % C16) ^ Cfg::swz(row);
-          if (va[sg][i] != kBufRange && (gbyte*)lowest(la, p) + dla[p][sg] + va[sg][i] != la.row_ptr(row, sg, p) + la.col_off(c16)) {
+          if (va[sg][i] != kBufRange && (gbyte*)(kBufDma == 2 ? la.seg_base(sg, p) : lowest(la, p)) + dla[p][sg] + va[sg][i] != la.row_ptr(row, sg, p) + la.col_off(c16)) {
             printf("DMA address mismatch A seg %d plane %d row %d c16 %d\n", sg, p, row, c16);
             va[sg][i] = kBufRange;
           }
@@ -309,7 +313,7 @@ __device__ __forceinline__ void gemm_tile(const LoaderA& la, const LoaderB& lb, 
         for (int i = 0; i < NB; ++i) {
           const int row = (wave * NB + i) * RPI + lane / C16;
           const int c16 = (lane % C16) ^ Cfg::swz(row);
-          if (vb[sg][i] != kBufRange && (gbyte*)lowest(lb, p) + dlb[p][sg] + vb[sg][i] != lb.row_ptr(row, sg, p) + lb.col_off(c16)) {
+          if (vb[sg][i] != kBufRange && (gbyte*)(kBufDma == 2 ? lb.seg_base(sg, p) : lowest(lb, p)) + dlb[p][sg] + vb[sg][i] != lb.row_ptr(row, sg, p) + lb.col_off(c16)) {
             printf("DMA address mismatch B seg %d plane %d row %d c16 %d\n", sg, p, row, c16);
             vb[sg][i] = kBufRange;
           }
@@ -322,12 +326,21 @@ __device__ __forceinline__ void gemm_tile(const LoaderA& la, const LoaderB& lb, 
     __amdgpu_buffer_rsrc_t ra[NP], rb[NP];
 #pragma unroll
     for (int p = 0; p < NP; ++p) {
-      ra[p] = make_rsrc(lowest(la, p));
-      rb[p] = make_rsrc(lowest(lb, p));
+      ra[p] = make_rsrc(kBufDma == 2 ? la.seg_base(0, p) : lowest(la, p));
+      rb[p] = make_rsrc(kBufDma == 2 ? lb.seg_base(0, p) : lowest(lb, p));
     }
     unsigned cva[NA], cvb[NB];
     unsigned cda[NP], cdb[NP];  // the current segment's distance from the base, per plane (uniform)
     auto enter_seg = [&](int sg) {  // uniform sg
+      if constexpr (kBufDma == 2) {
+        if (sg > 0) {
+#pragma unroll
+          for (int p = 0; p < NP; ++p) {
+            ra[p] = make_rsrc(la.seg_base(sg, p));
+            rb[p] = make_rsrc(lb.seg_base(sg, p));
+          }
+        }
+      }
 #pragma unroll
       for (int i = 0; i < NA; ++i) cva[i] = sg == 0 ? va[0][i] : (sg == 1 ? va[1][i] : va[2][i]);
 #pragma unroll

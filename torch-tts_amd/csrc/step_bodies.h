@@ -26,13 +26,16 @@ struct LoaderPlain {
   __device__ __forceinline__ long col_off(int c16) const { return seg_col_off(s, c16); }
   __device__ __forceinline__ long tile_inc(int rowb) const { return seg_tile_inc(s, rowb); }
   // buffer-descriptor form (gemm_tile kBufDma): the segment's base (uniform) and a row's byte offset from it
+  // (based at THIS workgroup's first row, so the per-lane offsets stay small whatever the operand's size)
   __device__ __forceinline__ const void* seg_base(int i, int plane) const {
     const Seg3& q = plane == 0 ? s : s_lo;
-    return i == 0 ? q.p0 : (i == 1 ? q.p1 : q.p2);
+    const int ld = i == 0 ? q.ld0 : (i == 1 ? q.ld1 : q.ld2);
+    const char* p = static_cast<const char*>(i == 0 ? q.p0 : (i == 1 ? q.p1 : q.p2));
+    return p + (s.mpad > 0 ? (long)m0 * kChunkBytes : (long)m0 * ld * EB);
   }
   __device__ __forceinline__ unsigned row_off(int r, int i) const {
     const int ld = i == 0 ? s.ld0 : (i == 1 ? s.ld1 : s.ld2);
-    return s.mpad > 0 ? (unsigned)(m0 + r) * kChunkBytes : (unsigned)(m0 + r) * (unsigned)ld * EB;
+    return s.mpad > 0 ? (unsigned)r * kChunkBytes : (unsigned)r * (unsigned)ld * EB;
   }
 };
 
@@ -207,7 +210,7 @@ __device__ __forceinline__ void lstm_body(LstmArgs g, float* smem, int bx, int b
       }
     }
   }
-  gemm_tile<Cfg, LoaderPlain<EB>, LoaderWLstm<BU, EB>, RoleGateT<kWhole>, true>(la, lb, smem, live, g.dbg, gate);
+  gemm_tile<Cfg, LoaderPlain<EB>, LoaderWLstm<BU, EB>, RoleGateT<kWhole>, 1>(la, lb, smem, live, g.dbg, gate);
   if (!live) return;
   if constexpr (!kEarlyEpi) load_epi();
 
