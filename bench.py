@@ -21,7 +21,8 @@ synchronize on both sides and the maximum over ranks:
   * "split_f16": the same workload in the library's opt-in split-fp16 mode (include/ttsdec.h TTSDEC_PREC_SPLIT_F16:
     two fp16 planes per operand, narrower than fp32 - a named sub-record, never the headline);
   * "b64_f32": BASELINE.json configs[1] (batch 64 per GPU, fp32);
-  * "vits2": BASELINE.json configs[4] (TextEncoder + reverse flow, --workload vits2's step on a short run).
+  * "vits2": BASELINE.json configs[4] (TextEncoder + reverse flow, --workload vits2's step on a short run) - in the
+    headline's arithmetic, with the other mode nested as ITS sub-record.
 The injected-mask parity of the timed configurations against the CPU oracle (all 600 frames when the CPU sample
 covers them), including the bf16 Postnet of configs[2], is reported under "parity".
 """
@@ -189,57 +190,81 @@ def bench_vits2(args, T, torch, dist, dev, world, rank, cpu_baseline=True):
     z = torch.randn(B, D["inter_channels"], Ty, generator=g).to(dev)
     ym = torch.ones(B, 1, Ty, device=dev)
 
-    def one_step():
-        with torch.no_grad():
-            a = te(ids, xl)
-            return a, fl(z, ym, reverse=True)
-
     def fence():
         torch.cuda.synchronize()
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
 
-    for _ in range(max(1, args.warmup)):
-        one_step()
-    fence()
-    ev = [torch.cuda.Event(enable_timing=True) for _ in range(3)]
-    te_ms = fl_ms = 0.0
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        with torch.no_grad():
-            ev[0].record(); te(ids, xl); ev[1].record(); out = fl(z, ym, reverse=True); ev[2].record()
-        ev[2].synchronize()
-        te_ms += ev[0].elapsed_time(ev[1]); fl_ms += ev[1].elapsed_time(ev[2])
-    fence()
-    elapsed = time.perf_counter() - t0
-    if world > 1:
-        tt = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        elapsed = float(tt.item())
-    assert bool(torch.isfinite(out).all())
     Bg = B * world
     f_te, f_fl = vits2_flops(Tx, Ty, D)
-    fl_s = fl_ms / args.steps * 1e-3
-    # every GEMM runs as 3 f16 MFMA products per fp32 product (split-fp16), so the matrix pipe that bounds the
-    # pass is the f16 one and one algorithmic FLOP costs three of its FLOPs
-    peak = F16_MFMA_PEAK_TFLOPS / 3.0
+
+    def timed(precision, steps, warmup):
+        """K timed passes in one arithmetic mode: exact fp32 (the reference's own) or the library's split-fp16."""
+        te.precision = fl.precision = precision
+
+        def one_step():
+            with torch.no_grad():
+                a = te(ids, xl)
+                return a, fl(z, ym, reverse=True)
+
+        for _ in range(max(1, warmup)):
+            one_step()
+        fence()
+        ev = [torch.cuda.Event(enable_timing=True) for _ in range(3)]
+        te_ms = fl_ms = 0.0
+        out = None
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            with torch.no_grad():
+                ev[0].record(); te(ids, xl); ev[1].record(); out = fl(z, ym, reverse=True); ev[2].record()
+            ev[2].synchronize()
+            te_ms += ev[0].elapsed_time(ev[1]); fl_ms += ev[1].elapsed_time(ev[2])
+        fence()
+        elapsed = time.perf_counter() - t0
+        if world > 1:
+            tt = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+            elapsed = float(tt.item())
+        assert bool(torch.isfinite(out).all())
+        fl_s = fl_ms / steps * 1e-3
+        if precision == "f32":
+            peak, note = 157.3, "fp32 matrix instruction (v_mfma_f32_32x32x2_f32), 157.3 TFLOP/s"
+            dtype = "f32 (exact fp32 matrix instruction for every GEMM and for the attention's QK^T / PV); elementwise math f32"
+        else:
+            # every GEMM runs as 3 f16 MFMA products per fp32 product (split-fp16), so the matrix pipe that bounds the
+            # pass is the f16 one and one algorithmic FLOP costs three of its FLOPs
+            peak, note = F16_MFMA_PEAK_TFLOPS / 3.0, "dense f16 MFMA peak (2500 TFLOP/s) / 3 products per fp32 product"
+            dtype = ("f32 via split-fp16 (hi+lo fp16 planes, 3 f16 MFMA products, fp32 accumulate) for every GEMM and the flow's attention; "
+                     "elementwise math f32")
+        return {
+            "value": round(Bg * Ty * steps / elapsed, 1), "unit": "mel-frames/s", "steps": steps, "warmup": warmup,
+            "ms_per_step": round(elapsed * 1e3 / steps, 3), "dtype": dtype,
+            "rtf": round((elapsed / steps) / (Ty * FRAME_SEC), 6),
+            "text_encoder_ms": round(te_ms / steps, 3), "flow_reverse_ms": round(fl_ms / steps, 3),
+            "roofline": {"bound": "mfma", "kernel": "flow_reverse (whole pass: GEMMs + attention)", "achieved": round(B * f_fl / fl_s / 1e12, 2),
+                         "peak": round(peak, 1), "unit": "TFLOP/s", "frac": round(B * f_fl / fl_s / 1e12 / peak, 4), "peak_note": note,
+                         "traffic": None, "alg_flops_per_utterance": {"text_encoder": f_te, "flow_reverse": f_fl}},
+        }
+
+    prec = getattr(args, "vits2_precision", None) or ("f32" if args.precision == "f32" else "split_f16")
+    head = timed(prec, args.steps, args.warmup)
     res = {
-        "metric": METRIC,
-        "value": round(Bg * Ty * args.steps / elapsed, 1), "unit": "mel-frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-        "ms_per_step": round(elapsed * 1e3 / args.steps, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-        "dtype": "f32 via split-fp16 (hi+lo fp16 planes, 3 f16 MFMA products, fp32 accumulate) for every GEMM; attention QK^T / PV and all "
-                 "elementwise math in f32",
+        "metric": METRIC, "value": head["value"], "unit": "mel-frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": head["ms_per_step"], "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": head["dtype"],
         "data": "synthetic",
         "config": {"workload": f"vits2 second hot path (BASELINE.json configs[4]): TextEncoder [B={B}/GPU, {Tx} tokens] + reverse flow "
-                               f"[B, 192, {Ty} frames], ModelConfig defaults", "global_batch": Bg, "parallelism": f"utterance-shard x{world}"},
-        "rtf": round((elapsed / args.steps) / (Ty * FRAME_SEC), 6),
-        "text_encoder_ms": round(te_ms / args.steps, 3), "flow_reverse_ms": round(fl_ms / args.steps, 3),
-        "roofline": {"bound": "mfma", "kernel": "flow_reverse (whole pass: GEMMs + attention)", "achieved": round(B * f_fl / fl_s / 1e12, 2),
-                     "peak": round(peak, 1), "unit": "TFLOP/s", "frac": round(B * f_fl / fl_s / 1e12 / peak, 4),
-                     "peak_note": "dense f16 MFMA peak (2500 TFLOP/s) / 3 products per fp32 product",
-                     "traffic": None, "alg_flops_per_utterance": {"text_encoder": f_te, "flow_reverse": f_fl}},
+                               f"[B, 192, {Ty} frames], ModelConfig defaults", "global_batch": Bg, "parallelism": f"utterance-shard x{world}",
+                   "precision": prec},
+        "rtf": head["rtf"], "text_encoder_ms": head["text_encoder_ms"], "flow_reverse_ms": head["flow_reverse_ms"], "roofline": head["roofline"],
     }
+    if not args.no_extra_legs:  # the other arithmetic mode as a named sub-record
+        other = "split_f16" if prec == "f32" else "f32"
+        leg = timed(other, args.steps, args.warmup)
+        res["split_f16" if other == "split_f16" else "f32_exact"] = dict(
+            leg, what=("the same pass in the library's opt-in split-fp16 mode (two fp16 planes per operand: narrower than fp32)" if other == "split_f16"
+                       else "the same pass on the reference's own arithmetic: exact fp32"))
+        te.precision = fl.precision = prec
     if rank == 0 and cpu_baseline and not args.no_cpu_baseline:
         from oracle import vits2_oracle as V
 
@@ -627,7 +652,7 @@ def main():
         va.steps, va.warmup = max(3, min(args.steps, 10)), max(1, min(args.warmup, 2))
         v = bench_vits2(va, T, torch, dist, dev, world, rank, cpu_baseline=False)
         out["vits2"] = {k: v[k] for k in ("value", "unit", "ms_per_step", "steps", "warmup", "dtype", "config", "rtf", "text_encoder_ms",
-                                           "flow_reverse_ms", "roofline")}
+                                           "flow_reverse_ms", "roofline") + tuple(k for k in ("split_f16", "f32_exact") if k in v)}
         out["vits2"]["what"] = "BASELINE.json configs[4]: VITS2 TextEncoder + reverse flow, `bench.py --workload vits2`'s step"
 
     if rank == 0 and lj and not args.no_cpu_baseline:  # (rank 0's shard and host cores, whatever the world size)
