@@ -10,10 +10,12 @@
 //     [frame || lstm_att] -> query -> [attention || lstm_dec] -> proj            (4 launches instead of 6)
 // Workgroups [0, n_a) of such a launch run role A (the producer), the rest the LSTM, which walks its K axis
 // with the dependent segment LAST and, right before the first tile of that segment, waits for role A's
-// arrival counter (common.h role_signal / role_wait: agent-scope release -> counter -> relaxed poll ->
-// acquire, Guideline 16).  Role A has the lowest block ids and waits for nothing, so it is resident or done
-// before any LSTM workgroup spins; the spin is bounded regardless.  Normally nobody waits: the early
-// segments take longer than role A.
+// arrival counter (common.h role_signal / role_poll: every handed-off byte stored write-through and drained, one lane's
+// agent-scope counter add; the consumer's sc1 poll, then sc1 loads - MI355X_MICROARCH.md "Hand-offs measured with sc1 loads
+// in place of the acquire", row 1).  Role A has the lowest block ids and waits for nothing, so under the
+// observed in-order dispatch it is resident or done before any LSTM workgroup spins; nothing DEPENDS on that order: the spin
+// is bounded (~1-4 ms, once per call), a timed-out call is flagged and repeated with one role per launch.  Normally nobody
+// waits long: the early segments take about as long as role A.
 // What makes it pay is co-residency: the LSTM runs on the "lean" GEMM tile (gemm_tile.h: 64-80 KiB of LDS,
 // <= 128 VGPRs), so a CU holds one workgroup of each role and the LSTM's tile stream fills the issue slots
 // and memory queues the small kernel leaves empty.
