@@ -58,10 +58,17 @@ def build(force: bool = False, verbose: bool = False) -> str:
     objs = [os.path.join(LIBDIR, src.replace(".hip", ".o")) for src in SOURCES]
 
     def compile_one(src, obj):
-        cmd = [hipcc, *FLAGS, "-c", os.path.join(CSRC, src), "-o", obj]
+        # (-Rpass-analysis: the compiler's per-kernel register / LDS / scratch report, kept beside the object - tests/ checks that
+        # no kernel of the library touches scratch memory: a spill inside a K loop once cost the split-fp16 step 45 %)
+        cmd = [hipcc, *FLAGS, "-Rpass-analysis=kernel-resource-usage", "-c", os.path.join(CSRC, src), "-o", obj]
         if verbose:
             print(" ".join(cmd), flush=True)
-        subprocess.run(cmd, check=True)
+        r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)
+        with open(obj[:-2] + ".resources.txt", "w") as f:
+            f.write("\n".join(l for l in r.stderr.splitlines() if "remark:" in l))
+        if r.returncode != 0:
+            sys.stderr.write(r.stderr)
+            raise subprocess.CalledProcessError(r.returncode, cmd)
 
     # the translation units are independent: one hipcc per source, side by side (each is itself single-threaded)
     from concurrent.futures import ThreadPoolExecutor

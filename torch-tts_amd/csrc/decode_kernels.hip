@@ -201,8 +201,8 @@ __global__ __launch_bounds__(kGemmThreads, Cfg::kWavesPerSimd) void gemm_rows_ke
     const Seg3 ws = make_seg3(w, g.ldw, k0, w + (size_t)k0 * EB, g.ldw, k1, w + (size_t)(k0 + k1) * EB, g.ldw, k2);
     const Seg3 wsl = make_seg3(wl, g.ldw, k0, wl + (size_t)k0 * EB, g.ldw, k1, wl + (size_t)(k0 + k1) * EB, g.ldw, k2);
     const LoaderW<EB> lb{ws, wsl, n0, g.N};
-    const LoaderPlain<EB> la{s, s_lo, m0, g.M};
-    gemm_tile<Cfg, LoaderPlain<EB>, LoaderW<EB>, NoGate, 2>(la, lb, smem, live);
+    const LoaderPlain<EB, true> la{s, s_lo, m0, g.M};
+    gemm_tile<Cfg, LoaderPlain<EB, true>, LoaderW<EB>, NoGate, 2>(la, lb, smem, live);
   }
   if (!live) return;
 

@@ -10,7 +10,11 @@ namespace ttsdec {
 
 // rows m0.. of an [M, K] activation made of up to three K segments; EB-byte elements,
 // plane 1 (fp16 lo) comes from a second Seg3 of identical shape
-template <int EB>
+// kWgBase: the buffer-descriptor form is based at THIS workgroup's first row (per-lane offsets stay small whatever the operand's
+// size: the generic row GEMMs); false: at the segment's own pointer, the row block's offset riding in the per-lane offsets (the
+// LSTM kernels: library-internal operands far below 2 GiB - and six 64-bit base computations fewer in kernels that sit at the
+// scalar-register limit; with them the split-fp16 two-role kernels spilled to scratch and the step went from 61.6 to 89.5 us).
+template <int EB, bool kWgBase = false>
 struct LoaderPlain {
   Seg3 s, s_lo;
   int m0, M;
@@ -26,16 +30,17 @@ struct LoaderPlain {
   __device__ __forceinline__ long col_off(int c16) const { return seg_col_off(s, c16); }
   __device__ __forceinline__ long tile_inc(int rowb) const { return seg_tile_inc(s, rowb); }
   // buffer-descriptor form (gemm_tile kBufDma): the segment's base (uniform) and a row's byte offset from it
-  // (based at THIS workgroup's first row, so the per-lane offsets stay small whatever the operand's size)
   __device__ __forceinline__ const void* seg_base(int i, int plane) const {
     const Seg3& q = plane == 0 ? s : s_lo;
-    const int ld = i == 0 ? q.ld0 : (i == 1 ? q.ld1 : q.ld2);
     const char* p = static_cast<const char*>(i == 0 ? q.p0 : (i == 1 ? q.p1 : q.p2));
+    if constexpr (!kWgBase) return p;
+    const int ld = i == 0 ? q.ld0 : (i == 1 ? q.ld1 : q.ld2);
     return p + (s.mpad > 0 ? (long)m0 * kChunkBytes : (long)m0 * ld * EB);
   }
   __device__ __forceinline__ unsigned row_off(int r, int i) const {
     const int ld = i == 0 ? s.ld0 : (i == 1 ? s.ld1 : s.ld2);
-    return s.mpad > 0 ? (unsigned)r * kChunkBytes : (unsigned)r * (unsigned)ld * EB;
+    const int row = kWgBase ? r : m0 + r;
+    return s.mpad > 0 ? (unsigned)row * kChunkBytes : (unsigned)row * (unsigned)ld * EB;
   }
 };
 
