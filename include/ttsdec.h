@@ -36,7 +36,8 @@ extern "C" {
 
 /* ABI version: bumped whenever an entry point's argument list or a struct layout changes.  2 (round 4): ttsenc_forward /
  * ttsvits_text_encoder / ttsvits_flow_reverse carry `g` and a status word, ttsvits_dims two more fields (round 3, unversioned
- * then).  The Python binding refuses a library whose ttsdec_version() differs from the version it was written for. */
+ * then); ttsenc_set_precision / ttsenc_get_precision added, and exact fp32 became the default arithmetic of the ttsenc_ / ttsvits_
+ * handles as it always was of the ttsdec_ ones (split-fp16 is opt-in everywhere).  The Python binding refuses a library whose ttsdec_version() differs from the version it was written for. */
 #define TTSDEC_VERSION 2
 
 enum {
@@ -369,6 +370,11 @@ size_t ttsenc_workspace_bytes(const ttsenc_handle* h, int B, int L);
  * reads the word with the results (no scan of the ids on the host, no synchronisation before the launch). */
 int ttsenc_forward(ttsenc_handle* h, const int64_t* ids, const int32_t* lengths, int B, int L, int L_out, float* memory,
                    void* workspace, size_t workspace_bytes, void* stream, int32_t* status);
+/* Arithmetic of the encoder's conv and input-projection GEMMs: TTSDEC_PREC_F32 (default: exact fp32, the reference's own) or
+ * TTSDEC_PREC_SPLIT_F16 (two fp16 planes per operand; needs d_emb % 8 == 0, else exact fp32 stays).  The recurrence is always
+ * exact fp32.  Both weight forms live in the packed blob: switchable per call. */
+int ttsenc_set_precision(ttsenc_handle* h, int precision);
+int ttsenc_get_precision(const ttsenc_handle* h);
 
 /* ---------------------------------------------------------------------------------------
  * VITS2 second hot path (BASELINE.json configs[4]):
@@ -419,9 +425,10 @@ typedef struct ttsvits_handle ttsvits_handle;
  * A NULL entry leaves that tensor zero (a module that owns only the text encoder or only the flow). */
 int ttsvits_create(const ttsvits_dims* dims, ttsvits_handle** out);
 int ttsvits_destroy(ttsvits_handle* h);
-/* Arithmetic of every GEMM of the two entry points below: TTSDEC_PREC_SPLIT_F16 (default: hi + lo fp16 planes, fp32 accumulate)
- * or TTSDEC_PREC_F32 (exact fp32 matrix instruction); both forms of the weights live in the packed blob, so this can be
- * switched at any time.  Attention and the elementwise math are fp32 in both modes. */
+/* Arithmetic of every GEMM of the two entry points below: TTSDEC_PREC_F32 (default: exact fp32 matrix instruction, the
+ * reference's own arithmetic) or TTSDEC_PREC_SPLIT_F16 (hi + lo fp16 planes, fp32 accumulate: opt-in, ~1.8x faster); both forms
+ * of the weights live in the packed blob, so this can be switched at any time.  The elementwise math is fp32 in both modes;
+ * the flow's attention runs on the f16 flash kernel in split mode and on exact-fp32 MFMAs otherwise. */
 int ttsvits_set_precision(ttsvits_handle* h, int precision);
 int ttsvits_get_precision(const ttsvits_handle* h);
 const char* ttsvits_last_hip_error(const ttsvits_handle* h);

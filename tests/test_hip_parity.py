@@ -695,15 +695,18 @@ def test_encoder2_golden_and_ljspeech_dims(H):
     missing, unexpected = enc.load_state_dict(wts, strict=False)
     assert not unexpected and all(k.endswith("num_batches_tracked") for k in missing)
     enc = enc.cuda().eval()
+    assert enc.precision == "f32"  # (the reference's arithmetic is the default; split-fp16 is opt-in: ttsenc_set_precision)
     with torch.no_grad():
-        for suf in ("", "2"):  # the reference's own vectors (ragged lengths; case 2: no utterance fills the padding)
-            ids, lens, mem = (torch.from_numpy(g[n + suf]) for n in ("ids", "lengths", "memory"))
-            out = enc(ids.cuda(), lens)
-            assert out.shape == mem.shape
-            H.assert_close(out.cpu(), mem, RTOL, ATOL, "memory" + suf)
-            for b, n in enumerate(lens.tolist()):
-                if n < out.shape[1]:
-                    assert float(out[b, n:].abs().max()) == 0.0, "padded rows must be exactly zero (rnn.py:126)"
+        for prec in ("f32", "split_f16"):
+            enc.precision = prec
+            for suf in ("", "2"):  # the reference's own vectors (ragged lengths; case 2: no utterance fills the padding)
+                ids, lens, mem = (torch.from_numpy(g[n + suf]) for n in ("ids", "lengths", "memory"))
+                out = enc(ids.cuda(), lens)
+                assert out.shape == mem.shape
+                H.assert_close(out.cpu(), mem, RTOL, ATOL, f"memory{suf} ({prec})")
+                for b, n in enumerate(lens.tolist()):
+                    if n < out.shape[1]:
+                        assert float(out[b, n:].abs().max()) == 0.0, "padded rows must be exactly zero (rnn.py:126)"
         # LJSpeech dims against the oracle, and against the stock PyTorch-ROCm ops of the same module
         wl = O.random_encoder2_weights(40, 512, 512, seed=3)
         encl = T.Encoder2(40, dim_out=512, dim_emb=512)
@@ -716,8 +719,10 @@ def test_encoder2_golden_and_ljspeech_dims(H):
         for b in range(B):
             ids[b, lens[b]:] = 0
         ref = O.encoder2(ids, lens, wl)
-        out = encl(ids.cuda(), lens)
-        H.assert_close(out.cpu(), ref, RTOL, ATOL, "memory (LJSpeech dims)")
+        for prec in ("split_f16", "f32"):
+            encl.precision = prec
+            out = encl(ids.cuda(), lens)
+            H.assert_close(out.cpu(), ref, RTOL, ATOL, f"memory (LJSpeech dims, {prec})")
         encl.use_hip = False
         stock = encl(ids.cuda(), lens)
         H.assert_close(out.cpu(), stock.cpu(), RTOL, ATOL, "HIP vs stock ops")

@@ -66,6 +66,8 @@ SYMBOLS = (
     "ttsenc_bind_weights",
     "ttsenc_workspace_bytes",
     "ttsenc_forward",
+    "ttsenc_set_precision",
+    "ttsenc_get_precision",
     "ttsvits_create",
     "ttsvits_destroy",
     "ttsvits_set_precision",
@@ -242,6 +244,10 @@ def load() -> C.CDLL:
         lib.ttsvits_create.argtypes = [C.POINTER(VitsDims), C.POINTER(vp)]
         lib.ttsvits_destroy.restype = i32
         lib.ttsvits_destroy.argtypes = [vp]
+        lib.ttsenc_set_precision.restype = i32
+        lib.ttsenc_set_precision.argtypes = [vp, i32]
+        lib.ttsenc_get_precision.restype = i32
+        lib.ttsenc_get_precision.argtypes = [vp]
         lib.ttsvits_set_precision.restype = i32
         lib.ttsvits_set_precision.argtypes = [vp, i32]
         lib.ttsvits_get_precision.restype = i32

@@ -4,7 +4,7 @@
 //   embedding gather -> 3 x implicit-GEMM conv (k=5) + BN + ISRLU -> cat[conv, emb]
 //   -> one GEMM for the input projections of both LSTM directions over all time steps
 //   -> L sequential steps of the LSTM kernel in packed-sequence mode (forward and reverse).
-// Convs and the input projection: split-fp16 GEMMs (fp32-class accuracy); the recurrence: exact fp32.
+// Convs and the input projection: exact fp32 GEMMs (default) or split-fp16 ones (ttsenc_set_precision); the recurrence: exact fp32.
 #include <string.h>
 
 #include <new>
@@ -31,6 +31,7 @@ struct ttsenc_handle {
   EncBlob bl;
   const float* blob;
   int device;  // HIP device current at create (-1: none); must be current for every later call
+  int precision;  // TTSDEC_PREC_F32 (default: the reference's arithmetic) or TTSDEC_PREC_SPLIT_F16 for the convs and the input projection
   std::string hip_err;
 };
 
@@ -93,6 +94,7 @@ int ttsenc_create(const ttsenc_dims* dims, ttsenc_handle** out) {
   h->bl = make_layout(d);
   h->blob = nullptr;
   h->device = current_device_or_minus1();
+  h->precision = TTSDEC_PREC_F32;
   *out = h;
   return TTSDEC_OK;
 }
@@ -103,6 +105,12 @@ int ttsenc_destroy(ttsenc_handle* h) {
 }
 
 const char* ttsenc_last_hip_error(const ttsenc_handle* h) { return h ? h->hip_err.c_str() : ""; }
+int ttsenc_set_precision(ttsenc_handle* h, int precision) {
+  if (!h || (precision != TTSDEC_PREC_F32 && precision != TTSDEC_PREC_SPLIT_F16)) return TTSDEC_ERR_INVALID_ARG;
+  h->precision = precision;
+  return TTSDEC_OK;
+}
+int ttsenc_get_precision(const ttsenc_handle* h) { return h ? h->precision : TTSDEC_ERR_INVALID_ARG; }
 int ttsenc_num_weight_tensors(const ttsenc_handle* h) { return h ? TTSENC_W_COUNT : TTSDEC_ERR_INVALID_ARG; }
 size_t ttsenc_packed_bytes(const ttsenc_handle* h) { return h ? h->bl.total * sizeof(float) : 0; }
 size_t ttsenc_workspace_bytes(const ttsenc_handle* h, int B, int L) {
@@ -179,9 +187,9 @@ int ttsenc_forward(ttsenc_handle* h, const int64_t* ids, const int32_t* lengths,
   // encoder.py:69: embedding (row 0 of the table is the zero padding vector); also the right half of the cat
   launch_embed(reinterpret_cast<const long long*>(ids), blob + bl.emb, d.alphabet_size, M, E, x, E, cat + E, 2 * E, status, st);
   // encoder.py:70: three conv blocks over the padded sequence; the last writes the left half of the cat
-  // The convs and the input projection run in the GEMM core's split-fp16 mode (fp32-class accuracy,
-  // gemm_tile.h): one elementwise pass makes the hi / lo planes of each A operand.
-  const bool split = !(E & 7);
+  // In split-fp16 mode the convs and the input projection run on two fp16 planes per operand (gemm_tile.h): one elementwise
+  // pass makes the hi / lo planes of each A operand.
+  const bool split = h->precision == TTSDEC_PREC_SPLIT_F16 && !(E & 7);  // (ttsenc_set_precision; exact fp32 MFMAs otherwise)
   f16* ph = reinterpret_cast<f16*>(ws + W.planes);
   const float* in = x;
   for (int i = 0; i < 3; ++i) {

@@ -52,7 +52,7 @@ struct ttsvits_handle {
   VitsBlob bl;
   const float* blob;
   int device;  // HIP device current at create (-1: none); must be current for every later call
-  int precision;  // TTSDEC_PREC_SPLIT_F16 (default) or TTSDEC_PREC_F32: arithmetic of every GEMM (ttsvits_set_precision)
+  int precision;  // TTSDEC_PREC_F32 (default) or TTSDEC_PREC_SPLIT_F16: arithmetic of every GEMM (ttsvits_set_precision)
   std::string hip_err;
 };
 
@@ -1322,7 +1322,7 @@ int ttsvits_create(const ttsvits_dims* dims, ttsvits_handle** out) {
   h->bl = make_layout(*dims);
   h->blob = nullptr;
   h->device = current_device_or_minus1();
-  h->precision = TTSDEC_PREC_SPLIT_F16;
+  h->precision = TTSDEC_PREC_F32;  // (the reference's arithmetic; ttsvits_set_precision opts into split-fp16)
   *out = h;
   return TTSDEC_OK;
 }

@@ -85,6 +85,10 @@ class EncoderEngine:
             raise _lib.TtsdecError(rc, "ttsenc_pack_weights", self._lib.ttsenc_last_hip_error(self._h).decode())
         self.blob, self._fingerprint = blob, fp
 
+    def set_precision(self, mode: str) -> None:
+        """"f32" (exact, default) or "split_f16": arithmetic of the conv / input-projection GEMMs (include/ttsdec.h ttsenc_set_precision)."""
+        _lib.check(self._lib.ttsenc_set_precision(self._h, {"f32": _lib.PREC_F32, "split_f16": _lib.PREC_SPLIT_F16}[mode]), "ttsenc_set_precision")
+
     def check_ids(self) -> None:
         """Raises IndexError if the last forward met a token id outside the table (nn.Embedding does, encoder.py:69).  Reads the
         device status word: ONE host sync, placed by the caller - Encoder2.forward right behind its launches, Tacotron.forward
@@ -146,6 +150,7 @@ class Encoder2(PackedWeightsMixin, nn.Module):
         self.rnn_h0 = nn.Parameter(torch.zeros(1, 1, dim_out))
         self.rnn_c0 = nn.Parameter(torch.zeros(1, 1, dim_out))
         self.use_hip = True  # eval-mode forwards on a ROCm device go through libttsdec
+        self.precision = "f32"  # convs / input projection: "f32" (exact, the reference's own: default) or "split_f16" (opt-in)
         # nn.Embedding raises IndexError on an id outside the table; the HIP path finds out from a device status word.  False:
         # forward reads it before returning (one host sync); True: the caller reads it later through check_ids()
         # (Tacotron.forward does, at the decoder's own sync)
@@ -186,6 +191,7 @@ class Encoder2(PackedWeightsMixin, nn.Module):
             eng = EncoderEngine(self.emb.num_embeddings, self.dim_emb, self.dim_out, float(self.conv[1].eps), torch.device("cuda", idx))
             self._engines.by_dev[idx] = eng
         eng.ensure_packed(self.weight_tensors())
+        eng.set_precision(self.precision)
         memory = eng.forward(x, x_lengths)
         if not self.defer_id_check:
             eng.check_ids()  # (one sync, behind the queued launches; Tacotron.forward defers it to the decoder's sync)

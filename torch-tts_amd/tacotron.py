@@ -45,18 +45,21 @@ class Tacotron(PackedWeightsMixin, nn.Module):
             the default `dropout_source = "reference_rng"` draws ~80 MB of masks on the host and uploads them per 256 x 600
             batch, which exists for bit-compatibility with the reference's RNG stream, not for speed;
           * split-fp16 arithmetic (fp32-class accuracy: 22 significand bits per operand, fp32 accumulate) for the decoder's
-            and the Postnet's GEMMs instead of exact fp32 matrix instructions (about half the step time at 256 utterances).
+            the Postnet's and the text encoder's GEMMs instead of exact fp32 matrix instructions (about 0.6 of the step time at
+            256 utterances).
         Returns self; `reference_compatible()` switches back."""
         self.decoder.dropout_source, self.decoder.dropout_seed, self.decoder.precision = "philox", int(seed), "split_f16"
-        if self.postnet is not None and hasattr(self.postnet, "precision"):
-            self.postnet.precision = "split_f16"
+        for m in (self.postnet, self.encoder):
+            if m is not None and hasattr(m, "precision"):
+                m.precision = "split_f16"
         return self
 
     def reference_compatible(self):
         """The defaults: the reference's RNG stream for the always-on PreNet dropout, exact fp32 arithmetic."""
         self.decoder.dropout_source, self.decoder.precision = "reference_rng", "f32"
-        if self.postnet is not None and hasattr(self.postnet, "precision"):
-            self.postnet.precision = "f32"
+        for m in (self.postnet, self.encoder):
+            if m is not None and hasattr(m, "precision"):
+                m.precision = "f32"
         return self
 
     def forward(self, cond, cond_lengths, x=None, x_lengths=None, xref=None, xref_lengths=None, max_steps: int = 0):
