@@ -461,3 +461,37 @@ def test_no_kernel_of_the_library_uses_scratch_memory():
                 bad += 1
                 print("spill:", os.path.basename(fn), name, m.group(1))
     assert kernels > 100 and bad == 0, (kernels, bad)
+
+
+def test_exact_fp32_is_every_handles_default_arithmetic():
+    """The reference computes in fp32: every handle of the C ABI and every drop-in module starts in exact fp32 and split-fp16 is
+    an explicit opt-in (ttsdec_ / ttsenc_ / ttsvits_set_precision; Tacotron.fast_inference() sets all of a model's modules)."""
+    import ctypes as C
+    import json
+
+    lib = _lib.load()
+    h = C.c_void_p()
+    d = json.load(open(os.path.join(ROOT, "tests", "golden", "vits2_meta.json")))["dims"]
+    dims = _lib.VitsDims(*[int(d.get(n, 0)) for n, _ in _lib.VitsDims._fields_])
+    assert lib.ttsvits_create(C.byref(dims), C.byref(h)) == _lib.OK
+    assert lib.ttsvits_get_precision(h) == _lib.PREC_F32
+    assert lib.ttsvits_set_precision(h, _lib.PREC_SPLIT_F16) == _lib.OK and lib.ttsvits_get_precision(h) == _lib.PREC_SPLIT_F16
+    assert lib.ttsvits_set_precision(h, 7) == _lib.ERR_INVALID_ARG
+    lib.ttsvits_destroy(h)
+    e = C.c_void_p()
+    assert lib.ttsenc_create(C.byref(_lib.EncDims(40, 64, 64, 5, 1e-5)), C.byref(e)) == _lib.OK
+    assert lib.ttsenc_get_precision(e) == _lib.PREC_F32
+    assert lib.ttsenc_set_precision(e, _lib.PREC_SPLIT_F16) == _lib.OK and lib.ttsenc_get_precision(e) == _lib.PREC_SPLIT_F16
+    assert lib.ttsenc_set_precision(e, -1) == _lib.ERR_INVALID_ARG and lib.ttsenc_set_precision(None, 0) == _lib.ERR_INVALID_ARG
+    lib.ttsenc_destroy(e)
+    model = T.build_tacotron({"text": {"alphabet": "abc"}, "audio": {"num_mels": 80}, "model": {
+        "encoder": {"type": "tacotron2", "dim_emb": 64, "dim_out": 64}, "decoder": {"type": "tacotron2prod", "r": 1, "dim_pre": 128, "dim_att": 128, "dim_rnn": [128, 128]},
+        "postnet": {"type": "tacotron2", "dim_hidden": 64, "num_layers": 3}}})
+    assert (model.decoder.precision, model.postnet.precision, model.encoder.precision) == ("f32", "f32", "f32")
+    model.fast_inference(3)
+    assert (model.decoder.precision, model.postnet.precision, model.encoder.precision) == ("split_f16",) * 3
+    model.reference_compatible()
+    assert (model.decoder.precision, model.postnet.precision, model.encoder.precision) == ("f32", "f32", "f32")
+    te = T.vits2.TextEncoder(20, 16, 16, 32, 2, 1, 3, 0.1)
+    fl = T.vits2.ResidualCouplingTransformersBlock(16, 16, 5, 1, 2, use_transformer_flows=True)
+    assert te.precision == "f32" and fl.precision == "f32"
