@@ -1,7 +1,8 @@
 #!/bin/bash
-# build_variant.sh <name> <extra flags...>: torch-tts_amd/lib/libttsdec_<name>.so
+# build_variant.sh <name> <extra flags...>: torch-tts_amd/lib/libttsdec_<name>.so - another build of the same library (e.g. with a
+# -DTTSDEC_EXPERIMENT_* switch) for same-box A/B runs through TTSDEC_LIB=...; objects under /tmp, nothing of it is shipped.
 set -e
-cd /root/repo
+cd "$(dirname "$0")/.."
 N=$1; shift
 F="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off -fno-fast-math $*"
 mkdir -p /tmp/ttsdec_$N
