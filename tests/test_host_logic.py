@@ -495,3 +495,26 @@ def test_exact_fp32_is_every_handles_default_arithmetic():
     te = T.vits2.TextEncoder(20, 16, 16, 32, 2, 1, 3, 0.1)
     fl = T.vits2.ResidualCouplingTransformersBlock(16, 16, 5, 1, 2, use_transformer_flows=True)
     assert te.precision == "f32" and fl.precision == "f32"
+
+
+def test_committed_traffic_captures_belong_to_these_kernel_sources():
+    """bench.py prints roofline.traffic only from a PMC capture whose digest of the kernel sources equals the running sources'
+    (profiles/r04_traffic_*.json, tools/summarize_pmc.py): a kernel edit without a new capture would silently turn the field
+    into null on the driver's line.  This keeps the two together."""
+    import importlib.util
+    import json
+
+    spec = importlib.util.spec_from_file_location("bench_mod2", os.path.join(ROOT, "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    dig = bench.sources_digest()
+    files = sorted(f for f in os.listdir(os.path.join(ROOT, "profiles")) if f.startswith("r04_traffic") and f.endswith(".json"))
+    assert len(files) >= 3, files
+    seen = set()
+    for fn in files:
+        tj = json.load(open(os.path.join(ROOT, "profiles", fn)))
+        assert tj["sources_digest"] == dig, (fn, tj["sources_digest"], dig)
+        seen.add((tj["precision"], tj["batch"]))
+        for name, v in tj["per_launch"].items():
+            assert v["hbm_bytes"] > 0, (fn, name)
+    assert {("f32", 256), ("f32", 64), ("split_f16", 256)} <= seen, seen
