@@ -123,6 +123,14 @@ def step_flops(B, L, m):
 
 
 F16_MFMA_PEAK_TFLOPS = 2500.0  # MI355X_MICROARCH.md: dense bf16/f16 matrix peak
+F32_MFMA_PEAK_TFLOPS = 157.3   # v_mfma_f32_32x32x2_f32: 256 CUs x 4 SIMDs x 64 FLOP/clk x 2.4 GHz
+
+
+def postnet_flops_per_frame(cfg):
+    """MelPostnet (tacotron/modules/modules.py: num_layers x [Conv1d(k=5) -> BN -> isru] -> Linear + residual): 2 per weight."""
+    pn, M = cfg["model"]["postnet"], cfg["audio"].get("num_mels", 80)
+    H, n, k = pn["dim_hidden"], pn["num_layers"], 5
+    return 2 * (k * M * H + (n - 1) * k * H * H + H * M)
 
 
 def sources_digest():
@@ -391,6 +399,32 @@ class Workload:
             "lstm_precision": self.eng.precision(), "postnet_precision": postnet, "batch_per_gpu": B, "global_batch": Bg,
         }
 
+    def time_postnet_modes(self, B, steps):
+        """MelPostnet alone on y [B, frames, 80] in exact fp32 / split-fp16 / bf16: ms per pass and the fraction of the matrix
+        peak of the instruction each mode runs on (algorithmic FLOPs: postnet_flops_per_frame)."""
+        torch, _lib = self.torch, self._lib
+        io = self.inputs(B)
+        flop = postnet_flops_per_frame(self.cfg) * B * self.args.frames
+        peaks = {"f32": F32_MFMA_PEAK_TFLOPS, "split_f16": F16_MFMA_PEAK_TFLOPS / 3.0, "bf16": F16_MFMA_PEAK_TFLOPS}
+        modes = {"f32": _lib.POSTNET_F32, "split_f16": _lib.POSTNET_SPLIT_F16, "bf16": _lib.POSTNET_BF16}
+        rec = {"what": "MelPostnet alone, ms per pass over this rank's [B, frames, 80]; frac = algorithmic TFLOP/s over the dense matrix peak "
+                       "of the mode's instruction (split-fp16: three f16 products per term)",
+               "batch_per_gpu": B, "frames": self.args.frames, "alg_tflop_per_pass": round(flop / 1e12, 4)}
+        ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        for name, pm in modes.items():
+            self.peng.postnet(io["y"], pm)
+            torch.cuda.synchronize()
+            ev0.record()
+            for _ in range(steps):
+                yp = self.peng.postnet(io["y"], pm)
+            ev1.record()
+            ev1.synchronize()
+            ms = ev0.elapsed_time(ev1) / steps
+            tf = flop / (ms * 1e-3) / 1e12
+            rec[name] = {"ms": round(ms, 4), "tflop_per_s": round(tf, 1), "peak_tflop_per_s": round(peaks[name], 1), "frac": round(tf / peaks[name], 4),
+                         "finite": bool(torch.isfinite(yp).all())}
+        return rec
+
     def roofline(self, B, precision, decode_step_ms):
         """Roofline record of the decode STEP (north_star's quantity) and of every launch in it, from in-loop times.
 
@@ -654,6 +688,11 @@ def main():
         out["vits2"] = {k: v[k] for k in ("value", "unit", "ms_per_step", "steps", "warmup", "dtype", "config", "rtf", "text_encoder_ms",
                                            "flow_reverse_ms", "roofline") + tuple(k for k in ("split_f16", "f32_exact") if k in v)}
         out["vits2"]["what"] = "BASELINE.json configs[4]: VITS2 TextEncoder + reverse flow, `bench.py --workload vits2`'s step"
+
+    if lj and not args.no_extra_legs:
+        # BASELINE.json configs[2] names the Postnet's bf16 MFMA mode: the Postnet alone in each of its arithmetic modes on the
+        # driver's clock (every rank runs it - the timing is rank-local, device events around `steps` passes over this rank's y)
+        out["postnet_modes"] = wk.time_postnet_modes(B, max(3, min(args.steps, 10)))
 
     if rank == 0 and lj and not args.no_cpu_baseline:  # (rank 0's shard and host cores, whatever the world size)
         pairs = [(args.precision, args.postnet)]

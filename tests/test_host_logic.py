@@ -428,6 +428,8 @@ def test_bench_byte_and_flop_model_follows_the_selected_config():
     assert b["query"] == 256 * 1024 * 4 and b["proj"] == (162 * 1024 + 162) * 4 + 256 * (2 * 80 * 4 + 2 * 4)
     rd = bench.cell_model(bench.RDH)
     assert rd["taco2"] and rd["P0"] == 128 and rd["D"] == 512 and rd["Kq"] == 2048
+    # MelPostnet of the LJSpeech / rdh configs: 3 x conv(k = 5) 80 -> 512 -> 512 -> 512 and the 512 -> 80 Linear, 2 FLOP per weight and frame
+    assert bench.postnet_flops_per_frame(bench.CONFIGS["ljspeech"]) == 2 * (5 * 80 * 512 + 2 * 5 * 512 * 512 + 512 * 80)
 
 
 def test_no_kernel_of_the_library_uses_scratch_memory():
