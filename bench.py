@@ -135,11 +135,11 @@ def postnet_flops_per_frame(cfg):
 
 def sources_digest():
     """sha256 over the decoder's kernel sources: ties a PMC capture of the decode step (profiles/*traffic.json) to the code it was
-    taken on.  (encoder.hip and vits2.hip hold no kernel of the step: editing them leaves the capture valid.)"""
+    taken on.  (encoder.hip, vits2.hip and conv256.hip hold no kernel of the step: editing them leaves the capture valid.)"""
     h = hashlib.sha256()
     for root in (os.path.join(ROOT, "torch-tts_amd", "csrc"), os.path.join(ROOT, "include")):
         for fn in sorted(os.listdir(root)):
-            if fn.endswith((".hip", ".h")) and fn not in ("encoder.hip", "vits2.hip"):
+            if fn.endswith((".hip", ".h")) and fn not in ("encoder.hip", "vits2.hip", "conv256.hip"):
                 with open(os.path.join(root, fn), "rb") as f:
                     h.update(fn.encode())
                     h.update(f.read())

@@ -6,7 +6,7 @@ cd "$(dirname "$0")/.."
 N=$1; shift
 F="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off -fno-fast-math $*"
 mkdir -p /tmp/ttsdec_$N
-for s in decode_kernels frame_kernel fused_kernels api encoder vits2; do
+for s in decode_kernels frame_kernel fused_kernels api encoder vits2 conv256; do
   hipcc $F -c torch-tts_amd/csrc/$s.hip -o /tmp/ttsdec_$N/$s.o 2>/dev/null &
 done
 wait

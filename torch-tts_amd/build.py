@@ -16,7 +16,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIBDIR = os.path.join(HERE, "lib")
 LIB = os.path.join(LIBDIR, "libttsdec.so")
-SOURCES = ["decode_kernels.hip", "frame_kernel.hip", "fused_kernels.hip", "api.hip", "encoder.hip", "vits2.hip"]
+SOURCES = ["decode_kernels.hip", "frame_kernel.hip", "fused_kernels.hip", "api.hip", "encoder.hip", "vits2.hip", "conv256.hip"]
 FLAGS = [
     "--offload-arch=gfx950",
     "-O3",

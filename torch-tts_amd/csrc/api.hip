@@ -1476,6 +1476,13 @@ int ttsdec_postnet(ttsdec_handle* h, const float* y, int B, int T, int precision
       g.out_kind = 2;
       g.out_h = reinterpret_cast<f16*>(o);
       in0 = in1 = o;
+      // the wide hidden -> hidden layers on the 256 x 256 schedule (conv256.hip: half the staged bytes per product) where the
+      // shape is that kernel's; TTSDEC_CONV256=0 keeps the shared tile (measurement)
+      static const bool use256 = [] { const char* e = getenv("TTSDEC_CONV256"); return !(e && e[0] == '0'); }();
+      if (use256 && launch_conv256_bf16(g.a.p0, g.W, g.alpha, g.beta, o, (int)M, T, cin, d.postnet_kernel, d.postnet_hidden, st)) {
+        cin = d.postnet_hidden;
+        continue;
+      }
     }
     launch_gemm(g, A_CONV, EPI_BN_ISRU, st);
     cin = d.postnet_hidden;

@@ -299,6 +299,10 @@ void launch_split_chunked(const float* src, f16* hi, f16* lo, int M, int K, int 
 // [H / 16][K / 32][gate * 16 + unit % 16][32]  (step_bodies.h LoaderWLstm); needs H % 16 == 0, K % 32 == 0
 void launch_pack_lstm_chunked(const float* src, f16* hi, f16* lo, int H, int K, hipStream_t st);
 void launch_to_bf16(const float* src, void* dst, size_t n, hipStream_t st);
+// conv256.hip: out[M, N] bf16 = isru(conv_k(x [M = B * T, Cin] bf16, w [N, taps * Cin] bf16) * alpha[n] + beta[n]) on 256 x 256 tiles;
+// false = not that kernel's shape (Cin % 64, N % 256, odd taps, 32-bit offsets): the caller keeps the shared GEMM
+bool launch_conv256_bf16(const void* x, const void* w, const float* alpha, const float* beta, void* out, int M, int T, int Cin, int taps, int N,
+                         hipStream_t st);
 // *out = max(*out, max |src[i]|)  (*out must hold a non-negative float, e.g. 0)
 void launch_absmax(const float* src, size_t n, float* out, hipStream_t st);
 // out_a[m, 0:E] (ld lda) and out_b[m, 0:E] (ld ldb) = table[ids[m], :]   (nn.Embedding lookup)
