@@ -8,8 +8,9 @@
 // wave a 128 x 64 block of the tile on v_mfma_f32_32x32x16_bf16 (4 x 2 accumulators = 128 VGPRs).  EVERY wave issues both
 // LDS-DMA and MFMAs: two waves per SIMD fill each other's gaps, a wave's DMA instructions sit between its MFMA groups, and the
 // fragment reads of a k16 step are issued one step ahead of its MFMAs.  Operand ring: five 32-KiB slots (160 KiB of LDS), a
-// slot = one operand's 256 rows x 64 k; the order A(s) B(s) A(s+1) B(s+1) A(s+2) keeps the activations two steps and the
-// (L2-resident) weights one step ahead, behind a counted s_waitcnt vmcnt and ONE raw s_barrier per step (gemm_tile.h on why
+// slot = one operand's 256 rows x 64 k; the order B(s) A(s) B(s+1) A(s+1) B(s+2) keeps the weights two steps and the
+// activations one step ahead (the weights are the lines EVERY workgroup asks its L2 for at the same moment: with the leads the
+// other way round the layer took 5 % longer), behind a counted s_waitcnt vmcnt and ONE raw s_barrier per step (gemm_tile.h on why
 // not __syncthreads()).
 //
 // Operands: x [M = B * T, Cin] bf16, channel-last, so the im2col row of frame m is the contiguous window of `taps` frames
@@ -97,9 +98,9 @@ __global__ __launch_bounds__(kThreads256, 2) void conv256_bf16_kernel(Conv256Arg
       a_off[i] = ok ? (unsigned)(a_m[i] + tap - pad) * (unsigned)g.Cin * 2u + a_cb[i] : kOob;
     }
   };
-  // the activation stream and the weight stream advance on their own (the ring holds A one step further ahead than B)
-  int la_step = 0, la_tap = 0, la_in_tap = 0, la_slot = 0;  // next A unit to request and the slot it goes to
-  int lb_step = 0, lb_slot = 1;
+  // the activation stream and the weight stream advance on their own (the ring holds B one step further ahead than A)
+  int la_step = 0, la_tap = 0, la_in_tap = 0, la_slot = 1;  // next A unit to request and the slot it goes to
+  int lb_step = 0, lb_slot = 0;
   set_tap(0);
   bool in_loop = false;
   auto issue_a = [&](int i) {  // (past the last step: zeros, so that the vmcnt arithmetic stays uniform)
@@ -148,8 +149,8 @@ __global__ __launch_bounds__(kThreads256, 2) void conv256_bf16_kernel(Conv256Arg
   // the 8 waves' LDS reads run beside the matrix pipe instead of in front of it.
   // A DMA instruction holds its wave's issue slot for ~100 cycles (gemm_tile.h: why the shared tile has loader waves); here every
   // wave is both, so its eight DMA instructions per step sit between its MFMA groups - each issues under the matrix pipe time of
-  // the four MFMAs in front of it, the SIMD's other wave fills what is left (sched_barrier pins the order).  The weights of the
-  // NEXT step go first (they are needed one step from now), then the activations of the step after it.
+  // the four MFMAs in front of it, the SIMD's other wave fills what is left (sched_barrier pins the order).  The activations of the
+  // NEXT step go first (they are needed one step from now), then the weights of the step after it.
   bf16x8 a0[4] = {}, b0[2] = {}, a1[4], b1[2];
 #pragma unroll
   for (int mt = 0; mt < 4; ++mt)
@@ -159,13 +160,13 @@ __global__ __launch_bounds__(kThreads256, 2) void conv256_bf16_kernel(Conv256Arg
   for (int nt = 0; nt < 2; ++nt)
 #pragma unroll
     for (int e = 0; e < 8; ++e) b1[nt][e] = (bf16)0.f;
-  // prologue: A(0), B(0), A(1)
-  for (int i = 0; i < 4; ++i) issue_a(i);
-  next_a();
+  // prologue: B(0), A(0), B(1)
   for (int i = 0; i < 4; ++i) issue_b(i);
   next_b();
   for (int i = 0; i < 4; ++i) issue_a(i);
   next_a();
+  for (int i = 0; i < 4; ++i) issue_b(i);
+  next_b();
 #define TTSDEC_MFMA4(A, B, mt0)                                                                                                      \
   _Pragma("unroll") for (int mt = mt0; mt < mt0 + 2; ++mt) _Pragma("unroll") for (int nt = 0; nt < 2; ++nt) {                          \
     if (ABL == 2 || ABL == 3) asm volatile("" ::"v"(A[mt]), "v"(B[nt]));                                                                        \
@@ -176,11 +177,11 @@ __global__ __launch_bounds__(kThreads256, 2) void conv256_bf16_kernel(Conv256Arg
   _Pragma("unroll") for (int nt = 0; nt < 2; ++nt) if (ABL != 3) B[nt] = *reinterpret_cast<const bf16x8*>(sb + (fb0 ^ ((ks) << 5)) + nt * 4096)
 #define TTSDEC_FENCE() __builtin_amdgcn_sched_barrier(0)
   in_loop = true;
-  int ra_slot = 0, rb_slot = 1;
+  int ra_slot = 1, rb_slot = 0;
   for (int kk = 0; kk < nk; ++kk) {
-    if (ABL != 1 && ABL != 4) wait_vm<4>();  // this wave's loads of A(kk), B(kk) have landed (A(kk + 1) may still be in flight)
+    if (ABL != 1 && ABL != 4) wait_vm<4>();  // this wave's loads of B(kk), A(kk) have landed (B(kk + 1) may still be in flight)
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // ... and its reads of step kk - 1's slots are done (issued 8 MFMAs ago)
-    __builtin_amdgcn_s_barrier();   // everybody's: B(kk + 1) and A(kk + 2) may go into those slots
+    __builtin_amdgcn_s_barrier();   // everybody's: A(kk + 1) and B(kk + 2) may go into those slots
     const char* sa = smem + ra_slot * kSlot;
     const char* sb = smem + rb_slot * kSlot;
     ra_slot += 2; if (ra_slot >= kSlots) ra_slot -= kSlots;
@@ -189,31 +190,31 @@ __global__ __launch_bounds__(kThreads256, 2) void conv256_bf16_kernel(Conv256Arg
     TTSDEC_FENCE();
     TTSDEC_MFMA4(a1, b1, 0);  // the previous step's last k16 (zeros at kk = 0)
     TTSDEC_FENCE();
-    issue_b(0); issue_b(1);
+    issue_a(0); issue_a(1);
     TTSDEC_FENCE();
     TTSDEC_MFMA4(a1, b1, 2);
     TTSDEC_FENCE();
-    issue_b(2); issue_b(3);
-    next_b();
+    issue_a(2); issue_a(3);
+    next_a();
     TTSDEC_READS(a1, b1, 1);
     TTSDEC_FENCE();
     TTSDEC_MFMA4(a0, b0, 0);
     TTSDEC_FENCE();
-    issue_a(0);
+    issue_b(0);
     TTSDEC_FENCE();
     TTSDEC_MFMA4(a0, b0, 2);
     TTSDEC_FENCE();
-    issue_a(1);
+    issue_b(1);
     TTSDEC_READS(a0, b0, 2);
     TTSDEC_FENCE();
     TTSDEC_MFMA4(a1, b1, 0);
     TTSDEC_FENCE();
-    issue_a(2);
+    issue_b(2);
     TTSDEC_FENCE();
     TTSDEC_MFMA4(a1, b1, 2);
     TTSDEC_FENCE();
-    issue_a(3);
-    next_a();
+    issue_b(3);
+    next_b();
     TTSDEC_READS(a1, b1, 3);
     TTSDEC_FENCE();
     TTSDEC_MFMA4(a0, b0, 0);
