@@ -1461,10 +1461,18 @@ int ttsdec_postnet(ttsdec_handle* h, const float* y, int B, int T, int precision
     g.alpha = h->blob + L.conv_alpha[i]; g.beta = h->blob + L.conv_beta[i];
     g.ldo = d.postnet_hidden;
     char* o = act[i & 1];
+    // the wide hidden -> hidden layers on the 256 x 256 schedule (conv256.hip) where the shape is that kernel's - exact fp32 and
+    // bf16; TTSDEC_CONV256=0 keeps the shared tile (measurement)
+    static const bool use256 = [] { const char* e = getenv("TTSDEC_CONV256"); return !(e && e[0] == '0'); }();
     if (prec == PREC_F32) {
       g.W = g.W_lo = h->blob + L.conv_w[i];
       g.out = reinterpret_cast<float*>(o);
       in0 = in1 = o;
+      if (use256 && launch_conv256_f32(static_cast<const float*>(g.a.p0), static_cast<const float*>(g.W), g.alpha, g.beta, g.out, (int)M, T, cin,
+                                       d.postnet_kernel, d.postnet_hidden, st)) {
+        cin = d.postnet_hidden;
+        continue;
+      }
     } else if (prec == PREC_F16S) {
       g.W = plane(L.conv_wh[i]); g.W_lo = plane(L.conv_wl[i]);
       g.out_kind = 1;
@@ -1476,9 +1484,6 @@ int ttsdec_postnet(ttsdec_handle* h, const float* y, int B, int T, int precision
       g.out_kind = 2;
       g.out_h = reinterpret_cast<f16*>(o);
       in0 = in1 = o;
-      // the wide hidden -> hidden layers on the 256 x 256 schedule (conv256.hip: half the staged bytes per product) where the
-      // shape is that kernel's; TTSDEC_CONV256=0 keeps the shared tile (measurement)
-      static const bool use256 = [] { const char* e = getenv("TTSDEC_CONV256"); return !(e && e[0] == '0'); }();
       if (use256 && launch_conv256_bf16(g.a.p0, g.W, g.alpha, g.beta, o, (int)M, T, cin, d.postnet_kernel, d.postnet_hidden, st)) {
         cin = d.postnet_hidden;
         continue;

@@ -1,4 +1,4 @@
-// conv256.hip - the Postnet's wide bf16 conv layers as a 256 x 256-tile GEMM (tacotron/modules/modules.py:170-184 MelPostnet:
+// conv256.hip - the Postnet's wide conv layers (bf16 and exact fp32) as a 256 x 256-tile GEMM (tacotron/modules/modules.py:170-184 MelPostnet:
 // Conv1d(k, pad=(k-1)/2, no bias) -> BatchNorm1d(eval) -> isru, the hidden -> hidden layers).
 //
 // Why a second GEMM schedule: the shared tile (gemm_tile.h, 128 x 128, loader waves + 4 MFMA waves, two workgroups per CU)
@@ -12,6 +12,10 @@
 // activations one step ahead (the weights are the lines EVERY workgroup asks its L2 for at the same moment: with the leads the
 // other way round the layer took 5 % longer), behind a counted s_waitcnt vmcnt and ONE raw s_barrier per step (gemm_tile.h on why
 // not __syncthreads()).
+//
+// The same tile, ring and schedule in exact fp32 (kF32: 32 fp32 of k per 128-byte row piece, v_mfma_f32_32x32x2_f32, fp32 output
+// stored straight from the accumulators) serves the fp32 Postnet: there the matrix pipe binds and the gain is the loop's (0.91 of
+// the instruction's rate against ~0.84 for the shared 64 x 64 tile).
 //
 // Operands: x [M = B * T, Cin] bf16, channel-last, so the im2col row of frame m is the contiguous window of `taps` frames
 // around it; a K step is 64 channels of one tap: tile row r reads frame m0 + r + tap - taps/2 of the SAME utterance or zeros
@@ -29,8 +33,8 @@ namespace ttsdec {
 namespace {
 
 constexpr int kT256 = 256;                     // tile rows = tile columns
-constexpr int kBK = 64;                        // k per step: 128-byte rows, i.e. whole cache lines per row piece
-constexpr int kSlot = kT256 * kBK * 2;         // one operand's bytes per step (32 KiB)
+constexpr int kRowB = 128;                     // bytes of a row piece per step: whole cache lines (64 bf16 or 32 fp32 of k)
+constexpr int kSlot = kT256 * kRowB;           // one operand's bytes per step (32 KiB)
 constexpr int kSlots = 5;                      // ring of operand slots: A(s), B(s), A(s + 1), B(s + 1), A(s + 2) = 160 KiB
 constexpr int kThreads256 = 512;
 constexpr unsigned kOob = 0x7FFFF000u;         // (gemm_tile.h kBufRange: an offset no buffer reaches -> the lane's 16 bytes are zeros)
@@ -38,11 +42,11 @@ constexpr unsigned kOob = 0x7FFFF000u;         // (gemm_tile.h kBufRange: an off
 typedef __attribute__((address_space(3))) void lds_void256;
 
 struct Conv256Args {
-  const bf16* x;
-  const bf16* w;
+  const void* x;
+  const void* w;
   const float* alpha;
   const float* beta;
-  bf16* out;
+  void* out;
   int M, T, Cin, taps, N;
   int n_row_tiles, n_col_tiles;
 };
@@ -53,8 +57,12 @@ __device__ __forceinline__ void wait_vm() {
 }
 
 // ABL (tools/ubench_conv256.hip only): 1 = no DMA inside the loop, 2 = no MFMAs, 3 = DMA only, 4 = DMA without the vmcnt waits
-template <int ABL>
-__global__ __launch_bounds__(kThreads256, 2) void conv256_bf16_kernel(Conv256Args g) {
+// kF32: exact fp32 operands on v_mfma_f32_32x32x2_f32 (32 k per step, fp32 output) instead of bf16 on v_mfma_f32_32x32x16_bf16
+// (64 k per step, bf16 output); same tile, ring and schedule
+template <int ABL, bool kF32>
+__global__ __launch_bounds__(kThreads256, 2) void conv256_kernel(Conv256Args g) {
+  constexpr int EB = kF32 ? 4 : 2;          // operand element bytes
+  constexpr int kBK = kRowB / EB;            // k per step
   __shared__ __attribute__((aligned(16))) char smem[kSlots * kSlot];
   // XCD-aware order: the column tiles of a row tile run back to back on one XCD (blockIdx % 8 labels the workgroups that share
   // an XCD under round-robin placement - speed only), so its L2 fetches the activation rows once
@@ -87,7 +95,7 @@ __global__ __launch_bounds__(kThreads256, 2) void conv256_bf16_kernel(Conv256Arg
     a_m[i] = m0 + row;
     a_t[i] = a_m[i] % g.T;
     a_cb[i] = (unsigned)c * 16u;
-    b_off[i] = (unsigned)(n0 + row) * (unsigned)K * 2u + (unsigned)c * 16u;
+    b_off[i] = (unsigned)(n0 + row) * (unsigned)K * (unsigned)EB + (unsigned)c * 16u;
   }
   unsigned a_off[4] = {kOob, kOob, kOob, kOob};
   auto set_tap = [&](int tap) {
@@ -95,7 +103,7 @@ __global__ __launch_bounds__(kThreads256, 2) void conv256_bf16_kernel(Conv256Arg
     for (int i = 0; i < 4; ++i) {
       const int tt = a_t[i] + tap - pad;
       const bool ok = a_m[i] < g.M && tt >= 0 && tt < g.T;
-      a_off[i] = ok ? (unsigned)(a_m[i] + tap - pad) * (unsigned)g.Cin * 2u + a_cb[i] : kOob;
+      a_off[i] = ok ? (unsigned)(a_m[i] + tap - pad) * (unsigned)g.Cin * (unsigned)EB + a_cb[i] : kOob;
     }
   };
   // the activation stream and the weight stream advance on their own (the ring holds B one step further ahead than A)
@@ -106,7 +114,7 @@ __global__ __launch_bounds__(kThreads256, 2) void conv256_bf16_kernel(Conv256Arg
   auto issue_a = [&](int i) {  // (past the last step: zeros, so that the vmcnt arithmetic stays uniform)
     if (ABL == 1 && in_loop) return;
     char* d = smem + la_slot * kSlot + (wave * 4 + i) * 1024;
-    __builtin_amdgcn_raw_ptr_buffer_load_lds(rx, (lds_void256*)d, 16, (int)(la_step < nk ? a_off[i] : kOob), la_in_tap * (kBK * 2), 0, 0);
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rx, (lds_void256*)d, 16, (int)(la_step < nk ? a_off[i] : kOob), la_in_tap * kRowB, 0, 0);
   };
   auto next_a = [&]() {
     ++la_step;
@@ -120,7 +128,7 @@ __global__ __launch_bounds__(kThreads256, 2) void conv256_bf16_kernel(Conv256Arg
   auto issue_b = [&](int i) {
     if (ABL == 1 && in_loop) return;
     char* d = smem + lb_slot * kSlot + (wave * 4 + i) * 1024;
-    __builtin_amdgcn_raw_ptr_buffer_load_lds(rw, (lds_void256*)d, 16, (int)(lb_step < nk ? b_off[i] : kOob), lb_step * (kBK * 2), 0, 0);
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rw, (lds_void256*)d, 16, (int)(lb_step < nk ? b_off[i] : kOob), lb_step * kRowB, 0, 0);
   };
   auto next_b = [&]() {
     ++lb_step;
@@ -151,15 +159,9 @@ __global__ __launch_bounds__(kThreads256, 2) void conv256_bf16_kernel(Conv256Arg
   // wave is both, so its eight DMA instructions per step sit between its MFMA groups - each issues under the matrix pipe time of
   // the four MFMAs in front of it, the SIMD's other wave fills what is left (sched_barrier pins the order).  The activations of the
   // NEXT step go first (they are needed one step from now), then the weights of the step after it.
-  bf16x8 a0[4] = {}, b0[2] = {}, a1[4], b1[2];
-#pragma unroll
-  for (int mt = 0; mt < 4; ++mt)
-#pragma unroll
-    for (int e = 0; e < 8; ++e) a1[mt][e] = (bf16)0.f;
-#pragma unroll
-  for (int nt = 0; nt < 2; ++nt)
-#pragma unroll
-    for (int e = 0; e < 8; ++e) b1[nt][e] = (bf16)0.f;
+  // (fp32: a fragment register set is 4 consecutive k per lane group, i.e. MFMA e of a read takes k pair (e, 4 + e) of its 8 - a
+  // permutation of k that both operands share)
+  f32x4 a0[4] = {}, b0[2] = {}, a1[4] = {}, b1[2] = {};
   // prologue: B(0), A(0), B(1)
   for (int i = 0; i < 4; ++i) issue_b(i);
   next_b();
@@ -170,11 +172,15 @@ __global__ __launch_bounds__(kThreads256, 2) void conv256_bf16_kernel(Conv256Arg
 #define TTSDEC_MFMA4(A, B, mt0)                                                                                                      \
   _Pragma("unroll") for (int mt = mt0; mt < mt0 + 2; ++mt) _Pragma("unroll") for (int nt = 0; nt < 2; ++nt) {                          \
     if (ABL == 2 || ABL == 3) asm volatile("" ::"v"(A[mt]), "v"(B[nt]));                                                                        \
-    else acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A[mt], B[nt], acc[mt][nt], 0, 0, 0);                                  \
+    else if constexpr (kF32) {                                                                                                        \
+      _Pragma("unroll") for (int e = 0; e < 4; ++e) acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(A[mt][e], B[nt][e], acc[mt][nt], 0, 0, 0); \
+    } else {                                                                                                                          \
+      acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, A[mt]), __builtin_bit_cast(bf16x8, B[nt]), acc[mt][nt], 0, 0, 0); \
+    }                                                                                                                                 \
   }
 #define TTSDEC_READS(A, B, ks)                                                                                                       \
-  _Pragma("unroll") for (int mt = 0; mt < 4; ++mt) if (ABL != 3) A[mt] = *reinterpret_cast<const bf16x8*>(sa + (fa0 ^ ((ks) << 5)) + mt * 4096); \
-  _Pragma("unroll") for (int nt = 0; nt < 2; ++nt) if (ABL != 3) B[nt] = *reinterpret_cast<const bf16x8*>(sb + (fb0 ^ ((ks) << 5)) + nt * 4096)
+  _Pragma("unroll") for (int mt = 0; mt < 4; ++mt) if (ABL != 3) A[mt] = *reinterpret_cast<const f32x4*>(sa + (fa0 ^ ((ks) << 5)) + mt * 4096); \
+  _Pragma("unroll") for (int nt = 0; nt < 2; ++nt) if (ABL != 3) B[nt] = *reinterpret_cast<const f32x4*>(sb + (fb0 ^ ((ks) << 5)) + nt * 4096)
 #define TTSDEC_FENCE() __builtin_amdgcn_sched_barrier(0)
   in_loop = true;
   int ra_slot = 1, rb_slot = 0;
@@ -226,6 +232,21 @@ __global__ __launch_bounds__(kThreads256, 2) void conv256_bf16_kernel(Conv256Arg
   wait_vm<0>();                  // the trailing zero loads
   __builtin_amdgcn_s_barrier();  // nobody reads a stage any more: the ring becomes the output staging area
 
+  if constexpr (kF32) {
+    // ---- epilogue, fp32: BN (folded) + isru, stored straight from the accumulators (a store instruction = two rows x 128 bytes) ----
+    float* out = static_cast<float*>(g.out);
+#pragma unroll
+    for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+      for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+          const int m = m0 + wr * 128 + mt * 32 + (e & 3) + 8 * (e >> 2) + 4 * (lane >> 5);
+          const int n = n0 + wc * 64 + nt * 32 + (lane & 31);
+          const float v = isru_fast(add_rn(mul_rn(acc[mt][nt][e], al[nt]), be[nt]));  // (as decode_kernels.hip EPI_BN_ISRU)
+          if (m < g.M) out[(size_t)m * g.N + n] = v;
+        }
+  } else {
   // ---- epilogue: BN (folded) + isru, to bf16, through this wave's 16 KiB of LDS so that the stores are whole 16-byte pieces ----
   char* ow = smem + wave * 16384;  // [128 rows][64 columns] bf16
 #pragma unroll
@@ -249,6 +270,7 @@ __global__ __launch_bounds__(kThreads256, 2) void conv256_bf16_kernel(Conv256Arg
     const u32x4 v = *reinterpret_cast<const u32x4*>(ow + row * 128 + cc * 16);
     if (m < g.M) *reinterpret_cast<u32x4*>(reinterpret_cast<char*>(g.out) + ((size_t)m * g.N + n0 + wc * 64) * 2 + cc * 16) = v;
   }
+  }
 }
 
 #undef TTSDEC_MFMA4
@@ -258,22 +280,27 @@ __global__ __launch_bounds__(kThreads256, 2) void conv256_bf16_kernel(Conv256Arg
 }  // namespace
 
 // false: the shape is not this kernel's (the caller keeps the shared GEMM)
-template <int ABL>
+template <int ABL, bool kF32>
 static bool launch_conv256_abl(const void* x, const void* w, const float* alpha, const float* beta, void* out, int M, int T, int Cin, int taps, int N,
                                hipStream_t st) {
-  if (M <= 0 || T <= 0 || (Cin % kBK) || (N % kT256) || !(taps & 1) || taps > 15) return false;
-  if ((size_t)M * Cin * 2 >= kOob || (size_t)N * taps * Cin * 2 >= kOob) return false;  // 32-bit buffer offsets
+  constexpr int EB = kF32 ? 4 : 2;
+  if (M <= 0 || T <= 0 || ((Cin * EB) % kRowB) || (N % kT256) || !(taps & 1) || taps > 15) return false;
+  if ((size_t)M * Cin * EB >= kOob || (size_t)N * taps * Cin * EB >= kOob) return false;  // 32-bit buffer offsets
   Conv256Args g;
-  g.x = static_cast<const bf16*>(x); g.w = static_cast<const bf16*>(w); g.alpha = alpha; g.beta = beta; g.out = static_cast<bf16*>(out);
+  g.x = x; g.w = w; g.alpha = alpha; g.beta = beta; g.out = out;
   g.M = M; g.T = T; g.Cin = Cin; g.taps = taps; g.N = N;
   g.n_row_tiles = (M + kT256 - 1) / kT256; g.n_col_tiles = N / kT256;
   const int groups = (g.n_row_tiles + 7) / 8;
-  hipLaunchKernelGGL(conv256_bf16_kernel<ABL>, dim3((unsigned)(groups * 8 * g.n_col_tiles)), dim3(kThreads256), 0, st, g);
+  hipLaunchKernelGGL((conv256_kernel<ABL, kF32>), dim3((unsigned)(groups * 8 * g.n_col_tiles)), dim3(kThreads256), 0, st, g);
   return true;
 }
 bool launch_conv256_bf16(const void* x, const void* w, const float* alpha, const float* beta, void* out, int M, int T, int Cin, int taps, int N,
                          hipStream_t st) {
-  return launch_conv256_abl<0>(x, w, alpha, beta, out, M, T, Cin, taps, N, st);
+  return launch_conv256_abl<0, false>(x, w, alpha, beta, out, M, T, Cin, taps, N, st);
+}
+bool launch_conv256_f32(const float* x, const float* w, const float* alpha, const float* beta, float* out, int M, int T, int Cin, int taps, int N,
+                        hipStream_t st) {
+  return launch_conv256_abl<0, true>(x, w, alpha, beta, out, M, T, Cin, taps, N, st);
 }
 
 }  // namespace ttsdec

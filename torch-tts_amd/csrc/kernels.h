@@ -303,6 +303,9 @@ void launch_to_bf16(const float* src, void* dst, size_t n, hipStream_t st);
 // false = not that kernel's shape (Cin % 64, N % 256, odd taps, 32-bit offsets): the caller keeps the shared GEMM
 bool launch_conv256_bf16(const void* x, const void* w, const float* alpha, const float* beta, void* out, int M, int T, int Cin, int taps, int N,
                          hipStream_t st);
+// ... and the same in exact fp32 (x, w, out fp32; Cin % 32)
+bool launch_conv256_f32(const float* x, const float* w, const float* alpha, const float* beta, float* out, int M, int T, int Cin, int taps, int N,
+                        hipStream_t st);
 // *out = max(*out, max |src[i]|)  (*out must hold a non-negative float, e.g. 0)
 void launch_absmax(const float* src, size_t n, float* out, hipStream_t st);
 // out_a[m, 0:E] (ld lda) and out_b[m, 0:E] (ld ldb) = table[ids[m], :]   (nn.Embedding lookup)
