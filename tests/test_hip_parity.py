@@ -2,6 +2,8 @@
 (a) golden vectors produced by the reference itself and (b) the CPU oracle on the same
 seeded inputs.  Tolerance (BASELINE.json north_star): mel / stop logits within 1e-4
 relative (atol 1e-5 for values near zero), attention argmax indices bit-exact."""
+import os
+
 import pytest
 import torch
 
@@ -545,11 +547,33 @@ def test_postnet_bf16_vs_its_own_rounding_emulated_on_the_cpu(H, B, T):
     ref = y + torch.nn.functional.linear(xc.transpose(1, 2), rb(pw["fc_out.weight"]))
     pn = H.make_postnet(80, 512, 3, pw)
     pn.precision = "bf16"
-    with torch.no_grad():
-        out = pn(y.cuda()).cpu()
+    os.environ["TTSDEC_CONV256_FORCE"] = "1"  # (the library takes that kernel only where its tiles fill the chip: csrc/conv256.hip)
+    try:
+        with torch.no_grad():
+            out = pn(y.cuda()).cpu()
+    finally:
+        del os.environ["TTSDEC_CONV256_FORCE"]
     err = float((out - ref).abs().max())
     print(f"postnet bf16 vs bf16 emulation, B = {B}, T = {T}: max abs err {err:.3e}")
     assert err < 8e-3, err  # (the shared tile and the 256-wide kernel both measure 2e-3 ... 5e-3 here; a leaked tap is >= 5e-2)
+
+
+@pytest.mark.parametrize("B,T", [(5, 131), (3, 600), (1, 257)])
+def test_postnet_fp32_on_the_256_wide_conv_kernel_vs_oracle(H, B, T):
+    """The exact-fp32 form of csrc/conv256.hip (the hidden -> hidden layers of the headline's Postnet) against the oracle at the
+    fp32 bar, forced at shapes the oracle finishes in seconds: utterance edges inside 256-row tiles, a ragged last tile."""
+    pw = O.random_postnet_weights(80, 512, 3, seed=9)
+    g = torch.Generator().manual_seed(2)
+    y = torch.randn(B, T, 80, generator=g)
+    ref = O.mel_postnet(y, pw, 3)
+    pn = H.make_postnet(80, 512, 3, pw)
+    os.environ["TTSDEC_CONV256_FORCE"] = "1"
+    try:
+        with torch.no_grad():
+            out = pn(y.cuda()).cpu()
+    finally:
+        del os.environ["TTSDEC_CONV256_FORCE"]
+    H.assert_close(out, ref, RTOL, ATOL, "postnet fp32 (conv256)")
 
 
 def test_philox_mode_matches_oracle_masks(H):

@@ -67,7 +67,7 @@ static int run(int B, int T, int Cin, int taps, int N, int reps) {
   fill_f32<<<(N + 255) / 256, 256>>>(beta, N, 4u, -0.3f, 0.3f);
   CK(hipMemset(out, 0xff, no * 2));
   CK(hipDeviceSynchronize());
-  if (!launch_conv256_bf16(x, w, alpha, beta, out, M, T, Cin, taps, N, nullptr)) { printf("shape refused\n"); return 1; }
+  if (!launch_conv256_abl<5, false>(x, w, alpha, beta, out, M, T, Cin, taps, N, nullptr)) { printf("shape refused\n"); return 1; }
   CK(hipDeviceSynchronize());
   // rows to check: utterance edges, tile edges, a spread of others
   std::vector<int> rows;
@@ -95,9 +95,9 @@ static int run(int B, int T, int Cin, int taps, int N, int reps) {
     }
   hipEvent_t e0, e1;
   CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
-  for (int i = 0; i < 3; ++i) launch_conv256_bf16(x, w, alpha, beta, out, M, T, Cin, taps, N, nullptr);
+  for (int i = 0; i < 3; ++i) launch_conv256_abl<5, false>(x, w, alpha, beta, out, M, T, Cin, taps, N, nullptr);
   CK(hipEventRecord(e0));
-  for (int i = 0; i < reps; ++i) launch_conv256_bf16(x, w, alpha, beta, out, M, T, Cin, taps, N, nullptr);
+  for (int i = 0; i < reps; ++i) launch_conv256_abl<5, false>(x, w, alpha, beta, out, M, T, Cin, taps, N, nullptr);
   CK(hipEventRecord(e1));
   CK(hipEventSynchronize(e1));
   float ms;
@@ -155,7 +155,7 @@ static int run_f32(int B, int T, int Cin, int taps, int N, int reps) {
   fill_f32<<<(N + 255) / 256, 256>>>(beta, N, 4u, -0.3f, 0.3f);
   CK(hipMemset(out, 0xff, no * 4));
   CK(hipDeviceSynchronize());
-  if (!launch_conv256_f32(x, w, alpha, beta, out, M, T, Cin, taps, N, nullptr)) { printf("shape refused\n"); return 1; }
+  if (!launch_conv256_abl<5, true>(x, w, alpha, beta, out, M, T, Cin, taps, N, nullptr)) { printf("shape refused\n"); return 1; }
   CK(hipDeviceSynchronize());
   std::vector<int> rows;
   for (int r : {0, 1, 2, 3, T - 3, T - 2, T - 1, T, T + 1, 255, 256, 257, M - 1, M - 2, M - 3, M - T, M - T - 1}) if (r >= 0 && r < M) rows.push_back(r);
@@ -178,9 +178,9 @@ static int run_f32(int B, int T, int Cin, int taps, int N, int reps) {
     }
   hipEvent_t e0, e1;
   CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
-  for (int i = 0; i < 2; ++i) launch_conv256_f32(x, w, alpha, beta, out, M, T, Cin, taps, N, nullptr);
+  for (int i = 0; i < 2; ++i) launch_conv256_abl<5, true>(x, w, alpha, beta, out, M, T, Cin, taps, N, nullptr);
   CK(hipEventRecord(e0));
-  for (int i = 0; i < reps; ++i) launch_conv256_f32(x, w, alpha, beta, out, M, T, Cin, taps, N, nullptr);
+  for (int i = 0; i < reps; ++i) launch_conv256_abl<5, true>(x, w, alpha, beta, out, M, T, Cin, taps, N, nullptr);
   CK(hipEventRecord(e1));
   CK(hipEventSynchronize(e1));
   float ms;

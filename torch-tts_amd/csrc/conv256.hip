@@ -56,7 +56,8 @@ __device__ __forceinline__ void wait_vm() {
   asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
 }
 
-// ABL (tools/ubench_conv256.hip only): 1 = no DMA inside the loop, 2 = no MFMAs, 3 = DMA only, 4 = DMA without the vmcnt waits
+// ABL (tools/ubench_conv256.hip only): 1 = no DMA inside the loop, 2 = no MFMAs, 3 = DMA only, 4 = DMA without the vmcnt waits,
+// 5 = the kernel as shipped, launched whatever the tile count
 // kF32: exact fp32 operands on v_mfma_f32_32x32x2_f32 (32 k per step, fp32 output) instead of bf16 on v_mfma_f32_32x32x16_bf16
 // (64 k per step, bf16 output); same tile, ring and schedule
 template <int ABL, bool kF32>
@@ -290,6 +291,21 @@ static bool launch_conv256_abl(const void* x, const void* w, const float* alpha,
   g.x = x; g.w = w; g.alpha = alpha; g.beta = beta; g.out = out;
   g.M = M; g.T = T; g.Cin = Cin; g.taps = taps; g.N = N;
   g.n_row_tiles = (M + kT256 - 1) / kT256; g.n_col_tiles = N / kT256;
+  // One workgroup per CU and whole rounds of tiles: the schedule pays where the tiles fill their rounds.  Its advantage over the
+  // shared tile is 9-12 % per layer at 1 200 tiles on 256 CUs (4.7 rounds, 0.94 full); below ~0.86 the shared tile - hundreds of
+  // small tiles, no rounds to speak of - is the faster one (one utterance: 6 tiles here, 0.6 ms a layer against 0.04).
+  {
+    static const int cus = [] {
+      int dev = 0, n = 0;
+      if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) { (void)hipGetLastError(); n = 0; }
+      return n;
+    }();
+    const long tiles = (long)g.n_row_tiles * g.n_col_tiles;
+    if (cus <= 0) return false;
+    const long rounds = (tiles + cus - 1) / cus;
+    const char* force = getenv("TTSDEC_CONV256_FORCE");  // (tests: the kernel's edge cases at shapes a CPU oracle finishes in seconds)
+    if (ABL == 0 && !(force && force[0] == '1') && tiles * 100 < 86 * rounds * cus) return false;
+  }
   const int groups = (g.n_row_tiles + 7) / 8;
   hipLaunchKernelGGL((conv256_kernel<ABL, kF32>), dim3((unsigned)(groups * 8 * g.n_col_tiles)), dim3(kThreads256), 0, st, g);
   return true;
