@@ -174,9 +174,12 @@ int ttsdec_get_precision(const ttsdec_handle* h);
  * option drops the handle's captured graph.  MEASUREMENT ONLY - not part of the drop-in surface.
  * The environment variable TTSDEC_OPTIONS="name=value,name=value" (names below, lower case without the prefix) presets
  * the options of every handle created afterwards; it is read once per ttsdec_create.  The only other environment
- * variables the library reads, both measurement-only as well: TTSDEC_STAMPS=<file> (per-workgroup time stamps of the
- * two-role launches of a decode call's last step, written to <file>; synchronises the stream) and
- * TTSDEC_NO_LEAN_SKINNY=1 (short-K row GEMMs of the VITS2 path back on the 128 x 128 tile). */
+ * variables the library reads, all measurement-only as well: TTSDEC_STAMPS=<file> (per-workgroup time stamps of the
+ * two-role launches of a decode call's last step, written to <file>; synchronises the stream),
+ * TTSDEC_NO_LEAN_SKINNY=1 (short-K row GEMMs of the VITS2 path back on the 128 x 128 tile), TTSDEC_LEAN8_F32_MAX=<rows>
+ * (largest batch on the 32-row exact-fp32 LSTM tile), TTSDEC_CONV256=0 (the Postnet's hidden conv layers back on the
+ * shared GEMM tile) and TTSDEC_CONV256_FORCE=1 (those layers on the 256 x 256 kernel even where its tiles do not fill
+ * the chip - the tests' switch). */
 enum {
   TTSDEC_OPT_GRAPH = 0,        /* "graph": 0 = launch every step kernel from the host instead of replaying a captured hipGraph  */
   TTSDEC_OPT_OVERLAP,          /* "overlap": two-role launches 0 = none, 1 = frame || lstm_att, 2 = also attention || lstm_dec;
