@@ -71,7 +71,7 @@ static int run(int B, int T, int Cin, int taps, int N, int reps) {
   CK(hipDeviceSynchronize());
   // rows to check: utterance edges, tile edges, a spread of others
   std::vector<int> rows;
-  for (int r : {0, 1, 2, 3, T - 3, T - 2, T - 1, T, T + 1, 255, 256, 257, M - 1, M - 2, M - 3, M - T, M - T - 1}) if (r >= 0 && r < M) rows.push_back(r);
+  for (int r : {0, 1, 2, 3, T - 3, T - 2, T - 1, T, T + 1, 255, 256, 257, M - 1, M - 2, M - 3, M - T, M - T - 1, 131071, 131072, 131073, 131072 + 95, 131072 + 96, 131072 + 175, 131072 + 176, 131072 + 177, 131072 + 351, 131072 + 352}) if (r >= 0 && r < M) rows.push_back(r);
   for (int k = 0; k < 200; ++k) rows.push_back((int)(((long long)k * 7919 * 131 + 17) % M));
   int* drows; float* dref;
   CK(hipMalloc(&drows, rows.size() * 4)); CK(hipMalloc(&dref, rows.size() * N * 4));
@@ -158,7 +158,7 @@ static int run_f32(int B, int T, int Cin, int taps, int N, int reps) {
   if (!launch_conv256_abl<5, true>(x, w, alpha, beta, out, M, T, Cin, taps, N, nullptr)) { printf("shape refused\n"); return 1; }
   CK(hipDeviceSynchronize());
   std::vector<int> rows;
-  for (int r : {0, 1, 2, 3, T - 3, T - 2, T - 1, T, T + 1, 255, 256, 257, M - 1, M - 2, M - 3, M - T, M - T - 1}) if (r >= 0 && r < M) rows.push_back(r);
+  for (int r : {0, 1, 2, 3, T - 3, T - 2, T - 1, T, T + 1, 255, 256, 257, M - 1, M - 2, M - 3, M - T, M - T - 1, 131071, 131072, 131073, 131072 + 95, 131072 + 96, 131072 + 175, 131072 + 176, 131072 + 177, 131072 + 351, 131072 + 352}) if (r >= 0 && r < M) rows.push_back(r);
   for (int k = 0; k < 200; ++k) rows.push_back((int)(((long long)k * 7919 * 131 + 17) % M));
   int* drows; float* dref;
   CK(hipMalloc(&drows, rows.size() * 4)); CK(hipMalloc(&dref, rows.size() * N * 4));

@@ -49,6 +49,7 @@ struct Conv256Args {
   void* out;
   int M, T, Cin, taps, N;
   int n_row_tiles, n_col_tiles;
+  int m_base, rows_t;  // this launch's first frame and the rows of its tiles (256, or fewer for the tiles of a last, partial round)
 };
 
 template <int N>
@@ -60,7 +61,8 @@ __device__ __forceinline__ void wait_vm() {
 // 5 = the kernel as shipped, launched whatever the tile count
 // kF32: exact fp32 operands on v_mfma_f32_32x32x2_f32 (32 k per step, fp32 output) instead of bf16 on v_mfma_f32_32x32x16_bf16
 // (64 k per step, bf16 output); same tile, ring and schedule
-template <int ABL, bool kF32>
+// NMT: 32-row MFMA blocks per wave (4 = whole 256-row tiles; the tiles of a last partial round have 1 ... 3: launch_conv256_abl)
+template <int ABL, bool kF32, int NMT>
 __global__ __launch_bounds__(kThreads256, 2) void conv256_kernel(Conv256Args g) {
   constexpr int EB = kF32 ? 4 : 2;          // operand element bytes
   constexpr int kBK = kRowB / EB;            // k per step
@@ -70,7 +72,8 @@ __global__ __launch_bounds__(kThreads256, 2) void conv256_kernel(Conv256Args g) 
   const int id = blockIdx.x, xcd = id & 7, j = id >> 3;
   const int ct = j % g.n_col_tiles, rt = (j / g.n_col_tiles) * 8 + xcd;
   if (rt >= g.n_row_tiles) return;
-  const int m0 = rt * kT256, n0 = ct * kT256;
+  const int m0 = g.m_base + rt * g.rows_t, n0 = ct * kT256;
+  const int m_end = (m0 + g.rows_t < g.M) ? m0 + g.rows_t : g.M;  // one past the tile's last frame
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wr = wave >> 2, wc = wave & 3;
   const int K = g.taps * g.Cin, pad = g.taps / 2, steps_per_tap = g.Cin / kBK, nk = g.taps * steps_per_tap;
@@ -103,7 +106,7 @@ __global__ __launch_bounds__(kThreads256, 2) void conv256_kernel(Conv256Args g) 
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
       const int tt = a_t[i] + tap - pad;
-      const bool ok = a_m[i] < g.M && tt >= 0 && tt < g.T;
+      const bool ok = a_m[i] < m_end && tt >= 0 && tt < g.T;
       a_off[i] = ok ? (unsigned)(a_m[i] + tap - pad) * (unsigned)g.Cin * (unsigned)EB + a_cb[i] : kOob;
     }
   };
@@ -141,13 +144,13 @@ __global__ __launch_bounds__(kThreads256, 2) void conv256_kernel(Conv256Args g) 
   // address of k16 step ks is the one of step 0 with bits 5-6 flipped by ks (the swizzle only XORs the chunk index)
   unsigned fa0, fb0;
   {
-    const int ra = wr * 128 + (lane & 31), rb = wc * 64 + (lane & 31);
+    const int ra = wr * (NMT * 32) + (lane & 31), rb = wc * 64 + (lane & 31);
     fa0 = (unsigned)ra * 128u + (unsigned)(((lane >> 5) ^ ((ra >> 1) & 7)) * 16);
     fb0 = (unsigned)rb * 128u + (unsigned)(((lane >> 5) ^ ((rb >> 1) & 7)) * 16);
   }
-  f32x16 acc[4][2];
+  f32x16 acc[NMT][2];
 #pragma unroll
-  for (int mt = 0; mt < 4; ++mt)
+  for (int mt = 0; mt < NMT; ++mt)
 #pragma unroll
     for (int nt = 0; nt < 2; ++nt)
 #pragma unroll
@@ -162,7 +165,7 @@ __global__ __launch_bounds__(kThreads256, 2) void conv256_kernel(Conv256Args g) 
   // NEXT step go first (they are needed one step from now), then the weights of the step after it.
   // (fp32: a fragment register set is 4 consecutive k per lane group, i.e. MFMA e of a read takes k pair (e, 4 + e) of its 8 - a
   // permutation of k that both operands share)
-  f32x4 a0[4] = {}, b0[2] = {}, a1[4] = {}, b1[2] = {};
+  f32x4 a0[NMT] = {}, b0[2] = {}, a1[NMT] = {}, b1[2] = {};
   // prologue: B(0), A(0), B(1)
   for (int i = 0; i < 4; ++i) issue_b(i);
   next_b();
@@ -171,7 +174,7 @@ __global__ __launch_bounds__(kThreads256, 2) void conv256_kernel(Conv256Args g) 
   for (int i = 0; i < 4; ++i) issue_b(i);
   next_b();
 #define TTSDEC_MFMA4(A, B, mt0)                                                                                                      \
-  _Pragma("unroll") for (int mt = mt0; mt < mt0 + 2; ++mt) _Pragma("unroll") for (int nt = 0; nt < 2; ++nt) {                          \
+  _Pragma("unroll") for (int mt = mt0; mt < mt0 + 2 && mt < NMT; ++mt) _Pragma("unroll") for (int nt = 0; nt < 2; ++nt) {               \
     if (ABL == 2 || ABL == 3) asm volatile("" ::"v"(A[mt]), "v"(B[nt]));                                                                        \
     else if constexpr (kF32) {                                                                                                        \
       _Pragma("unroll") for (int e = 0; e < 4; ++e) acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(A[mt][e], B[nt][e], acc[mt][nt], 0, 0, 0); \
@@ -180,7 +183,7 @@ __global__ __launch_bounds__(kThreads256, 2) void conv256_kernel(Conv256Args g) 
     }                                                                                                                                 \
   }
 #define TTSDEC_READS(A, B, ks)                                                                                                       \
-  _Pragma("unroll") for (int mt = 0; mt < 4; ++mt) if (ABL != 3) A[mt] = *reinterpret_cast<const f32x4*>(sa + (fa0 ^ ((ks) << 5)) + mt * 4096); \
+  _Pragma("unroll") for (int mt = 0; mt < NMT; ++mt) if (ABL != 3) A[mt] = *reinterpret_cast<const f32x4*>(sa + (fa0 ^ ((ks) << 5)) + mt * 4096); \
   _Pragma("unroll") for (int nt = 0; nt < 2; ++nt) if (ABL != 3) B[nt] = *reinterpret_cast<const f32x4*>(sb + (fb0 ^ ((ks) << 5)) + nt * 4096)
 #define TTSDEC_FENCE() __builtin_amdgcn_sched_barrier(0)
   in_loop = true;
@@ -237,21 +240,21 @@ __global__ __launch_bounds__(kThreads256, 2) void conv256_kernel(Conv256Args g) 
     // ---- epilogue, fp32: BN (folded) + isru, stored straight from the accumulators (a store instruction = two rows x 128 bytes) ----
     float* out = static_cast<float*>(g.out);
 #pragma unroll
-    for (int mt = 0; mt < 4; ++mt)
+    for (int mt = 0; mt < NMT; ++mt)
 #pragma unroll
       for (int nt = 0; nt < 2; ++nt)
 #pragma unroll
         for (int e = 0; e < 16; ++e) {
-          const int m = m0 + wr * 128 + mt * 32 + (e & 3) + 8 * (e >> 2) + 4 * (lane >> 5);
+          const int m = m0 + (wr * NMT + mt) * 32 + (e & 3) + 8 * (e >> 2) + 4 * (lane >> 5);
           const int n = n0 + wc * 64 + nt * 32 + (lane & 31);
           const float v = isru_fast(add_rn(mul_rn(acc[mt][nt][e], al[nt]), be[nt]));  // (as decode_kernels.hip EPI_BN_ISRU)
-          if (m < g.M) out[(size_t)m * g.N + n] = v;
+          if (m < m_end) out[(size_t)m * g.N + n] = v;
         }
   } else {
   // ---- epilogue: BN (folded) + isru, to bf16, through this wave's 16 KiB of LDS so that the stores are whole 16-byte pieces ----
-  char* ow = smem + wave * 16384;  // [128 rows][64 columns] bf16
+  char* ow = smem + wave * 16384;  // [NMT * 32 rows][64 columns] bf16
 #pragma unroll
-  for (int mt = 0; mt < 4; ++mt)
+  for (int mt = 0; mt < NMT; ++mt)
 #pragma unroll
     for (int nt = 0; nt < 2; ++nt)
 #pragma unroll
@@ -265,11 +268,11 @@ __global__ __launch_bounds__(kThreads256, 2) void conv256_kernel(Conv256Args g) 
   // (each wave reads back only what it wrote itself: no barrier, the compiler's lgkmcnt wait orders the LDS accesses)
   typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 #pragma unroll
-  for (int it = 0; it < 16; ++it) {
+  for (int it = 0; it < 4 * NMT; ++it) {
     const int q = it * 64 + lane, row = q >> 3, cc = q & 7;
-    const int m = m0 + wr * 128 + row;
+    const int m = m0 + wr * (NMT * 32) + row;
     const u32x4 v = *reinterpret_cast<const u32x4*>(ow + row * 128 + cc * 16);
-    if (m < g.M) *reinterpret_cast<u32x4*>(reinterpret_cast<char*>(g.out) + ((size_t)m * g.N + n0 + wc * 64) * 2 + cc * 16) = v;
+    if (m < m_end) *reinterpret_cast<u32x4*>(reinterpret_cast<char*>(g.out) + ((size_t)m * g.N + n0 + wc * 64) * 2 + cc * 16) = v;
   }
   }
 }
@@ -279,6 +282,14 @@ __global__ __launch_bounds__(kThreads256, 2) void conv256_kernel(Conv256Args g) 
 #undef TTSDEC_FENCE
 
 }  // namespace
+
+// one launch: `n_rt` row tiles of `rows_t` rows (NMT 32-row blocks per wave) from frame `m_base`
+template <int ABL, bool kF32, int NMT>
+static void launch_conv256_tiles(Conv256Args g, int m_base, int rows_t, int n_rt, hipStream_t st) {
+  g.m_base = m_base; g.rows_t = rows_t; g.n_row_tiles = n_rt;
+  const int groups = (n_rt + 7) / 8;
+  hipLaunchKernelGGL((conv256_kernel<ABL, kF32, NMT>), dim3((unsigned)(groups * 8 * g.n_col_tiles)), dim3(kThreads256), 0, st, g);
+}
 
 // false: the shape is not this kernel's (the caller keeps the shared GEMM)
 template <int ABL, bool kF32>
@@ -290,24 +301,42 @@ static bool launch_conv256_abl(const void* x, const void* w, const float* alpha,
   Conv256Args g;
   g.x = x; g.w = w; g.alpha = alpha; g.beta = beta; g.out = out;
   g.M = M; g.T = T; g.Cin = Cin; g.taps = taps; g.N = N;
-  g.n_row_tiles = (M + kT256 - 1) / kT256; g.n_col_tiles = N / kT256;
-  // One workgroup per CU and whole rounds of tiles: the schedule pays where the tiles fill their rounds.  Its advantage over the
-  // shared tile is 9-12 % per layer at 1 200 tiles on 256 CUs (4.7 rounds, 0.94 full); below ~0.86 the shared tile - hundreds of
-  // small tiles, no rounds to speak of - is the faster one (one utterance: 6 tiles here, 0.6 ms a layer against 0.04).
-  {
-    static const int cus = [] {
-      int dev = 0, n = 0;
-      if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) { (void)hipGetLastError(); n = 0; }
-      return n;
-    }();
-    const long tiles = (long)g.n_row_tiles * g.n_col_tiles;
-    if (cus <= 0) return false;
-    const long rounds = (tiles + cus - 1) / cus;
-    const char* force = getenv("TTSDEC_CONV256_FORCE");  // (tests: the kernel's edge cases at shapes a CPU oracle finishes in seconds)
-    if (ABL == 0 && !(force && force[0] == '1') && tiles * 100 < 86 * rounds * cus) return false;
+  g.n_col_tiles = N / kT256;
+  static const int cus = [] {
+    int dev = 0, n = 0;
+    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) { (void)hipGetLastError(); n = 0; }
+    return n;
+  }();
+  if (cus <= 0) return false;
+  // One workgroup per CU and whole ROUNDS of tiles.  The row tiles of the whole rounds are one launch; what is left is cut into one
+  // more round of SHORT tiles - h rows each, ceil(h / 64) of the four 32-row MFMA blocks per wave, their own instantiation - so
+  // that 4.7 rounds cost 4.75, not 5 (the same kernel with the block count as a run-time predicate lost what this wins).
+  const int n_rt = (M + kT256 - 1) / kT256, slots = cus / g.n_col_tiles > 0 ? cus / g.n_col_tiles : 1;
+  const int full = (n_rt / slots) * slots;        // row tiles of the whole rounds
+  const int rem = M - full * kT256;               // rows left for the last round (<= 0: none)
+  int h = 0, nmt = 0, n_short = 0;
+  if (rem > 0) {
+    h = (rem + slots - 1) / slots;
+    h = (h + 7) & ~7;                             // (whole 8-row DMA groups)
+    nmt = (h + 63) >> 6;
+    n_short = (rem + h - 1) / h;
   }
-  const int groups = (g.n_row_tiles + 7) / 8;
-  hipLaunchKernelGGL((conv256_kernel<ABL, kF32>), dim3((unsigned)(groups * 8 * g.n_col_tiles)), dim3(kThreads256), 0, st, g);
+  // The schedule pays where its rounds are full: its advantage over the shared tile is 9-12 % per layer; below ~0.86 of the ideal
+  // the shared tile - hundreds of small tiles, no rounds to speak of - is the faster one (one utterance: 6 tiles here, 0.6 ms a
+  // layer against 0.04).
+  {
+    const double ideal = (double)M / kT256 / slots, cost = (double)(full / slots) + (rem > 0 ? nmt / 4.0 : 0.0);
+    const char* force = getenv("TTSDEC_CONV256_FORCE");  // (tests: the kernel's edge cases at shapes a CPU oracle finishes in seconds)
+    if (ABL == 0 && !(force && force[0] == '1') && ideal < 0.86 * cost) return false;
+  }
+  if (full > 0) launch_conv256_tiles<ABL, kF32, 4>(g, 0, kT256, full, st);
+  if (rem > 0) {
+    const int mb = full * kT256;
+    if (nmt >= 4) launch_conv256_tiles<ABL, kF32, 4>(g, mb, h, n_short, st);
+    else if (nmt == 3) launch_conv256_tiles<ABL, kF32, 3>(g, mb, h, n_short, st);
+    else if (nmt == 2) launch_conv256_tiles<ABL, kF32, 2>(g, mb, h, n_short, st);
+    else launch_conv256_tiles<ABL, kF32, 1>(g, mb, h, n_short, st);
+  }
   return true;
 }
 bool launch_conv256_bf16(const void* x, const void* w, const float* alpha, const float* beta, void* out, int M, int T, int Cin, int taps, int N,
