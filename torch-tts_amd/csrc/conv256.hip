@@ -17,6 +17,9 @@
 // stored straight from the accumulators) serves the fp32 Postnet: there the matrix pipe binds and the gain is the loop's (0.91 of
 // the instruction's rate against ~0.84 for the shared 64 x 64 tile).
 //
+// Rounds: one workgroup per CU means whole rounds of tiles; what the whole rounds leave is one more launch of SHORT tiles (NMT < 4
+// 32-row MFMA blocks per wave), and the library takes the kernel only where that pays (launch_conv256_abl).
+//
 // Operands: x [M = B * T, Cin] bf16, channel-last, so the im2col row of frame m is the contiguous window of `taps` frames
 // around it; a K step is 64 channels of one tap: tile row r reads frame m0 + r + tap - taps/2 of the SAME utterance or zeros
 // (buffer loads with an out-of-range offset write zeros to LDS - gemm_tile.h make_rsrc).  w [N, taps * Cin] bf16 (k = tap * Cin
@@ -35,7 +38,7 @@ namespace {
 constexpr int kT256 = 256;                     // tile rows = tile columns
 constexpr int kRowB = 128;                     // bytes of a row piece per step: whole cache lines (64 bf16 or 32 fp32 of k)
 constexpr int kSlot = kT256 * kRowB;           // one operand's bytes per step (32 KiB)
-constexpr int kSlots = 5;                      // ring of operand slots: A(s), B(s), A(s + 1), B(s + 1), A(s + 2) = 160 KiB
+constexpr int kSlots = 5;                      // ring of operand slots: B(s), A(s), B(s + 1), A(s + 1), B(s + 2) = 160 KiB
 constexpr int kThreads256 = 512;
 constexpr unsigned kOob = 0x7FFFF000u;         // (gemm_tile.h kBufRange: an offset no buffer reaches -> the lane's 16 bytes are zeros)
 
